@@ -1,0 +1,8 @@
+"""astar-pairwise-aligner_amd -- MI355X-native drop-in for the bit-parallel block-DP hot path of
+RagnarGrootKoerkamp/astar-pairwise-aligner (pa-bitpacking + the astarpa2 block engine).
+
+The compute path is hand-written HIP for gfx950 in libastarpa_c_hip.so (built in-tree from csrc/);
+this package is the thin host-side mirror of the reference's interfaces.  No CPU fallback exists.
+"""
+from . import _build, capi, generate  # noqa: F401
+from .capi import Batch, PaError, compute, fill, profile_build, require_gpu  # noqa: F401

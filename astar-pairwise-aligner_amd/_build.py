@@ -1,0 +1,44 @@
+"""Build the in-tree HIP shared library (gfx950 only; hipcc cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC = PKG_DIR / "csrc"
+LIB_PATH = PKG_DIR / "libastarpa_c_hip.so"
+
+HIP_SOURCES = ["pa_hip.hip", "engine_hip.hip", "astarpa_c.hip"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X library cannot be built")
+
+
+def sources() -> list[Path]:
+    return [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()]
+
+
+def is_stale() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    t = LIB_PATH.stat().st_mtime
+    deps = list(CSRC.glob("*")) + list((PKG_DIR.parent / "include").glob("*.h"))
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """hipcc --offload-arch=gfx950 -> libastarpa_c_hip.so next to this file."""
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I", str(PKG_DIR.parent / "include"), "-o", str(LIB_PATH)] + [str(s) for s in sources()]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH

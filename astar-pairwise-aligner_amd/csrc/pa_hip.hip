@@ -1,0 +1,491 @@
+// pa_hip.hip -- host side of libastarpa_c_hip.so: device buffers, strip planning, the operator
+// C ABI (include/pa_bitpacking_hip.h) and the batched full-DP plan.  gfx950 only.
+#include "pa_hip_internal.hpp"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace pa {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+bool hip_ok(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    set_error("HIP error in %s: %s", what, hipGetErrorString(e));
+    return false;
+}
+
+// ---- device kernels: profile building ---------------------------------------------------------
+
+// rank in "ACGT" (bio RankTransform as used by BitProfile::build, profile.rs:113); -1 otherwise
+__device__ __forceinline__ int rank_acgt(uint8_t c) {
+    return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
+}
+
+// One thread per 16 columns: ASCII -> packed 2-bit codes.
+__global__ void encode_a_kernel(const uint8_t* __restrict__ a, int n, uint32_t* __restrict__ codes, int nwords,
+                                uint32_t* __restrict__ bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwords) return;
+    uint32_t w = 0;
+    bool invalid = false;
+    for (int k = 0; k < 16; ++k) {
+        const int c = i * 16 + k;
+        if (c < n) {
+            const int r = rank_acgt(a[c]);
+            invalid |= r < 0;
+            w |= (uint32_t)(r & 3) << (2 * k);
+        }
+    }
+    codes[i] = w;
+    if (invalid) atomicOr(bad, 1u);
+}
+
+// One wave per 64-row word: negated bit-planes via ballot; rows >= m stay (0,0) (profile.rs:127-132).
+__global__ void build_b_kernel(const uint8_t* __restrict__ b, int m, uint64_t* __restrict__ prof, int nwords,
+                               uint32_t* __restrict__ bad) {
+    const int word = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (word >= nwords) return;
+    const int lane = threadIdx.x & 63;
+    const int j = word * 64 + lane;
+    int r = 3;  // (r&1)^1 == 0 and ((r>>1)&1)^1 == 0 => pad rows contribute 0 bits
+    bool invalid = false;
+    if (j < m) {
+        r = rank_acgt(b[j]);
+        invalid = r < 0;
+        r &= 3;
+    }
+    const uint64_t nb0 = __ballot(((r & 1) ^ 1) != 0);
+    const uint64_t nb1 = __ballot((((r >> 1) & 1) ^ 1) != 0);
+    if (lane == 0) {
+        prof[2 * word] = nb0;
+        prof[2 * word + 1] = nb1;
+    }
+    if (invalid) atomicOr(bad, 1u);
+}
+
+template __global__ void strip_kernel<false>(const StripJob*, int, uint32_t*, uint32_t*);
+template __global__ void strip_kernel<true>(const StripJob*, int, uint32_t*, uint32_t*);
+
+// ---- device context -----------------------------------------------------------------------------
+
+int g_device_props_cus = 0;
+
+bool ensure_device() {
+    static thread_local bool inited = false;
+    if (inited) return true;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) {
+        set_error("no HIP device available: the MI355X path is required (there is no CPU fallback)");
+        return false;
+    }
+    int dev = 0;
+    if (!hip_ok(hipGetDevice(&dev), "hipGetDevice")) return false;
+    hipDeviceProp_t prop;
+    if (!hip_ok(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties")) return false;
+    g_device_props_cus = prop.multiProcessorCount;
+    inited = true;
+    return true;
+}
+
+bool DeviceBuf::alloc(size_t bytes) {
+    release();
+    if (bytes == 0) bytes = 16;
+    if (!hip_ok(hipMalloc(&ptr, bytes), "hipMalloc")) {
+        ptr = nullptr;
+        return false;
+    }
+    size = bytes;
+    return true;
+}
+void DeviceBuf::release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    size = 0;
+}
+
+bool encode_a_device(const uint8_t* d_a, int n, uint32_t* d_codes, uint32_t* d_bad, hipStream_t s) {
+    const int nwords = (n + 15) / 16;
+    if (nwords == 0) return true;
+    hipLaunchKernelGGL(encode_a_kernel, dim3((nwords + 255) / 256), dim3(256), 0, s, d_a, n, d_codes, nwords, d_bad);
+    return hip_ok(hipGetLastError(), "encode_a_kernel");
+}
+
+bool build_b_device(const uint8_t* d_b, int m, uint64_t* d_prof, uint32_t* d_bad, hipStream_t s) {
+    const int nwords = (m + 63) / 64;
+    if (nwords == 0) return true;
+    hipLaunchKernelGGL(build_b_kernel, dim3((nwords + 3) / 4), dim3(256), 0, s, d_b, m, d_prof, nwords, d_bad);
+    return hip_ok(hipGetLastError(), "build_b_kernel");
+}
+
+// Plan the chained strips of one rectangle: words [w0, w1) x n columns.
+void plan_rect(std::vector<StripJob>& jobs, const RectPlan& r) {
+    const int w = r.w1 - r.w0;
+    const int S = (w + kWordsPerStrip - 1) / kWordsPerStrip;
+    for (int s = 0; s < S; ++s) {
+        StripJob j;
+        std::memset(&j, 0, sizeof j);
+        j.a_codes = r.a_codes;
+        j.b_prof = r.b_prof;
+        j.v = r.v;
+        j.n = r.n;
+        j.word0 = r.w0 + s * kWordsPerStrip;
+        const int words = std::min(kWordsPerStrip, w - s * kWordsPerStrip);
+        j.nlanes = 2 * words;
+        j.flags = r.v_init_one ? kJobVInitOne : 0;
+        if (s == 0) {
+            j.hin_arr = r.hin_arr;  // nullptr => +1
+        } else {
+            j.hin_gran = r.gran + (size_t)(s - 1) * r.gran_stride;
+        }
+        if (s + 1 < S) {
+            j.hout_gran = r.gran + (size_t)s * r.gran_stride;
+            j.exact_tail = 1;  // full strips anyway
+        } else {
+            j.hout_arr = r.hout_arr;
+            j.sum_out = r.sum_out;
+            j.exact_tail = (r.exact_end || r.hout_arr) ? 1 : 0;
+        }
+        if (r.values) {
+            j.values = r.values;
+            j.fill_stride = r.fill_stride;
+            j.fill_word0 = r.fill_word0 + s * kWordsPerStrip;
+        }
+        jobs.push_back(j);
+    }
+}
+
+size_t rect_granules(int n, int w) {
+    const int S = (w + kWordsPerStrip - 1) / kWordsPerStrip;
+    const size_t G = (size_t)(n + 15) / 16;
+    return S > 1 ? (size_t)(S - 1) * G : 0;
+}
+
+bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_ticket_err, hipStream_t s) {
+    if (njobs == 0) return true;
+    // d_ticket_err[0] = ticket, [1] = err
+    if (!hip_ok(hipMemsetAsync(d_ticket_err, 0, 2 * sizeof(uint32_t), s), "memset ticket")) return false;
+    const int grid = njobs;  // one wave per job; jobs beyond residency queue behind their producers (ticket order)
+    if (fill)
+        hipLaunchKernelGGL(strip_kernel<true>, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_ticket_err, d_ticket_err + 1);
+    else
+        hipLaunchKernelGGL(strip_kernel<false>, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_ticket_err, d_ticket_err + 1);
+    return hip_ok(hipGetLastError(), "strip_kernel launch");
+}
+
+}  // namespace pa
+
+using namespace pa;
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+
+extern "C" const char* pa_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int pa_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+extern "C" int pa_set_device(int device) {
+    if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return PA_E_HIP;
+    return 0;
+}
+
+extern "C" int pa_bp_profile_build(const uint8_t* a, size_t n, const uint8_t* b, size_t m, uint64_t* a2,
+                                   uint64_t* b2) {
+    if (!ensure_device()) return PA_E_HIP;
+    const size_t w = (m + 63) / 64, cw = (n + 15) / 16;
+    DeviceBuf d_a, d_b, d_codes, d_prof, d_bad;
+    if (!d_a.alloc(n) || !d_b.alloc(m) || !d_codes.alloc(cw * 4) || !d_prof.alloc(w * 16) || !d_bad.alloc(4))
+        return PA_E_HIP;
+    hipStream_t s = 0;
+    if (n && !hip_ok(hipMemcpyAsync(d_a.ptr, a, n, hipMemcpyHostToDevice, s), "H2D a")) return PA_E_HIP;
+    if (m && !hip_ok(hipMemcpyAsync(d_b.ptr, b, m, hipMemcpyHostToDevice, s), "H2D b")) return PA_E_HIP;
+    if (!hip_ok(hipMemsetAsync(d_bad.ptr, 0, 4, s), "memset")) return PA_E_HIP;
+    if (!encode_a_device(d_a.as<uint8_t>(), (int)n, d_codes.as<uint32_t>(), d_bad.as<uint32_t>(), s)) return PA_E_HIP;
+    if (!build_b_device(d_b.as<uint8_t>(), (int)m, d_prof.as<uint64_t>(), d_bad.as<uint32_t>(), s)) return PA_E_HIP;
+    std::vector<uint32_t> codes(cw);
+    uint32_t bad = 0;
+    if (cw && !hip_ok(hipMemcpyAsync(codes.data(), d_codes.ptr, cw * 4, hipMemcpyDeviceToHost, s), "D2H codes")) return PA_E_HIP;
+    if (w && !hip_ok(hipMemcpyAsync(b2, d_prof.ptr, w * 16, hipMemcpyDeviceToHost, s), "D2H prof")) return PA_E_HIP;
+    if (!hip_ok(hipMemcpyAsync(&bad, d_bad.ptr, 4, hipMemcpyDeviceToHost, s), "D2H bad")) return PA_E_HIP;
+    if (!hip_ok(hipStreamSynchronize(s), "sync")) return PA_E_HIP;
+    if (bad) {
+        set_error("sequence contains a base outside ACGT");
+        return PA_E_INVALID_BASE;
+    }
+    for (size_t i = 0; i < n; ++i) {  // exploded Bits of a (profile.rs:116-125)
+        const uint32_t r = (codes[i / 16] >> (2 * (i % 16))) & 3u;
+        a2[2 * i] = 0ull - (uint64_t)(r & 1);
+        a2[2 * i + 1] = 0ull - (uint64_t)((r >> 1) & 1);
+    }
+    return 0;
+}
+
+// Shared implementation of pa_bp_compute / pa_bp_fill on host buffers.
+static int32_t rect_host(const uint64_t* a2, size_t n, const uint64_t* b2, size_t w, uint64_t* h2, uint64_t* v2,
+                         int exact_end, uint64_t* values) {
+    if (!ensure_device()) return INT32_MIN;
+    if (n > (size_t)INT32_MAX / 2 || w > (size_t)INT32_MAX / 64) {
+        set_error("rectangle too large");
+        return INT32_MIN;
+    }
+    if (n == 0) return 0;
+    if (w == 0) {  // no rows: bottom == top
+        int32_t s = 0;
+        for (size_t i = 0; i < n; ++i) s += (int32_t)h2[2 * i] - (int32_t)h2[2 * i + 1];
+        return s;
+    }
+    const size_t cw = (n + 15) / 16;
+    std::vector<uint32_t> codes(cw, 0), hin(cw, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t r = (uint32_t)(a2[2 * i] & 1) | ((uint32_t)(a2[2 * i + 1] & 1) << 1);
+        codes[i / 16] |= r << (2 * (i % 16));
+        hin[i / 16] |= ((uint32_t)(h2[2 * i] & 1) | ((uint32_t)(h2[2 * i + 1] & 1) << 1)) << (2 * (i % 16));
+    }
+    const size_t ngran = rect_granules((int)n, (int)w);
+    DeviceBuf d_codes, d_prof, d_v, d_hin, d_hout, d_gran, d_jobs, d_misc, d_values;
+    if (!d_codes.alloc(cw * 4) || !d_prof.alloc(w * 16) || !d_v.alloc(w * 16) || !d_hin.alloc(cw * 4) ||
+        !d_hout.alloc(cw * 4) || !d_gran.alloc(ngran * 8) || !d_misc.alloc(16))
+        return INT32_MIN;
+    if (values && !d_values.alloc(n * w * 16)) return INT32_MIN;
+    hipStream_t s = 0;
+    bool ok = hip_ok(hipMemcpyAsync(d_codes.ptr, codes.data(), cw * 4, hipMemcpyHostToDevice, s), "H2D") &&
+              hip_ok(hipMemcpyAsync(d_prof.ptr, b2, w * 16, hipMemcpyHostToDevice, s), "H2D") &&
+              hip_ok(hipMemcpyAsync(d_v.ptr, v2, w * 16, hipMemcpyHostToDevice, s), "H2D") &&
+              hip_ok(hipMemcpyAsync(d_hin.ptr, hin.data(), cw * 4, hipMemcpyHostToDevice, s), "H2D") &&
+              hip_ok(hipMemsetAsync(d_gran.ptr, 0, std::max<size_t>(ngran * 8, 16), s), "memset gran") &&
+              hip_ok(hipMemsetAsync(d_misc.ptr, 0, 16, s), "memset misc");
+    if (!ok) return INT32_MIN;
+
+    std::vector<StripJob> jobs;
+    RectPlan r;
+    r.a_codes = d_codes.as<uint32_t>();
+    r.b_prof = d_prof.as<uint32_t>();
+    r.v = d_v.as<uint32_t>();
+    r.n = (int)n;
+    r.w0 = 0;
+    r.w1 = (int)w;
+    r.hin_arr = d_hin.as<uint32_t>();
+    r.hout_arr = d_hout.as<uint32_t>();
+    r.gran = d_gran.as<uint64_t>();
+    r.gran_stride = cw;
+    r.sum_out = d_misc.as<int32_t>() + 2;
+    r.exact_end = exact_end != 0 || values != nullptr;
+    if (!exact_end && !values) r.hout_arr = nullptr;  // padded-tail path: the bottom row itself is not an output
+    r.values = values ? d_values.as<uint32_t>() : nullptr;
+    r.fill_stride = (int)w;
+    r.fill_word0 = 0;
+    plan_rect(jobs, r);
+    if (!d_jobs.alloc(jobs.size() * sizeof(StripJob))) return INT32_MIN;
+    ok = hip_ok(hipMemcpyAsync(d_jobs.ptr, jobs.data(), jobs.size() * sizeof(StripJob), hipMemcpyHostToDevice, s), "H2D jobs") &&
+         launch_strips(d_jobs.as<StripJob>(), (int)jobs.size(), values != nullptr, d_misc.as<uint32_t>(), s);
+    if (!ok) return INT32_MIN;
+    uint32_t misc[4] = {0, 0, 0, 0};
+    std::vector<uint32_t> hout(cw, 0);
+    ok = hip_ok(hipMemcpyAsync(misc, d_misc.ptr, 16, hipMemcpyDeviceToHost, s), "D2H") &&
+         hip_ok(hipMemcpyAsync(v2, d_v.ptr, w * 16, hipMemcpyDeviceToHost, s), "D2H") &&
+         (r.hout_arr == nullptr || hip_ok(hipMemcpyAsync(hout.data(), d_hout.ptr, cw * 4, hipMemcpyDeviceToHost, s), "D2H")) &&
+         (!values || hip_ok(hipMemcpyAsync(values, d_values.ptr, n * w * 16, hipMemcpyDeviceToHost, s), "D2H values")) &&
+         hip_ok(hipStreamSynchronize(s), "sync");
+    if (!ok) return INT32_MIN;
+    if (misc[1] != PA_ERR_NONE) {
+        set_error("device spin timeout (err=%u)", misc[1]);
+        return INT32_MIN;
+    }
+    if (r.hout_arr) {
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t x = (hout[i / 16] >> (2 * (i % 16))) & 3u;
+            h2[2 * i] = x & 1;
+            h2[2 * i + 1] = x >> 1;
+        }
+    }
+    // exact_end == 0: the reference leaves h unspecified (simd.rs:184-225); h2 is left untouched.
+    return (int32_t)misc[2];
+}
+
+extern "C" int32_t pa_bp_compute(const uint64_t* a2, size_t n, const uint64_t* b2, size_t w, uint64_t* h2, uint64_t* v2,
+                                 int exact_end) {
+    return rect_host(a2, n, b2, w, h2, v2, exact_end, nullptr);
+}
+
+extern "C" int32_t pa_bp_fill(const uint64_t* a2, size_t n, const uint64_t* b2, size_t w, uint64_t* h2, uint64_t* v2,
+                              uint64_t* values) {
+    return rect_host(a2, n, b2, w, h2, v2, 1, values);
+}
+
+// ---- batched full DP ----------------------------------------------------------------------------
+
+struct pa_batch {
+    size_t pairs = 0;
+    std::vector<size_t> n, m, a_off, b_off, code_off, prof_off, gran_off;
+    DeviceBuf d_a, d_b, d_codes, d_prof, d_v, d_gran, d_jobs, d_sums, d_misc;
+    std::vector<StripJob> jobs;
+    std::vector<int> last_job;  // per pair (or -1 when w == 0)
+    size_t total_gran = 0;
+    double cells = 0, word_updates = 0, algo_bytes = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ~pa_batch() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+extern "C" pa_batch* pa_batch_create(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b,
+                                     const size_t* b_len, size_t pairs) {
+    if (!ensure_device()) return nullptr;
+    auto p = std::make_unique<pa_batch>();
+    p->pairs = pairs;
+    size_t ta = 0, tb = 0, tc = 0, tp = 0, tg = 0;
+    for (size_t i = 0; i < pairs; ++i) {
+        if (a_len[i] > (size_t)(1u << 30) || b_len[i] > (size_t)(1u << 30)) {
+            set_error("sequence too long");
+            return nullptr;
+        }
+        p->n.push_back(a_len[i]);
+        p->m.push_back(b_len[i]);
+        p->a_off.push_back(ta);
+        p->b_off.push_back(tb);
+        p->code_off.push_back(tc);
+        p->prof_off.push_back(tp);
+        p->gran_off.push_back(tg);
+        const size_t w = (b_len[i] + 63) / 64;
+        ta += (a_len[i] + 15) & ~size_t(15);
+        tb += (b_len[i] + 15) & ~size_t(15);
+        tc += (a_len[i] + 15) / 16;
+        tp += w;
+        tg += rect_granules((int)a_len[i], (int)w);
+        p->cells += (double)a_len[i] * (double)b_len[i];
+        p->word_updates += (double)a_len[i] * (double)w;
+        // algorithmic HBM bytes, cost-only rectangle: 0.75 B/column + 48 B/word
+        p->algo_bytes += 0.75 * (double)a_len[i] + 48.0 * (double)w;
+    }
+    p->total_gran = tg;
+    if (!p->d_a.alloc(ta) || !p->d_b.alloc(tb) || !p->d_codes.alloc(tc * 4) || !p->d_prof.alloc(tp * 16) ||
+        !p->d_v.alloc(tp * 16) || !p->d_gran.alloc(tg * 8) || !p->d_sums.alloc(pairs * 4) || !p->d_misc.alloc(16))
+        return nullptr;
+    if (!hip_ok(hipStreamCreate(&p->stream), "hipStreamCreate") || !hip_ok(hipEventCreate(&p->ev0), "event") ||
+        !hip_ok(hipEventCreate(&p->ev1), "event"))
+        return nullptr;
+    for (size_t i = 0; i < pairs; ++i) {
+        if (a_len[i] && !hip_ok(hipMemcpyAsync(p->d_a.as<uint8_t>() + p->a_off[i], a[i], a_len[i], hipMemcpyHostToDevice, p->stream), "H2D a"))
+            return nullptr;
+        if (b_len[i] && !hip_ok(hipMemcpyAsync(p->d_b.as<uint8_t>() + p->b_off[i], b[i], b_len[i], hipMemcpyHostToDevice, p->stream), "H2D b"))
+            return nullptr;
+    }
+    // Jobs: pair-major, strips of a pair consecutive (ticket order == dependency order).
+    p->last_job.assign(pairs, -1);
+    for (size_t i = 0; i < pairs; ++i) {
+        const int w = (int)((b_len[i] + 63) / 64);
+        if (w == 0 || a_len[i] == 0) continue;
+        RectPlan r;
+        r.a_codes = p->d_codes.as<uint32_t>() + p->code_off[i];
+        r.b_prof = p->d_prof.as<uint32_t>() + p->prof_off[i] * 4;
+        r.v = p->d_v.as<uint32_t>() + p->prof_off[i] * 4;
+        r.n = (int)a_len[i];
+        r.w0 = 0;
+        r.w1 = w;
+        r.gran = p->d_gran.as<uint64_t>() + p->gran_off[i];
+        r.gran_stride = (a_len[i] + 15) / 16;
+        r.sum_out = p->d_sums.as<int32_t>() + i;
+        r.exact_end = false;
+        r.v_init_one = true;
+        plan_rect(p->jobs, r);
+        p->last_job[i] = (int)p->jobs.size() - 1;
+    }
+    if (!p->d_jobs.alloc(p->jobs.size() * sizeof(StripJob))) return nullptr;
+    if (!p->jobs.empty() &&
+        !hip_ok(hipMemcpyAsync(p->d_jobs.ptr, p->jobs.data(), p->jobs.size() * sizeof(StripJob), hipMemcpyHostToDevice, p->stream), "H2D jobs"))
+        return nullptr;
+    if (!hip_ok(hipStreamSynchronize(p->stream), "sync")) return nullptr;
+    return p.release();
+}
+
+extern "C" int pa_batch_run(pa_batch* p, int32_t* cost_out, float* kernel_ms) {
+    if (!p) return PA_E_ARG;
+    hipStream_t s = p->stream;
+    // (1) profiles (BitProfile::build, once per pair: blocks.rs:112)
+    if (!hip_ok(hipMemsetAsync(p->d_misc.ptr, 0, 16, s), "memset")) return PA_E_HIP;
+    for (size_t i = 0; i < p->pairs; ++i) {
+        if (!encode_a_device(p->d_a.as<uint8_t>() + p->a_off[i], (int)p->n[i], p->d_codes.as<uint32_t>() + p->code_off[i],
+                             p->d_misc.as<uint32_t>() + 3, s))
+            return PA_E_HIP;
+        if (!build_b_device(p->d_b.as<uint8_t>() + p->b_off[i], (int)p->m[i], p->d_prof.as<uint64_t>() + p->prof_off[i] * 2,
+                            p->d_misc.as<uint32_t>() + 3, s))
+            return PA_E_HIP;
+    }
+    // (2) clear hand-off granules, (3) strips
+    if (p->total_gran && !hip_ok(hipMemsetAsync(p->d_gran.ptr, 0, p->total_gran * 8, s), "memset gran")) return PA_E_HIP;
+    if (!hip_ok(hipMemsetAsync(p->d_sums.ptr, 0, std::max<size_t>(p->pairs * 4, 16), s), "memset sums")) return PA_E_HIP;
+    if (!hip_ok(hipEventRecord(p->ev0, s), "event")) return PA_E_HIP;
+    if (!launch_strips(p->d_jobs.as<StripJob>(), (int)p->jobs.size(), false, p->d_misc.as<uint32_t>(), s)) return PA_E_HIP;
+    if (!hip_ok(hipEventRecord(p->ev1, s), "event")) return PA_E_HIP;
+    // (4) read back: bottom sums and each pair's last v word (for the rows beyond |b| in the last word)
+    std::vector<int32_t> sums(p->pairs, 0);
+    std::vector<uint64_t> lastv(2 * p->pairs, 0);
+    uint32_t misc[4] = {0, 0, 0, 0};
+    if (p->pairs && !hip_ok(hipMemcpyAsync(sums.data(), p->d_sums.ptr, p->pairs * 4, hipMemcpyDeviceToHost, s), "D2H")) return PA_E_HIP;
+    for (size_t i = 0; i < p->pairs; ++i) {
+        const size_t w = (p->m[i] + 63) / 64;
+        if (w == 0 || p->n[i] == 0 || p->m[i] % 64 == 0) continue;
+        if (!hip_ok(hipMemcpyAsync(&lastv[2 * i], p->d_v.as<uint64_t>() + (p->prof_off[i] + w - 1) * 2, 16, hipMemcpyDeviceToHost, s), "D2H v"))
+            return PA_E_HIP;
+    }
+    if (!hip_ok(hipMemcpyAsync(misc, p->d_misc.ptr, 16, hipMemcpyDeviceToHost, s), "D2H")) return PA_E_HIP;
+    if (!hip_ok(hipStreamSynchronize(s), "sync")) return PA_E_HIP;
+    if (misc[3]) {
+        set_error("sequence contains a base outside ACGT");
+        return PA_E_INVALID_BASE;
+    }
+    if (misc[1] != PA_ERR_NONE) {
+        set_error("device spin timeout (err=%u)", misc[1]);
+        return PA_E_TIMEOUT;
+    }
+    if (kernel_ms) {
+        *kernel_ms = 0.f;
+        if (!p->jobs.empty() && !hip_ok(hipEventElapsedTime(kernel_ms, p->ev0, p->ev1), "elapsed")) return PA_E_HIP;
+    }
+    for (size_t i = 0; i < p->pairs; ++i) {
+        const size_t n = p->n[i], m = p->m[i], w = (m + 63) / 64;
+        if (n == 0) { cost_out[i] = (int32_t)m; continue; }
+        if (w == 0) { cost_out[i] = (int32_t)n; continue; }
+        // bot_val = rounded |b| + sum of bottom deltas (blocks.rs:171,255-267); cost = get(|b|) (domain.rs:520)
+        int32_t bot = (int32_t)(w * 64) + sums[i];
+        if (m % 64 != 0) {
+            const int j = (int)(w * 64 - m);  // value_of_suffix(j), encoding.rs:33-38
+            const uint64_t mask = ~((1ull << (64 - j)) - 1);
+            bot -= (int32_t)__builtin_popcountll(lastv[2 * i] & mask) - (int32_t)__builtin_popcountll(lastv[2 * i + 1] & mask);
+        }
+        cost_out[i] = bot;
+    }
+    return 0;
+}
+
+extern "C" void pa_batch_stats(const pa_batch* p, double* cells, double* word_updates, double* strips, double* algo_bytes) {
+    if (cells) *cells = p->cells;
+    if (word_updates) *word_updates = p->word_updates;
+    if (strips) *strips = (double)p->jobs.size();
+    if (algo_bytes) *algo_bytes = p->algo_bytes;
+}
+
+extern "C" void pa_batch_destroy(pa_batch* p) { delete p; }

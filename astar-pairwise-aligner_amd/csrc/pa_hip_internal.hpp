@@ -1,0 +1,56 @@
+// pa_hip_internal.hpp -- shared declarations of the host side of libastarpa_c_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/pa_bitpacking_hip.h"
+#include "strip_kernel.hpp"
+
+namespace pa {
+
+constexpr int kWordsPerStrip = 32;  // 64 lanes x 32 rows = 32 reference words (2048 rows)
+
+void set_error(const char* fmt, ...);
+bool hip_ok(hipError_t e, const char* what);
+bool ensure_device();
+
+struct DeviceBuf {
+    void* ptr = nullptr;
+    size_t size = 0;
+    DeviceBuf() = default;
+    DeviceBuf(const DeviceBuf&) = delete;
+    DeviceBuf& operator=(const DeviceBuf&) = delete;
+    ~DeviceBuf() { release(); }
+    bool alloc(size_t bytes);
+    void release();
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(ptr); }
+};
+
+// One rectangle = words [w0,w1) x n columns of one pair, split into chained strips.
+struct RectPlan {
+    const uint32_t* a_codes = nullptr;  // device, already offset to the rectangle's first column (16-column aligned)
+    const uint32_t* b_prof = nullptr;   // device, u32 view of the pair's profile (word 0)
+    uint32_t* v = nullptr;              // device, u32 view of the v column (word 0 of the same indexing as b_prof)
+    int n = 0, w0 = 0, w1 = 0;
+    const uint32_t* hin_arr = nullptr;  // packed top deltas or nullptr (+1)
+    uint32_t* hout_arr = nullptr;       // packed bottom deltas out or nullptr
+    uint64_t* gran = nullptr;           // (S-1) * gran_stride granules, zeroed before launch
+    size_t gran_stride = 0;             // >= ceil(n/16)
+    int32_t* sum_out = nullptr;
+    bool exact_end = false;
+    bool v_init_one = false;
+    uint32_t* values = nullptr;  // fill mode
+    int fill_stride = 0, fill_word0 = 0;
+};
+
+void plan_rect(std::vector<StripJob>& jobs, const RectPlan& r);
+size_t rect_granules(int n, int w);
+bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_ticket_err, hipStream_t s);
+bool encode_a_device(const uint8_t* d_a, int n, uint32_t* d_codes, uint32_t* d_bad, hipStream_t s);
+bool build_b_device(const uint8_t* d_b, int m, uint64_t* d_prof, uint32_t* d_bad, hipStream_t s);
+
+}  // namespace pa

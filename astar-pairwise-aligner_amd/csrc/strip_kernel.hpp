@@ -1,0 +1,257 @@
+// strip_kernel.hpp -- the bit-parallel (Myers/Hyyro) block-DP kernel for gfx950 (MI355X).
+//
+// What it replaces: pa_bitpacking::simd::{compute,fill} and the column loop of
+// compute_block_of_rows (reference pa-bitpacking/src/simd.rs:98-315,326-547; myers.rs:27-91).
+//
+// MI355X-first design (not the CPU's 8-lane AVX2 strip):
+//  * A *strip* is one 64-lane wavefront.  Lane l owns 32 DP rows (one half of a reference 64-bit
+//    word; word = l/2, half = l&1), so a strip covers 2048 rows = 32 reference words.  32-bit lanes
+//    make every Myers op one VALU instruction (no carry pairs) which halves the per-step latency that
+//    bounds a single long pair.
+//  * Anti-diagonal skew inside the wave: at step t lane l processes column t-l.  The horizontal
+//    delta (2 bits) and the column's 2-bit base code travel lane->lane+1 in ONE packed register
+//    through a DPP `wave_shr:1` move -- no LDS, no barrier.
+//  * Strips of one rectangle are chained top->bottom.  The bottom row of strip s (2 bits/column) is
+//    handed to strip s+1 through 8-byte {tag,payload} granules (16 columns each) in global memory,
+//    written with one agent-scope relaxed atomic store and polled with agent-scope relaxed loads
+//    ("the data is the flag"; MI355X_MICROARCH.md, handoff R2).  No fences, no L2 writeback.
+//  * Work items are claimed through an atomic ticket, so a consumer's producer always started
+//    earlier => forward progress without assuming dispatch order.  Every spin is bounded.
+//  * HBM traffic is tiny by construction (0.25 B/column of `a`, 16 B/word of profile, 32 B/word of v,
+//    0.5 B/column of h per strip boundary): the kernel is integer-VALU-issue bound, not HBM bound.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pa {
+
+// One strip job = one wavefront.  All pointers are device pointers.
+struct StripJob {
+    const uint32_t* a_codes;  // 2-bit base codes (A0 C1 G2 T3), 16 per u32: column i at bits 2*(i%16)+{0,1} of word i/16
+    const uint32_t* b_prof;   // BitProfile of b: u32 view of (nb0:u64, nb1:u64) per 64-row word (profile.rs:112-133)
+    uint32_t* v;              // V(p:u64, m:u64) per 64-row word, u32 view, updated in place (encoding.rs:5-6)
+    const uint64_t* hin_gran; // granules from the strip above (tag = chunk+1), or nullptr
+    const uint32_t* hin_arr;  // packed top-row deltas (16 columns/u32: bit 2k = +1, bit 2k+1 = -1), or nullptr => all +1
+    uint64_t* hout_gran;      // granules for the strip below, or nullptr
+    uint32_t* hout_arr;       // packed bottom-row deltas out, or nullptr
+    uint32_t* values;         // fill mode: V of every column, u32 view of values[col][fill_stride] (V each); or nullptr
+    int32_t* sum_out;         // *sum_out = sum of bottom-row deltas over the n columns (if non-null)
+    int32_t n;                // columns
+    int32_t word0;            // first 64-row word of this strip (index into b_prof / v)
+    int32_t nlanes;           // real lanes: 2 * (words in this strip), 2..64, even
+    int32_t fill_stride;      // words per column in `values`
+    int32_t fill_word0;       // word index of this strip inside a `values` column
+    int32_t exact_tail;       // nlanes<64 only.  1: lanes >= nlanes forward h unchanged, so lane 63 carries the true
+                              //    bottom row (needed when the bottom deltas themselves are an output).
+                              // 0: lanes >= nlanes run as zero pad rows (b = Bits(0,0), v = V(0,0)) and the sum is
+                              //    corrected with their right edge -- the identity the reference's padded tail uses
+                              //    (simd.rs:184-225).
+    int32_t flags;            // kJobVInitOne: start from V::one() instead of loading v (first column, blocks.rs:163)
+    int32_t pad_;
+};
+enum : int32_t { kJobVInitOne = 1 };
+static_assert(sizeof(StripJob) == 104, "StripJob layout");
+
+enum : uint32_t {
+    PA_ERR_NONE = 0,
+    PA_ERR_SPIN_TIMEOUT = 1,  // a producer strip never delivered its granule
+};
+
+constexpr uint32_t kSpinLimit = 1u << 21;
+
+__device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t old_, uint32_t src) {
+    // v_mov_b32_dpp wave_shr:1 ; lane 0 has no source lane and keeps `old_`.
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old_, (int)src, 0x138, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
+// Packed pipeline register X:  bit0 = h.p (delta +1), bit1 = h.m (delta -1), bit30 = code&1, bit31 = code>>1.
+// One Myers step on a 32-row lane (myers.rs:27-55 with 32-bit words; eq from profile.rs:141-144).
+// `acc` collects the lane's outgoing deltas delayed by one step (2 bits per column, oldest lowest).
+template <bool PRED, bool PASS>
+__device__ __forceinline__ void myers_step(uint32_t s_x, uint32_t& X, uint32_t& vp, uint32_t& vm,
+                                           uint32_t nb0, uint32_t nb1, uint32_t& acc, bool active,
+                                           bool pass_lane) {
+    acc = __builtin_amdgcn_alignbit(X, acc, 2);
+    const uint32_t Xin = dpp_wave_shr1(s_x, X);
+    const uint32_t hp0 = Xin & 1u;
+    const uint32_t hm0 = (Xin >> 1) & 1u;
+    const uint32_t a0 = (uint32_t)((int32_t)(Xin << 1) >> 31);
+    const uint32_t a1 = (uint32_t)((int32_t)Xin >> 31);
+    const uint32_t x0 = a0 ^ nb0, x1 = a1 ^ nb1;
+    const uint32_t eq = x0 & x1;
+    const uint32_t vx = eq | vm;
+    const uint32_t eq2 = eq | hm0;
+    const uint32_t hx = (((eq2 & vp) + vp) ^ vp) | eq2;
+    uint32_t hp = vm | ~(hx | vp);
+    uint32_t hm = vp & hx;
+    const uint32_t pm = (hp >> 31) | ((hm >> 30) & 2u);
+    uint32_t Xo = (Xin & 0xC0000000u) | pm;
+    hp = (hp << 1) | hp0;
+    hm = (hm << 1) | hm0;
+    const uint32_t nvp = hm | ~(vx | hp);
+    const uint32_t nvm = hp & vx;
+    if (PASS) Xo = pass_lane ? Xin : Xo;
+    if (PRED) {
+        vp = active ? nvp : vp;
+        vm = active ? nvm : vm;
+    } else {
+        vp = nvp;
+        vm = nvm;
+    }
+    X = Xo;
+}
+
+template <bool PRED, bool PASS, bool FILL>
+__device__ __forceinline__ void run_chunk(const StripJob& job, int q, uint32_t XS, uint32_t& X, uint32_t& vp,
+                                          uint32_t& vm, uint32_t nb0, uint32_t nb1, uint32_t& acc, int lane,
+                                          bool pass_lane, uint32_t* vout) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t s_x = (uint32_t)__builtin_amdgcn_readlane((int)XS, j);
+        const int col = q * 16 + j - lane;
+        const bool active = PRED ? ((unsigned)col < (unsigned)job.n) : true;
+        myers_step<PRED, PASS>(s_x, X, vp, vm, nb0, nb1, acc, active, pass_lane);
+        if (FILL) {
+            if (active && lane < job.nlanes) {
+                uint32_t* dst = vout + (size_t)col * (size_t)job.fill_stride * 4;
+                dst[0] = vp;
+                dst[2] = vm;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t load_granule(const uint64_t* g) {
+    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Resolve the (possibly prefetched) granule of chunk q; polls when the producer is not there yet.
+__device__ __forceinline__ bool resolve_granule(const uint64_t* g, uint64_t pre, int q, uint32_t& bits, uint32_t* err) {
+    uint32_t spins = 0;
+    for (;;) {
+        const uint32_t tag = rfl((uint32_t)(pre >> 32));
+        if (tag == (uint32_t)(q + 1)) {
+            bits = rfl((uint32_t)pre);
+            return true;
+        }
+        if (++spins > kSpinLimit) {
+            if (err) __hip_atomic_store(err, (uint32_t)PA_ERR_SPIN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        pre = load_granule(g + q);
+    }
+}
+
+// Process one strip.  Returns false on a spin timeout.
+template <bool FILL>
+__device__ __forceinline__ bool run_strip(const StripJob& job, uint32_t* err) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int n = job.n;
+    const int G = (n + 15) >> 4;  // 16-column chunks == granules
+    const bool real = lane < job.nlanes;
+    const bool pass_lane = !real;
+    const int word = job.word0 + (lane >> 1);
+    const int half = lane & 1;
+
+    uint32_t vp = 0, vm = 0, nb0 = 0, nb1 = 0;
+    if (real) {
+        nb0 = job.b_prof[word * 4 + half];
+        nb1 = job.b_prof[word * 4 + 2 + half];
+        if (job.flags & kJobVInitOne) {
+            vp = 0xFFFFFFFFu;
+            vm = 0u;
+        } else {
+            vp = job.v[word * 4 + half];
+            vm = job.v[word * 4 + 2 + half];
+        }
+    }
+    uint32_t* vout = nullptr;
+    if (FILL) vout = job.values + ((size_t)(job.fill_word0 + (lane >> 1)) * 4 + half);
+
+    uint32_t X = 0, acc = 0;
+    int32_t sum = 0;
+    const uint32_t sh = 2u * (uint32_t)(lane & 15);
+    const bool exact_tail = job.exact_tail != 0 && job.nlanes < 64;
+
+    uint64_t pre = 0;
+    if (job.hin_gran && G > 0) pre = load_granule(job.hin_gran);
+    uint32_t codes_next = (G > 0) ? job.a_codes[0] : 0u;
+
+    // Steps t = 0 .. 16*(G+4)-1; lane l handles column t-l.  `acc` lags one step, so after chunk q
+    // lane 63's acc holds the bottom-row deltas of columns 16(q-4) .. 16(q-4)+15 == granule q-4.
+    for (int q = 0; q < G + 4; ++q) {
+        uint32_t hin = 0x55555555u;  // H::one() for every column (blocks.rs:732)
+        if (q < G) {
+            if (job.hin_gran) {
+                if (!resolve_granule(job.hin_gran, pre, q, hin, err)) return false;
+                if (q + 1 < G) pre = load_granule(job.hin_gran + q + 1);
+            } else if (job.hin_arr) {
+                hin = job.hin_arr[q];
+            }
+        }
+        const uint32_t codes = codes_next;
+        codes_next = (q + 1 < G) ? job.a_codes[q + 1] : 0u;
+        const uint32_t XS = ((codes >> sh) << 30) | ((hin >> sh) & 3u);
+
+        const bool interior = !FILL && (q >= 4) && (q * 16 + 15 < n);
+        if (interior) {
+            if (exact_tail) run_chunk<false, true, false>(job, q, XS, X, vp, vm, nb0, nb1, acc, lane, pass_lane, vout);
+            else run_chunk<false, false, false>(job, q, XS, X, vp, vm, nb0, nb1, acc, lane, pass_lane, vout);
+        } else {
+            if (exact_tail) run_chunk<true, true, FILL>(job, q, XS, X, vp, vm, nb0, nb1, acc, lane, pass_lane, vout);
+            else run_chunk<true, false, FILL>(job, q, XS, X, vp, vm, nb0, nb1, acc, lane, pass_lane, vout);
+        }
+
+        const int g = q - 4;
+        if (g >= 0) {  // g < G always holds here
+            const int cols = n - 16 * g;
+            const uint32_t mask = cols >= 16 ? 0xFFFFFFFFu : ((1u << (2 * cols)) - 1u);
+            const uint32_t val = (uint32_t)__builtin_amdgcn_readlane((int)acc, 63) & mask;
+            if (job.hout_gran) {
+                if (lane == 0)
+                    __hip_atomic_store(job.hout_gran + g, ((uint64_t)(uint32_t)(g + 1) << 32) | (uint64_t)val,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (job.hout_arr) {
+                if (lane == 0) job.hout_arr[g] = val;
+            }
+            sum += __builtin_popcount(val & 0x55555555u) - __builtin_popcount(val & 0xAAAAAAAAu);
+        }
+    }
+
+    if (real) {
+        job.v[word * 4 + half] = vp;
+        job.v[word * 4 + 2 + half] = vm;
+    }
+    if (job.sum_out) {
+        if (!exact_tail && job.nlanes < 64) {
+            // zero pad rows: subtract their right-edge value (simd.rs:202-224)
+            int32_t c = real ? 0 : (__builtin_popcount(vp) - __builtin_popcount(vm));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            sum -= c;
+        }
+        if (lane == 0) *job.sum_out = sum;
+    }
+    return true;
+}
+
+// Persistent strip kernel: each 64-thread block claims jobs by ticket until none are left.
+// `ticket` and `err` must be zeroed (and every hin/hout granule buffer cleared) before the launch.
+template <bool FILL>
+__global__ __launch_bounds__(64) void strip_kernel(const StripJob* __restrict__ jobs, int njobs,
+                                                   uint32_t* ticket, uint32_t* err) {
+    for (;;) {
+        uint32_t t = 0;
+        if ((threadIdx.x & 63) == 0) t = atomicAdd(ticket, 1u);
+        t = rfl(t);
+        if (t >= (uint32_t)njobs) return;
+        const StripJob job = jobs[t];
+        if (!run_strip<FILL>(job, err)) return;
+    }
+}
+
+}  // namespace pa

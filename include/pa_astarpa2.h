@@ -1,0 +1,70 @@
+/*
+ * pa_astarpa2.h -- C mirror of the A*PA2 aligner surface (parameters, stats, one entry point).
+ *
+ * Replaces, for the hot path only, the Rust surface
+ *   AstarPa2Params::{nw,simple,full}().make_aligner(trace) -> Box<dyn AstarPa2StatsAligner>
+ *   AstarPa2StatsAligner::align_with_stats(a, b) -> (Cost, Option<Cigar>, AstarPa2Stats)
+ * (astarpa2/src/params.rs:8-42,46-128,132; astarpa2/src/lib.rs:200-214; blocks.rs:31-84; domain.rs:31-43).
+ * Field names and meanings follow the reference structs one for one.
+ */
+#ifndef PA_ASTARPA2_H
+#define PA_ASTARPA2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { PA_DOMAIN_FULL = 0, PA_DOMAIN_GAP_START = 1, PA_DOMAIN_GAP_GAP = 2, PA_DOMAIN_ASTAR = 3 }; /* params.rs:231-242 */
+enum { PA_HEURISTIC_NONE = 0, PA_HEURISTIC_GAP = 1 };   /* NoCost (Dijkstra) / GapCost, pa-heuristic distances.rs */
+enum { PA_DOUBLING_NONE = 0, PA_DOUBLING_BAND = 1, PA_DOUBLING_LINEAR = 2 };                     /* band.rs:26-44 */
+enum { PA_START_ZERO = 0, PA_START_GAP = 1, PA_START_H0 = 2 };                                   /* band.rs:5-10 */
+
+typedef struct pa_block_params { /* BlockParams, blocks.rs:31-60 */
+    int32_t sparse;
+    int32_t simd;   /* accepted for compatibility: the GPU library always runs its own strip schedule */
+    int32_t no_ilp; /* idem */
+    int32_t incremental_doubling;
+    int32_t dt_trace;
+    int32_t max_g;
+    int32_t fr_drop;
+} pa_block_params;
+
+typedef struct pa_astarpa2_params { /* AstarPa2Params, params.rs:8-42 */
+    int32_t domain;
+    int32_t heuristic;
+    int32_t doubling;
+    int32_t doubling_start;
+    float factor; /* BandDoubling */
+    float delta;  /* LinearSearch */
+    int32_t block_width;
+    pa_block_params front;
+    int32_t sparse_h;
+    int32_t prune;
+} pa_astarpa2_params;
+
+typedef struct pa_astarpa2_stats { /* AstarPa2Stats + BlockStats + TraceStats */
+    uint64_t num_blocks, num_incremental_blocks, computed_lanes, unique_lanes;
+    uint64_t dt_trace_tries, dt_trace_success, dt_trace_fallback, fill_tries, fill_success, fill_fallback;
+    uint64_t f_max_tries;
+    uint64_t sanity_violations; /* times the reference's band.rs:117-135 asserts would have aborted */
+    double t_compute, t_dt, t_fill, t_precomp, t_j_range, t_fixed_j_range, t_pruning, t_contours_update;
+} pa_astarpa2_stats;
+
+/* Presets, params.rs:46-128.  `full` currently selects the `simple` parameter set: the GCSH heuristic
+ * (pa-heuristic) is not restated yet; the returned cost is identical either way. */
+void pa_params_nw(pa_astarpa2_params* p);
+void pa_params_simple(pa_astarpa2_params* p);
+void pa_params_full(pa_astarpa2_params* p);
+
+/* align_with_stats.  trace != 0 => *cigar_out receives a malloc'ed NUL-terminated CIGAR ("=I4=X=" style,
+ * free() it or use astarpa_free_cigar).  Returns 0, or a PA_E_* code.  All DP rectangles run on the GPU. */
+int pa_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params* params,
+             int trace, int32_t* cost_out, char** cigar_out, pa_astarpa2_stats* stats_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

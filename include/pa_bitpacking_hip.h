@@ -1,0 +1,79 @@
+/*
+ * pa_bitpacking_hip.h -- operator-level C ABI of libastarpa_c_hip.so (MI355X / gfx950).
+ *
+ * These are the entry points a Rust shim crate binds to replace the `pa_bitpacking` operators the
+ * A*PA2 block engine calls (see INTEGRATION.md for the `extern "C"` block):
+ *   pa_bp_profile_build  <- pa_bitpacking::BitProfile::build      pa-bitpacking/src/profile.rs:112-133
+ *   pa_bp_compute        <- pa_bitpacking::simd::compute::<2,H,4> pa-bitpacking/src/simd.rs:98-226
+ *                           (call sites astarpa2/src/blocks.rs:719-724)
+ *   pa_bp_fill           <- pa_bitpacking::simd::fill::<2,H,4>    pa-bitpacking/src/simd.rs:326-437
+ *                           (call site  astarpa2/src/blocks.rs:631)
+ * plus batched, device-resident forms with no reference counterpart (the reference aligns pairs one
+ * after another, pa-bin/src/main.rs:24-35) that keep many independent pairs in flight on one GPU.
+ *
+ * Layouts (plain pointers, host memory unless stated):
+ *   Bits / V / H = two u64 each, exactly the reference's (u64,u64) tuples once made repr(C):
+ *     a2[2*i+{0,1}]   BitProfile char of a: (-(r&1), -((r>>1)&1)), r = rank in "ACGT"
+ *     b2[2*j+{0,1}]   negated bit-planes of 64 rows of b; rows >= |b| are (0,0)
+ *     v2[2*j+{0,1}]   V(p,m): bit k of p/m <=> D[64j+k+1]-D[64j+k] = +1/-1
+ *     h2[2*i+{0,1}]   H=(p,m), each 0 or 1
+ * Errors: functions returning int return 0 on success, <0 on error (PA_E_*); pa_last_error()
+ * gives a message.  Cost-returning operators return INT32_MIN on error.
+ */
+#ifndef PA_BITPACKING_HIP_H
+#define PA_BITPACKING_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PA_E_INVALID_BASE (-1) /* a character outside "ACGT" (the reference panics, profile.rs:113-126) */
+#define PA_E_HIP (-2)          /* HIP runtime failure / no GPU */
+#define PA_E_TIMEOUT (-3)      /* device-side bounded spin expired */
+#define PA_E_ARG (-4)
+
+const char* pa_last_error(void);
+
+/* Number of visible GPUs (0 if none / HIP unavailable). */
+int pa_device_count(void);
+/* Select the GPU used by this thread's subsequent calls (one process per GPU: call once with LOCAL_RANK). */
+int pa_set_device(int device);
+
+/* BitProfile::build.  a2 has 2*n u64, b2 has 2*ceil(m/64) u64.  Runs on the GPU. */
+int pa_bp_profile_build(const uint8_t* a, size_t n, const uint8_t* b, size_t m, uint64_t* a2, uint64_t* b2);
+
+/* simd::compute: rectangle a[0..n) x b[0..w) words.  Updates h2 (top -> bottom deltas) and v2
+ * (left -> right deltas) in place and returns the sum of the bottom deltas.
+ * The return value and v2 are exact in both modes.  With exact_end != 0, h2 receives the exact bottom
+ * row; with exact_end == 0 the reference leaves h unspecified (padded tail, simd.rs:184-225) and this
+ * library leaves h2 untouched (the callers -- HMode::None / Input, blocks.rs:730-741 -- discard it). */
+int32_t pa_bp_compute(const uint64_t* a2, size_t n, const uint64_t* b2, size_t w, uint64_t* h2, uint64_t* v2,
+                      int exact_end);
+
+/* simd::fill: as compute (exact), additionally values[(i*w + j)*2 + {0,1}] = V of word j after column i. */
+int32_t pa_bp_fill(const uint64_t* a2, size_t n, const uint64_t* b2, size_t w, uint64_t* h2, uint64_t* v2,
+                   uint64_t* values);
+
+/* ---- batched full-DP (cost only) on device-resident pairs ------------------------------------------ */
+/* What `AstarPa2Params::nw().make_aligner(false).cost(a,b)` computes (astarpa2/src/params.rs:46-68,
+ * blocks.rs:252-277) for many independent pairs at once. */
+typedef struct pa_batch pa_batch;
+
+/* Upload `pairs` sequence pairs (ASCII "ACGT") and plan their strips.  Returns NULL on error. */
+pa_batch* pa_batch_create(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b,
+                          const size_t* b_len, size_t pairs);
+/* One pass: build profiles on the GPU, run every strip, read the costs back.  cost_out[pairs].
+ * kernel_ms (optional) receives the duration of the strip kernel alone, measured with HIP events on
+ * the launch stream. */
+int pa_batch_run(pa_batch* plan, int32_t* cost_out, float* kernel_ms);
+/* Totals for reporting: DP cells (sum n*m), word updates (64 cells each), strips, algorithmic HBM bytes. */
+void pa_batch_stats(const pa_batch* plan, double* cells, double* word_updates, double* strips, double* algo_bytes);
+void pa_batch_destroy(pa_batch* plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

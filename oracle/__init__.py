@@ -145,3 +145,90 @@ def levenshtein(a: bytes, b: bytes) -> int:
 def cigar_verify(cigar: str, a: bytes, b: bytes) -> int:
     """Cost of a valid unit-cost CIGAR for (a,b), or -1 if invalid."""
     return lib().pa_or_cigar_verify(cigar.encode(), _buf(a), len(a), _buf(b), len(b))
+
+
+# ---- host block engine over the CPU kernels (oracle/engine_cpu.cpp) ---------------------------------
+class BlockParamsC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("sparse", "simd", "no_ilp", "incremental_doubling", "dt_trace", "max_g", "fr_drop")]
+
+
+class AstarPa2ParamsC(C.Structure):
+    _fields_ = [("domain", C.c_int32), ("heuristic", C.c_int32), ("doubling", C.c_int32), ("doubling_start", C.c_int32),
+                ("factor", C.c_float), ("delta", C.c_float), ("block_width", C.c_int32), ("front", BlockParamsC),
+                ("sparse_h", C.c_int32), ("prune", C.c_int32)]
+
+
+class AstarPa2StatsC(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("num_blocks", "num_incremental_blocks", "computed_lanes", "unique_lanes",
+                                           "dt_trace_tries", "dt_trace_success", "dt_trace_fallback", "fill_tries",
+                                           "fill_success", "fill_fallback", "f_max_tries", "sanity_violations")] + \
+               [(n, C.c_double) for n in ("t_compute", "t_dt", "t_fill", "t_precomp", "t_j_range", "t_fixed_j_range",
+                                          "t_pruning", "t_contours_update")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+DOMAIN = {"full": 0, "gap_start": 1, "gap_gap": 2, "astar": 3}
+HEURISTIC = {"none": 0, "gap": 1}
+DOUBLING = {"none": 0, "band": 1, "linear": 2}
+START = {"zero": 0, "gap": 1, "h0": 2}
+
+
+def make_params(domain="astar", heuristic="gap", doubling="band", start="h0", factor=2.0, delta=1.0, block_width=256,
+                sparse=True, simd=True, no_ilp=False, incremental_doubling=True, dt_trace=False, max_g=40, fr_drop=20,
+                sparse_h=False, prune=False) -> AstarPa2ParamsC:
+    """Defaults follow BlockParams::default() (blocks.rs:62-74)."""
+    return AstarPa2ParamsC(DOMAIN[domain], HEURISTIC[heuristic], DOUBLING[doubling], START[start], factor, delta,
+                           block_width, BlockParamsC(int(sparse), int(simd), int(no_ilp), int(incremental_doubling),
+                                                     int(dt_trace), max_g, fr_drop), int(sparse_h), int(prune))
+
+
+def params_nw():  # params.rs:46-68
+    return make_params(domain="full", heuristic="none", doubling="none", block_width=256, sparse=False,
+                       incremental_doubling=False, dt_trace=False)
+
+
+def params_simple():  # params.rs:70-96
+    return make_params(domain="astar", heuristic="gap", doubling="band", start="h0", factor=2.0, block_width=256,
+                       sparse=True, incremental_doubling=False, dt_trace=True, max_g=40, fr_drop=10, sparse_h=True)
+
+
+class EnginePanic(RuntimeError):
+    pass
+
+
+_elib = None
+
+
+def engine_lib() -> C.CDLL:
+    global _elib
+    if _elib is None:
+        build()
+        L = C.CDLL(str(_DIR / "_build" / "libpa_engine_cpu.so"))
+        L.pa_cpu_align.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(AstarPa2ParamsC), C.c_int,
+                                   C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(AstarPa2StatsC)]
+        L.pa_cpu_align.restype = C.c_int
+        L.pa_cpu_free.argtypes = [C.c_void_p]
+        _elib = L
+    return _elib
+
+
+def cpu_align(a: bytes, b: bytes, params: AstarPa2ParamsC, trace: bool = True, self_check: bool = False):
+    """Host block engine over the CPU oracle kernels -> (cost, cigar or None, stats dict)."""
+    cost = C.c_int32(0)
+    cig = C.c_void_p(None)
+    stats = AstarPa2StatsC()
+    rc = engine_lib().pa_cpu_align(_buf(a), len(a), _buf(b), len(b), C.byref(params), int(trace), int(self_check),
+                                   C.byref(cost), C.byref(cig), C.byref(stats))
+    if rc == -1:
+        raise ValueError("sequence contains a character outside ACGT")
+    if rc == -5:
+        raise EnginePanic("engine panic (see stderr)")
+    if rc != 0:
+        raise RuntimeError(f"pa_cpu_align rc={rc}")
+    s = None
+    if cig.value:
+        s = C.string_at(cig.value).decode()
+        engine_lib().pa_cpu_free(cig)
+    return cost.value, s, stats.as_dict()

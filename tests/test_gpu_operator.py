@@ -1,0 +1,137 @@
+"""GPU parity of the HIP operators (through the C ABI) against the CPU oracle -- bit exact."""
+import numpy as np
+import pytest
+
+from tests.util_seq import PA_TEST_PAIRS, gen_pair, rand_seq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import astar_pairwise_aligner_amd as pa
+
+    pa.require_gpu()
+    return pa
+
+
+def _as_u64(arr):
+    return np.ascontiguousarray(arr).view(np.uint64).reshape(len(arr), 2)
+
+
+def _rand_hv(rng, n, w):
+    h = np.zeros((n, 2), np.uint64)
+    sel = rng.integers(0, 3, n)
+    h[:, 0] = sel == 0
+    h[:, 1] = sel == 1
+    p = rng.integers(0, 1 << 63, w, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, w, dtype=np.uint64)
+    m = (rng.integers(0, 1 << 63, w, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, w, dtype=np.uint64)) & ~p
+    v = np.stack([p, m], axis=1).astype(np.uint64)
+    return h, v
+
+
+def test_profile_build_matches_oracle(pa, oracle):
+    for n, m in [(1, 1), (7, 8), (64, 64), (100, 129), (1000, 2049), (5000, 4097)]:
+        a, b = rand_seq(n, seed=n), rand_seq(m, seed=m + 1)
+        a2, b2 = pa.profile_build(a, b)
+        oa, ob = oracle.bitprofile_build(a, b)
+        assert np.array_equal(a2, _as_u64(oa))
+        assert np.array_equal(b2, _as_u64(ob))
+    with pytest.raises(ValueError):
+        pa.profile_build(b"ACGN", b"ACGT")
+    with pytest.raises(ValueError):
+        pa.profile_build(b"ACGT", b"ACgT")
+
+
+# shapes: tiny, ragged tails (1..7 words past 8), one strip exactly, strip boundaries, several strips
+SHAPES = [(1, 1), (3, 1), (15, 2), (16, 3), (17, 5), (31, 7), (64, 8), (100, 9), (256, 12), (256, 31), (256, 32),
+          (256, 33), (250, 63), (256, 64), (256, 65), (300, 100), (512, 129), (1000, 40), (77, 97)]
+
+
+@pytest.mark.parametrize("n,w", SHAPES)
+@pytest.mark.parametrize("exact", [True, False])
+def test_compute_matches_oracle(pa, oracle, n, w, exact):
+    rng = np.random.default_rng(n * 1000 + w)
+    for trial in range(2):
+        m = 64 * w - int(rng.integers(0, 64)) if trial else 64 * w
+        a, b = rand_seq(n, seed=n + trial), rand_seq(m, seed=w * 7 + trial)
+        oa, ob = oracle.bitprofile_build(a, b)
+        if trial == 0:
+            h, v = np.zeros((n, 2), np.uint64), np.zeros((w, 2), np.uint64)
+            h[:, 0] = 1
+            v[:, 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        else:
+            h, v = _rand_hv(rng, n, w)
+        h_or, v_or = h.copy().view(oracle.H_DTYPE).reshape(n), v.copy().view(oracle.V_DTYPE).reshape(w)
+        want = oracle.simd_compute(oa, ob, h_or, v_or, True)
+        h_gpu, v_gpu = h.copy(), v.copy()
+        got = pa.compute(_as_u64(oa), _as_u64(ob), h_gpu, v_gpu, exact)
+        assert got == want
+        assert np.array_equal(v_gpu, _as_u64(v_or))
+        if exact:
+            assert np.array_equal(h_gpu, _as_u64(h_or))
+
+
+@pytest.mark.parametrize("n,w", [(1, 1), (5, 3), (16, 4), (100, 9), (256, 10), (256, 33), (64, 70)])
+def test_fill_matches_oracle(pa, oracle, n, w):
+    rng = np.random.default_rng(n * 31 + w)
+    a, b = rand_seq(n, seed=n), rand_seq(64 * w - 5, seed=w)
+    oa, ob = oracle.bitprofile_build(a, b)
+    h, v = _rand_hv(rng, n, w)
+    h_or, v_or = h.copy().view(oracle.H_DTYPE).reshape(n), v.copy().view(oracle.V_DTYPE).reshape(w)
+    want, values_or = oracle.scalar_fill(oa, ob, h_or, v_or)
+    h_gpu, v_gpu = h.copy(), v.copy()
+    got, values = pa.fill(_as_u64(oa), _as_u64(ob), h_gpu, v_gpu)
+    assert got == want
+    assert np.array_equal(v_gpu, _as_u64(v_or))
+    assert np.array_equal(h_gpu, _as_u64(h_or))
+    assert np.array_equal(values.reshape(n * w, 2), values_or.reshape(n * w).view(np.uint64).reshape(n * w, 2))
+
+
+def test_bench_rule_on_gpu(pa, oracle):
+    """benches/nw/main.rs:145-149: h=+1, v=+1 => returned bottom sum == lev(a,b) - |b| (256 x 64..512 rows)."""
+    a = rand_seq(256, seed=31415)
+    for rows in (64, 128, 192, 256, 320, 384, 448, 512):
+        b = rand_seq(rows, seed=31415 + rows)
+        a2, b2 = pa.profile_build(a, b)
+        h, v = np.zeros((256, 2), np.uint64), np.zeros((rows // 64, 2), np.uint64)
+        h[:, 0] = 1
+        v[:, 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        assert pa.compute(a2, b2, h, v, False) == oracle.levenshtein(a, b) - len(b)
+
+
+def test_batch_costs_small(pa, oracle):
+    pairs = list(PA_TEST_PAIRS)
+    for n in (0, 1, 2, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000, 2047, 2048, 2049, 4100):
+        for e in (0.0, 0.05, 0.3, 1.0):
+            pairs.append(gen_pair(n, e, seed=n * 17 + int(100 * e)))
+    pairs.append((b"", b""))
+    pairs.append((b"ACGT", b""))
+    pairs.append((b"", b"ACGTA"))
+    batch = pa.Batch(pairs)
+    costs, ms = batch.run()
+    for (a, b), c in zip(pairs, costs):
+        assert c == oracle.levenshtein(a, b), (len(a), len(b))
+    # idempotent: a second pass over the same resident inputs gives the same answers
+    costs2, _ = batch.run()
+    assert np.array_equal(costs, costs2)
+    batch.close()
+
+
+def test_c_example_pair_batch(pa):
+    # astarpa-c/example.c:8-29
+    batch = pa.Batch([(b"ACTCGCT", b"AACTCGTT")])
+    assert batch.run()[0].tolist() == [2]
+
+
+def test_batch_multi_strip_chain(pa, oracle):
+    """Many strips chained through granules (20 kbp => 10 strips), mixed with short pairs."""
+    pairs = [gen_pair(20000, 0.05, seed=5), gen_pair(300, 0.1, seed=6), gen_pair(12345, 0.15, seed=7)]
+    costs, _ = pa.Batch(pairs).run()
+    for (a, b), c in zip(pairs, costs):
+        assert c == oracle.nw_cost(a, b, True)
+
+
+def test_batch_invalid_base(pa):
+    with pytest.raises(ValueError):
+        pa.Batch([(b"ACGTN", b"ACGT")]).run()

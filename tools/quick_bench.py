@@ -1,0 +1,22 @@
+"""Quick timing probe of the batched full-DP path (not the contract bench; see bench.py)."""
+import sys
+import time
+
+sys.path.insert(0, ".")
+import astar_pairwise_aligner_amd as pa
+from astar_pairwise_aligner_amd.generate import generate_pair
+
+pa.require_gpu()
+for (n, pairs) in [(100000, 1), (100000, 4), (100000, 16), (100000, 32), (10000, 1000)]:
+    ps = [generate_pair(n, 0.05, seed=s + 1) for s in range(pairs)]
+    b = pa.Batch(ps)
+    st = b.stats()
+    costs, ms = b.run()
+    best = 1e9
+    for _ in range(3):
+        t = time.time()
+        costs, ms = b.run()
+        best = min(best, time.time() - t)
+    print(f"n={n} pairs={pairs} strips={int(st['strips'])} kernel_ms={ms:.3f} wall_ms={best*1e3:.3f} "
+          f"GCUPS(kernel)={st['cells']/ms/1e6:.1f} GCUPS(wall)={st['cells']/best/1e9:.1f} cost0={costs[0]}", flush=True)
+    b.close()

@@ -4,5 +4,7 @@ RagnarGrootKoerkamp/astar-pairwise-aligner (pa-bitpacking + the astarpa2 block e
 The compute path is hand-written HIP for gfx950 in libastarpa_c_hip.so (built in-tree from csrc/);
 this package is the thin host-side mirror of the reference's interfaces.  No CPU fallback exists.
 """
-from . import _build, capi, generate  # noqa: F401
+from . import _build, aligner, capi, generate  # noqa: F401
+from .aligner import (AstarPa2, AstarPa2Params, BlockParams, astarpa2_full, astarpa2_nw,  # noqa: F401
+                      astarpa2_simple, c_abi_align)
 from .capi import Batch, PaError, compute, fill, profile_build, require_gpu  # noqa: F401

@@ -1,0 +1,264 @@
+// engine_hip.hip -- the A*PA2 block engine (engine.hpp) driven by the HIP strip kernels.
+//
+// HipBackend keeps the pair's profile (packed codes of a, BitProfile words of b) and the persistent
+// horizontal-delta row (one byte per column, blocks.rs:103-105) resident on the GPU; every
+// compute / fill rectangle of the engine is one chained-strip launch of strip_kernel.  Block right-edge
+// columns (`Block::v`) live in host memory because the band logic reads them (Block::index).
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "engine_capi.hpp"
+#include "pa_hip_internal.hpp"
+
+namespace pa {
+
+using engine::BlockParams;
+using engine::Cost;
+using engine::HMode;
+using engine::I;
+using engine::V;
+
+struct HipBackend {
+    std::vector<uint8_t> a_, b_;
+    DeviceBuf d_a, d_b, d_codes, d_prof, d_h, d_htmp, d_v, d_gran, d_jobs, d_misc, d_values;
+    size_t w_total = 0;
+    hipStream_t s = nullptr;
+    bool ok = false;
+    int err = 0;
+    bool has_h = false;
+    // pinned staging
+    void* h_stage = nullptr;
+    size_t h_stage_size = 0;
+
+    HipBackend(const uint8_t* a, size_t n, const uint8_t* b, size_t m) : a_(a, a + n), b_(b, b + m) {
+        if (!ensure_device()) { err = PA_E_HIP; return; }
+        w_total = (m + 63) / 64;
+        const size_t cw = (n + 15) / 16 + 2;
+        if (!d_a.alloc(n) || !d_b.alloc(m) || !d_codes.alloc(cw * 4) || !d_prof.alloc(w_total * 16) ||
+            !d_v.alloc(w_total * 16) || !d_misc.alloc(16) || !d_htmp.alloc(n + 64)) { err = PA_E_HIP; return; }
+        if (!hip_ok(hipStreamCreate(&s), "hipStreamCreate")) { err = PA_E_HIP; return; }
+        bool good = hip_ok(hipMemsetAsync(d_codes.ptr, 0, cw * 4, s), "memset") &&
+                    hip_ok(hipMemsetAsync(d_misc.ptr, 0, 16, s), "memset") &&
+                    (n == 0 || hip_ok(hipMemcpyAsync(d_a.ptr, a, n, hipMemcpyHostToDevice, s), "H2D a")) &&
+                    (m == 0 || hip_ok(hipMemcpyAsync(d_b.ptr, b, m, hipMemcpyHostToDevice, s), "H2D b")) &&
+                    encode_a_device(d_a.as<uint8_t>(), (int)n, d_codes.as<uint32_t>(), d_misc.as<uint32_t>() + 3, s) &&
+                    build_b_device(d_b.as<uint8_t>(), (int)m, d_prof.as<uint64_t>(), d_misc.as<uint32_t>() + 3, s);
+        uint32_t misc[4] = {0, 0, 0, 0};
+        good = good && hip_ok(hipMemcpyAsync(misc, d_misc.ptr, 16, hipMemcpyDeviceToHost, s), "D2H") &&
+               hip_ok(hipStreamSynchronize(s), "sync");
+        if (!good) { err = PA_E_HIP; return; }
+        if (misc[3]) {
+            set_error("sequence contains a base outside ACGT");
+            err = PA_E_INVALID_BASE;
+            return;
+        }
+        ok = true;
+    }
+    ~HipBackend() {
+        if (h_stage) (void)hipHostFree(h_stage);
+        if (s) (void)hipStreamDestroy(s);
+    }
+
+    I n() const { return (I)a_.size(); }
+    I m() const { return (I)b_.size(); }
+    const uint8_t* a() const { return a_.data(); }
+    const uint8_t* b() const { return b_.data(); }
+
+    void fail(int code) {
+        err = code;
+        throw engine::EnginePanic(std::string("HIP backend failure: ") + pa_last_error());
+    }
+
+    void enable_h_row() {  // blocks.rs:119-123: vec![(0,0); a.len()]
+        if (has_h) return;
+        if (!d_h.alloc(a_.size() + 64) || !hip_ok(hipMemsetAsync(d_h.ptr, 0, a_.size() + 64, s), "memset h")) fail(PA_E_HIP);
+        has_h = true;
+    }
+
+    void* stage(size_t bytes) {
+        if (bytes > h_stage_size) {
+            if (h_stage) (void)hipHostFree(h_stage);
+            h_stage = nullptr;
+            h_stage_size = 0;
+            const size_t want = std::max<size_t>(bytes * 2, 1 << 16);
+            if (!hip_ok(hipHostMalloc(&h_stage, want, hipHostMallocDefault), "hipHostMalloc")) fail(PA_E_HIP);
+            h_stage_size = want;
+        }
+        return h_stage;
+    }
+
+    // One rectangle launch.  hin/hout are device byte rows indexed by absolute column (or nullptr).
+    Cost launch_rect(I i0, I i1, size_t w0, size_t w1, V* v, const uint8_t* hin, uint8_t* hout, bool exact,
+                     V* values_host, int8_t* hbot_host) {
+        const int n = i1 - i0;
+        const size_t w = w1 - w0;
+        const bool fill = values_host != nullptr;
+        const size_t ngran = rect_granules(n, (int)w);
+        const size_t G = (size_t)(n + 15) / 16;
+        if (d_gran.size < ngran * 8 && !d_gran.alloc(std::max<size_t>(ngran * 8 * 2, 4096))) fail(PA_E_HIP);
+        if (fill && d_values.size < (size_t)n * w * 16 && !d_values.alloc((size_t)n * w * 16 * 2)) fail(PA_E_HIP);
+        std::vector<StripJob> jobs;
+        RectPlan r;
+        r.a_codes = d_codes.as<uint32_t>();
+        r.col0 = i0;
+        r.b_prof = d_prof.as<uint32_t>();
+        r.v = d_v.as<uint32_t>();
+        r.n = n;
+        r.w0 = (int)w0;
+        r.w1 = (int)w1;
+        r.hin_arr = hin;
+        r.hout_arr = hout;
+        r.gran = d_gran.as<uint64_t>();
+        r.gran_stride = G;
+        r.sum_out = d_misc.as<int32_t>() + 2;
+        r.exact_end = exact;
+        r.values = fill ? d_values.as<uint32_t>() : nullptr;
+        r.fill_stride = (int)w;
+        r.fill_word0 = 0;
+        plan_rect(jobs, r);
+        if (fill)
+            for (auto& j : jobs) j.fill_word0 = j.word0 - (int)w0;
+        const size_t jb = jobs.size() * sizeof(StripJob);
+        if (d_jobs.size < jb && !d_jobs.alloc(jb * 2)) fail(PA_E_HIP);
+        // stage: [jobs | v]
+        uint8_t* st = (uint8_t*)stage(jb + w * 16 + 64);
+        std::memcpy(st, jobs.data(), jb);
+        std::memcpy(st + jb, v, w * 16);
+        bool good = hip_ok(hipMemcpyAsync(d_jobs.ptr, st, jb, hipMemcpyHostToDevice, s), "H2D jobs") &&
+                    hip_ok(hipMemcpyAsync(d_v.as<uint8_t>() + w0 * 16, st + jb, w * 16, hipMemcpyHostToDevice, s), "H2D v") &&
+                    (ngran == 0 || hip_ok(hipMemsetAsync(d_gran.ptr, 0, ngran * 8, s), "memset gran")) &&
+                    launch_strips(d_jobs.as<StripJob>(), (int)jobs.size(), fill, d_misc.as<uint32_t>(), s);
+        if (!good) fail(PA_E_HIP);
+        uint32_t* misc = (uint32_t*)(st + jb + w * 16);  // 16 B inside the pinned stage
+        good = hip_ok(hipMemcpyAsync(st + jb, d_v.as<uint8_t>() + w0 * 16, w * 16, hipMemcpyDeviceToHost, s), "D2H v") &&
+               hip_ok(hipMemcpyAsync(misc, d_misc.ptr, 16, hipMemcpyDeviceToHost, s), "D2H misc");
+        if (fill) {
+            good = good && hip_ok(hipMemcpyAsync(values_host, d_values.ptr, (size_t)n * w * 16, hipMemcpyDeviceToHost, s), "D2H values") &&
+                   hip_ok(hipMemcpyAsync(hbot_host, hout + i0, (size_t)n, hipMemcpyDeviceToHost, s), "D2H hbot");
+        }
+        good = good && hip_ok(hipStreamSynchronize(s), "sync");
+        if (!good) fail(PA_E_HIP);
+        if (misc[1] != PA_ERR_NONE) {
+            set_error("device spin timeout (err=%u)", misc[1]);
+            fail(PA_E_TIMEOUT);
+        }
+        std::memcpy(v, st + jb, w * 16);
+        return (Cost)(int32_t)misc[2];
+    }
+
+    Cost sum_h_row(I i0, I i1) {  // empty word range: bottom row == top row
+        std::vector<uint8_t> h((size_t)(i1 - i0));
+        if (!hip_ok(hipMemcpyAsync(h.data(), d_h.as<uint8_t>() + i0, h.size(), hipMemcpyDeviceToHost, s), "D2H h") ||
+            !hip_ok(hipStreamSynchronize(s), "sync"))
+            fail(PA_E_HIP);
+        Cost c = 0;
+        for (uint8_t x : h) c += (Cost)(x & 1) - (Cost)((x >> 1) & 1);
+        return c;
+    }
+
+    // blocks.rs:686-748 (the `simd` / `no_ilp` switches select CPU schedules in the reference; results are
+    // schedule independent, the GPU always runs its strip schedule).
+    Cost compute(I i0, I i1, size_t w0, size_t w1, V* v, HMode mode, const BlockParams&) {
+        const I n = i1 - i0;
+        if (n <= 0) return 0;
+        if (w0 >= w1) {
+            switch (mode) {
+                case HMode::None: return n;
+                case HMode::Output:
+                    if (!hip_ok(hipMemsetAsync(d_h.as<uint8_t>() + i0, 1, (size_t)n, s), "memset h")) fail(PA_E_HIP);
+                    return n;
+                default: return sum_h_row(i0, i1);
+            }
+        }
+        switch (mode) {
+            case HMode::None: return launch_rect(i0, i1, w0, w1, v, nullptr, nullptr, false, nullptr, nullptr);
+            case HMode::Input: return launch_rect(i0, i1, w0, w1, v, d_h.as<uint8_t>(), nullptr, false, nullptr, nullptr);
+            case HMode::Update: return launch_rect(i0, i1, w0, w1, v, d_h.as<uint8_t>(), d_h.as<uint8_t>(), true, nullptr, nullptr);
+            case HMode::Output: return launch_rect(i0, i1, w0, w1, v, nullptr, d_h.as<uint8_t>(), true, nullptr, nullptr);
+        }
+        return 0;
+    }
+
+    // blocks.rs:627-648
+    void fill(I i0, I i1, size_t w0, size_t w1, V* v, V* values, int8_t* hbot, const BlockParams&) {
+        const I n = i1 - i0;
+        if (n <= 0) return;
+        if (w0 >= w1) {
+            for (I i = 0; i < n; ++i) hbot[i] = 1;
+            return;
+        }
+        std::vector<int8_t> raw((size_t)n);
+        launch_rect(i0, i1, w0, w1, v, nullptr, d_htmp.as<uint8_t>(), true, values, raw.data());
+        for (I i = 0; i < n; ++i) hbot[i] = (int8_t)((raw[i] & 1) - ((raw[i] >> 1) & 1));
+    }
+
+    std::vector<int8_t> debug_read_h(I i0, I i1) {
+        std::vector<uint8_t> h((size_t)(i1 - i0));
+        if (!hip_ok(hipMemcpyAsync(h.data(), d_h.as<uint8_t>() + i0, h.size(), hipMemcpyDeviceToHost, s), "D2H h") ||
+            !hip_ok(hipStreamSynchronize(s), "sync"))
+            fail(PA_E_HIP);
+        std::vector<int8_t> r;
+        for (uint8_t x : h) r.push_back((int8_t)((x & 1) - ((x >> 1) & 1)));
+        return r;
+    }
+    void debug_write_h(I i0, I i1, const std::vector<int8_t>& x) {
+        std::vector<uint8_t> h((size_t)(i1 - i0));
+        for (size_t k = 0; k < h.size(); ++k) h[k] = (uint8_t)((x[k] > 0 ? 1 : 0) | (x[k] < 0 ? 2 : 0));
+        if (!hip_ok(hipMemcpyAsync(d_h.as<uint8_t>() + i0, h.data(), h.size(), hipMemcpyHostToDevice, s), "H2D h") ||
+            !hip_ok(hipStreamSynchronize(s), "sync"))
+            fail(PA_E_HIP);
+    }
+};
+
+// Shared by pa_align and the astarpa-c symbols.  Returns 0 or a PA_E_* code.
+int align_hip(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params& params,
+              bool trace, bool self_check, int32_t* cost_out, std::string* cigar_out, pa_astarpa2_stats* stats_out) {
+    if (!engine::params_valid(params)) {
+        set_error("invalid A*PA2 parameters");
+        return PA_E_ARG;
+    }
+    if (a_len > (size_t)(1u << 30) || b_len > (size_t)(1u << 30)) {
+        set_error("sequence too long for i32 coordinates");
+        return PA_E_ARG;
+    }
+    HipBackend be(a, a_len, b, b_len);
+    if (!be.ok) return be.err ? be.err : PA_E_HIP;
+    const engine::AstarPa2Params p = engine::params_from_c(params);
+    engine::AlignResult r;
+    try {
+        r = engine::cost_or_align(p, be, trace, self_check);
+    } catch (const engine::EnginePanic& e) {
+        if (be.err) return be.err;
+        set_error("astarpa2 engine panic: %s", e.what());
+        return PA_E_INTERNAL;
+    }
+    if (cost_out) *cost_out = r.cost;
+    if (cigar_out) *cigar_out = r.has_cigar ? r.cigar.to_string() : std::string();
+    if (stats_out) engine::stats_to_c(r.stats, stats_out);
+    return 0;
+}
+
+}  // namespace pa
+
+using namespace pa;
+
+extern "C" void pa_params_nw(pa_astarpa2_params* p) { engine::params_to_c(engine::AstarPa2Params::nw(), p); }
+extern "C" void pa_params_simple(pa_astarpa2_params* p) { engine::params_to_c(engine::AstarPa2Params::simple(), p); }
+extern "C" void pa_params_full(pa_astarpa2_params* p) { engine::params_to_c(engine::AstarPa2Params::simple(), p); }
+
+extern "C" int pa_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params* params,
+                        int trace, int32_t* cost_out, char** cigar_out, pa_astarpa2_stats* stats_out) {
+    if (!params) return PA_E_ARG;
+    std::string cigar;
+    const bool self_check = std::getenv("PA_ENGINE_SELF_CHECK") != nullptr;
+    const int rc = align_hip(a, a_len, b, b_len, *params, trace != 0, self_check, cost_out, &cigar, stats_out);
+    if (cigar_out) {
+        *cigar_out = nullptr;
+        if (rc == 0 && trace) {
+            *cigar_out = (char*)std::malloc(cigar.size() + 1);
+            std::memcpy(*cigar_out, cigar.c_str(), cigar.size() + 1);
+        }
+    }
+    return rc;
+}

@@ -105,7 +105,7 @@ bool ensure_device() {
 
 bool DeviceBuf::alloc(size_t bytes) {
     release();
-    if (bytes == 0) bytes = 16;
+    if (bytes < 64) bytes = 64;
     if (!hip_ok(hipMalloc(&ptr, bytes), "hipMalloc")) {
         ptr = nullptr;
         return false;
@@ -144,6 +144,7 @@ void plan_rect(std::vector<StripJob>& jobs, const RectPlan& r) {
         j.b_prof = r.b_prof;
         j.v = r.v;
         j.n = r.n;
+        j.col0 = r.col0;
         j.word0 = r.w0 + s * kWordsPerStrip;
         const int words = std::min(kWordsPerStrip, w - s * kWordsPerStrip);
         j.nlanes = 2 * words;
@@ -255,23 +256,24 @@ static int32_t rect_host(const uint64_t* a2, size_t n, const uint64_t* b2, size_
         return s;
     }
     const size_t cw = (n + 15) / 16;
-    std::vector<uint32_t> codes(cw, 0), hin(cw, 0);
+    std::vector<uint32_t> codes(cw, 0);
+    std::vector<uint8_t> hin(n, 0);
     for (size_t i = 0; i < n; ++i) {
         const uint32_t r = (uint32_t)(a2[2 * i] & 1) | ((uint32_t)(a2[2 * i + 1] & 1) << 1);
         codes[i / 16] |= r << (2 * (i % 16));
-        hin[i / 16] |= ((uint32_t)(h2[2 * i] & 1) | ((uint32_t)(h2[2 * i + 1] & 1) << 1)) << (2 * (i % 16));
+        hin[i] = (uint8_t)((h2[2 * i] & 1) | ((h2[2 * i + 1] & 1) << 1));
     }
     const size_t ngran = rect_granules((int)n, (int)w);
     DeviceBuf d_codes, d_prof, d_v, d_hin, d_hout, d_gran, d_jobs, d_misc, d_values;
-    if (!d_codes.alloc(cw * 4) || !d_prof.alloc(w * 16) || !d_v.alloc(w * 16) || !d_hin.alloc(cw * 4) ||
-        !d_hout.alloc(cw * 4) || !d_gran.alloc(ngran * 8) || !d_misc.alloc(16))
+    if (!d_codes.alloc(cw * 4) || !d_prof.alloc(w * 16) || !d_v.alloc(w * 16) || !d_hin.alloc(n) ||
+        !d_hout.alloc(n) || !d_gran.alloc(ngran * 8) || !d_misc.alloc(16))
         return INT32_MIN;
     if (values && !d_values.alloc(n * w * 16)) return INT32_MIN;
     hipStream_t s = 0;
     bool ok = hip_ok(hipMemcpyAsync(d_codes.ptr, codes.data(), cw * 4, hipMemcpyHostToDevice, s), "H2D") &&
               hip_ok(hipMemcpyAsync(d_prof.ptr, b2, w * 16, hipMemcpyHostToDevice, s), "H2D") &&
               hip_ok(hipMemcpyAsync(d_v.ptr, v2, w * 16, hipMemcpyHostToDevice, s), "H2D") &&
-              hip_ok(hipMemcpyAsync(d_hin.ptr, hin.data(), cw * 4, hipMemcpyHostToDevice, s), "H2D") &&
+              hip_ok(hipMemcpyAsync(d_hin.ptr, hin.data(), n, hipMemcpyHostToDevice, s), "H2D") &&
               hip_ok(hipMemsetAsync(d_gran.ptr, 0, std::max<size_t>(ngran * 8, 16), s), "memset gran") &&
               hip_ok(hipMemsetAsync(d_misc.ptr, 0, 16, s), "memset misc");
     if (!ok) return INT32_MIN;
@@ -284,8 +286,8 @@ static int32_t rect_host(const uint64_t* a2, size_t n, const uint64_t* b2, size_
     r.n = (int)n;
     r.w0 = 0;
     r.w1 = (int)w;
-    r.hin_arr = d_hin.as<uint32_t>();
-    r.hout_arr = d_hout.as<uint32_t>();
+    r.hin_arr = d_hin.as<uint8_t>();
+    r.hout_arr = d_hout.as<uint8_t>();
     r.gran = d_gran.as<uint64_t>();
     r.gran_stride = cw;
     r.sum_out = d_misc.as<int32_t>() + 2;
@@ -300,10 +302,10 @@ static int32_t rect_host(const uint64_t* a2, size_t n, const uint64_t* b2, size_
          launch_strips(d_jobs.as<StripJob>(), (int)jobs.size(), values != nullptr, d_misc.as<uint32_t>(), s);
     if (!ok) return INT32_MIN;
     uint32_t misc[4] = {0, 0, 0, 0};
-    std::vector<uint32_t> hout(cw, 0);
+    std::vector<uint8_t> hout(n, 0);
     ok = hip_ok(hipMemcpyAsync(misc, d_misc.ptr, 16, hipMemcpyDeviceToHost, s), "D2H") &&
          hip_ok(hipMemcpyAsync(v2, d_v.ptr, w * 16, hipMemcpyDeviceToHost, s), "D2H") &&
-         (r.hout_arr == nullptr || hip_ok(hipMemcpyAsync(hout.data(), d_hout.ptr, cw * 4, hipMemcpyDeviceToHost, s), "D2H")) &&
+         (r.hout_arr == nullptr || hip_ok(hipMemcpyAsync(hout.data(), d_hout.ptr, n, hipMemcpyDeviceToHost, s), "D2H")) &&
          (!values || hip_ok(hipMemcpyAsync(values, d_values.ptr, n * w * 16, hipMemcpyDeviceToHost, s), "D2H values")) &&
          hip_ok(hipStreamSynchronize(s), "sync");
     if (!ok) return INT32_MIN;
@@ -313,7 +315,7 @@ static int32_t rect_host(const uint64_t* a2, size_t n, const uint64_t* b2, size_
     }
     if (r.hout_arr) {
         for (size_t i = 0; i < n; ++i) {
-            const uint32_t x = (hout[i / 16] >> (2 * (i % 16))) & 3u;
+            const uint32_t x = hout[i] & 3u;
             h2[2 * i] = x & 1;
             h2[2 * i + 1] = x >> 1;
         }
@@ -382,7 +384,7 @@ extern "C" pa_batch* pa_batch_create(const uint8_t* const* a, const size_t* a_le
     }
     p->total_gran = tg;
     if (!p->d_a.alloc(ta) || !p->d_b.alloc(tb) || !p->d_codes.alloc(tc * 4) || !p->d_prof.alloc(tp * 16) ||
-        !p->d_v.alloc(tp * 16) || !p->d_gran.alloc(tg * 8) || !p->d_sums.alloc(pairs * 4) || !p->d_misc.alloc(16))
+        !p->d_v.alloc(tp * 16) || !p->d_gran.alloc(tg * 8) || !p->d_sums.alloc(std::max<size_t>(pairs * 4, 16)) || !p->d_misc.alloc(16))
         return nullptr;
     if (!hip_ok(hipStreamCreate(&p->stream), "hipStreamCreate") || !hip_ok(hipEventCreate(&p->ev0), "event") ||
         !hip_ok(hipEventCreate(&p->ev1), "event"))

@@ -32,12 +32,13 @@ struct DeviceBuf {
 
 // One rectangle = words [w0,w1) x n columns of one pair, split into chained strips.
 struct RectPlan {
-    const uint32_t* a_codes = nullptr;  // device, already offset to the rectangle's first column (16-column aligned)
+    const uint32_t* a_codes = nullptr;  // device, packed codes of the whole sequence
+    int col0 = 0;                       // absolute first column of the rectangle
     const uint32_t* b_prof = nullptr;   // device, u32 view of the pair's profile (word 0)
     uint32_t* v = nullptr;              // device, u32 view of the v column (word 0 of the same indexing as b_prof)
     int n = 0, w0 = 0, w1 = 0;
-    const uint32_t* hin_arr = nullptr;  // packed top deltas or nullptr (+1)
-    uint32_t* hout_arr = nullptr;       // packed bottom deltas out or nullptr
+    const uint8_t* hin_arr = nullptr;   // per-absolute-column top deltas or nullptr (+1)
+    uint8_t* hout_arr = nullptr;        // per-absolute-column bottom deltas out or nullptr
     uint64_t* gran = nullptr;           // (S-1) * gran_stride granules, zeroed before launch
     size_t gran_stride = 0;             // >= ceil(n/16)
     int32_t* sum_out = nullptr;

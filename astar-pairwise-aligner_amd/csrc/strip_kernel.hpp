@@ -23,17 +23,30 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifdef PA_STRIP_DEBUG
+// Probe builds only (tools/strip_probe.hip): lane 0 publishes progress markers to host-visible memory.
+extern __device__ unsigned int* g_pa_dbg;
+#define PA_DBG(slot, value)                                                                               \
+    do {                                                                                                    \
+        if (g_pa_dbg && (threadIdx.x & 63) == 0)                                                            \
+            __hip_atomic_store(g_pa_dbg + (slot), (unsigned int)(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+    } while (0)
+#else
+#define PA_DBG(slot, value) do { } while (0)
+#endif
+
 namespace pa {
 
 // One strip job = one wavefront.  All pointers are device pointers.
 struct StripJob {
-    const uint32_t* a_codes;  // 2-bit base codes (A0 C1 G2 T3), 16 per u32: column i at bits 2*(i%16)+{0,1} of word i/16
+    const uint32_t* a_codes;  // 2-bit base codes (A0 C1 G2 T3) of the WHOLE sequence a, 16 per u32: column i at bits
+                              // 2*(i%16)+{0,1} of word i/16; the rectangle starts at absolute column `col0`
     const uint32_t* b_prof;   // BitProfile of b: u32 view of (nb0:u64, nb1:u64) per 64-row word (profile.rs:112-133)
     uint32_t* v;              // V(p:u64, m:u64) per 64-row word, u32 view, updated in place (encoding.rs:5-6)
     const uint64_t* hin_gran; // granules from the strip above (tag = chunk+1), or nullptr
-    const uint32_t* hin_arr;  // packed top-row deltas (16 columns/u32: bit 2k = +1, bit 2k+1 = -1), or nullptr => all +1
+    const uint8_t* hin_arr;   // top-row deltas, one byte per ABSOLUTE column (bit0 = +1, bit1 = -1), or nullptr => all +1
     uint64_t* hout_gran;      // granules for the strip below, or nullptr
-    uint32_t* hout_arr;       // packed bottom-row deltas out, or nullptr
+    uint8_t* hout_arr;        // bottom-row deltas out, one byte per ABSOLUTE column, or nullptr
     uint32_t* values;         // fill mode: V of every column, u32 view of values[col][fill_stride] (V each); or nullptr
     int32_t* sum_out;         // *sum_out = sum of bottom-row deltas over the n columns (if non-null)
     int32_t n;                // columns
@@ -47,7 +60,7 @@ struct StripJob {
                               //    corrected with their right edge -- the identity the reference's padded tail uses
                               //    (simd.rs:184-225).
     int32_t flags;            // kJobVInitOne: start from V::one() instead of loading v (first column, blocks.rs:163)
-    int32_t pad_;
+    int32_t col0;             // absolute index of the rectangle's first column (into a_codes / hin_arr / hout_arr)
 };
 enum : int32_t { kJobVInitOne = 1 };
 static_assert(sizeof(StripJob) == 104, "StripJob layout");
@@ -128,26 +141,23 @@ __device__ __forceinline__ uint64_t load_granule(const uint64_t* g) {
 }
 
 // Resolve the (possibly prefetched) granule of chunk q; polls when the producer is not there yet.
-__device__ __forceinline__ bool resolve_granule(const uint64_t* g, uint64_t pre, int q, uint32_t& bits, uint32_t* err) {
+// Returns false (after a bounded number of polls) if the producer never delivered.
+__device__ __forceinline__ bool resolve_granule(const uint64_t* g, uint64_t pre, int q, uint32_t& bits) {
     uint32_t spins = 0;
-    for (;;) {
-        const uint32_t tag = rfl((uint32_t)(pre >> 32));
-        if (tag == (uint32_t)(q + 1)) {
-            bits = rfl((uint32_t)pre);
-            return true;
-        }
-        if (++spins > kSpinLimit) {
-            if (err) __hip_atomic_store(err, (uint32_t)PA_ERR_SPIN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
+    uint32_t tag = rfl((uint32_t)(pre >> 32));
+    while (tag != (uint32_t)(q + 1) && spins < kSpinLimit) {
         __builtin_amdgcn_s_sleep(1);
         pre = load_granule(g + q);
+        tag = rfl((uint32_t)(pre >> 32));
+        ++spins;
     }
+    bits = rfl((uint32_t)pre);
+    return tag == (uint32_t)(q + 1);
 }
 
-// Process one strip.  Returns false on a spin timeout.
+// Process one strip.  On a spin timeout the error word is set and the strip stops early.
 template <bool FILL>
-__device__ __forceinline__ bool run_strip(const StripJob& job, uint32_t* err) {
+__device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
     const int lane = (int)(threadIdx.x & 63);
     const int n = job.n;
     const int G = (n + 15) >> 4;  // 16-column chunks == granules
@@ -176,25 +186,40 @@ __device__ __forceinline__ bool run_strip(const StripJob& job, uint32_t* err) {
     const uint32_t sh = 2u * (uint32_t)(lane & 15);
     const bool exact_tail = job.exact_tail != 0 && job.nlanes < 64;
 
+    // Lane j (< 16) of XS carries the packed pipeline input of column 16q+j: base code and top delta.
+    const int cj = lane & 15;
+    auto load_code = [&](int q) -> uint32_t {
+        const int c = 16 * q + cj;
+        if (c >= n) return 0u;
+        const int ca = job.col0 + c;
+        return (job.a_codes[ca >> 4] >> (2 * (ca & 15))) & 3u;
+    };
+    auto load_hin_arr = [&](int q) -> uint32_t {
+        const int c = 16 * q + cj;
+        if (c >= n || !job.hin_arr) return 1u;  // H::one() (blocks.rs:732)
+        return (uint32_t)job.hin_arr[job.col0 + c] & 3u;
+    };
     uint64_t pre = 0;
     if (job.hin_gran && G > 0) pre = load_granule(job.hin_gran);
-    uint32_t codes_next = (G > 0) ? job.a_codes[0] : 0u;
+    uint32_t code_next = load_code(0);
+    uint32_t hin_next = load_hin_arr(0);
 
     // Steps t = 0 .. 16*(G+4)-1; lane l handles column t-l.  `acc` lags one step, so after chunk q
     // lane 63's acc holds the bottom-row deltas of columns 16(q-4) .. 16(q-4)+15 == granule q-4.
-    for (int q = 0; q < G + 4; ++q) {
-        uint32_t hin = 0x55555555u;  // H::one() for every column (blocks.rs:732)
-        if (q < G) {
-            if (job.hin_gran) {
-                if (!resolve_granule(job.hin_gran, pre, q, hin, err)) return false;
-                if (q + 1 < G) pre = load_granule(job.hin_gran + q + 1);
-            } else if (job.hin_arr) {
-                hin = job.hin_arr[q];
-            }
+    bool alive = true;
+    PA_DBG(1, 1);
+    for (int q = 0; q < G + 4 && alive; ++q) {
+        PA_DBG(2, q + 1);
+        uint32_t hin2 = hin_next;
+        if (q < G && job.hin_gran) {
+            uint32_t bits;
+            alive = resolve_granule(job.hin_gran, pre, q, bits);
+            if (q + 1 < G) pre = load_granule(job.hin_gran + q + 1);
+            hin2 = (bits >> sh) & 3u;
         }
-        const uint32_t codes = codes_next;
-        codes_next = (q + 1 < G) ? job.a_codes[q + 1] : 0u;
-        const uint32_t XS = ((codes >> sh) << 30) | ((hin >> sh) & 3u);
+        const uint32_t XS = (code_next << 30) | hin2;
+        code_next = load_code(q + 1);
+        hin_next = load_hin_arr(q + 1);
 
         const bool interior = !FILL && (q >= 4) && (q * 16 + 15 < n);
         if (interior) {
@@ -216,12 +241,17 @@ __device__ __forceinline__ bool run_strip(const StripJob& job, uint32_t* err) {
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (job.hout_arr) {
-                if (lane == 0) job.hout_arr[g] = val;
+                if (lane < 16 && lane < cols) job.hout_arr[job.col0 + 16 * g + lane] = (uint8_t)((val >> (2 * lane)) & 3u);
             }
             sum += __builtin_popcount(val & 0x55555555u) - __builtin_popcount(val & 0xAAAAAAAAu);
         }
     }
 
+    PA_DBG(1, 2);
+    if (!alive) {
+        if (lane == 0) __hip_atomic_store(err, (uint32_t)PA_ERR_SPIN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     if (real) {
         job.v[word * 4 + half] = vp;
         job.v[word * 4 + 2 + half] = vm;
@@ -236,22 +266,24 @@ __device__ __forceinline__ bool run_strip(const StripJob& job, uint32_t* err) {
         }
         if (lane == 0) *job.sum_out = sum;
     }
-    return true;
+    PA_DBG(1, 3);
 }
 
-// Persistent strip kernel: each 64-thread block claims jobs by ticket until none are left.
+// One 64-thread block = one wavefront = one strip job, claimed by ticket (jobs are listed producer before
+// consumer, so a consumer's producer has always started; no assumption about dispatch order).
 // `ticket` and `err` must be zeroed (and every hin/hout granule buffer cleared) before the launch.
 template <bool FILL>
 __global__ __launch_bounds__(64) void strip_kernel(const StripJob* __restrict__ jobs, int njobs,
                                                    uint32_t* ticket, uint32_t* err) {
-    for (;;) {
-        uint32_t t = 0;
-        if ((threadIdx.x & 63) == 0) t = atomicAdd(ticket, 1u);
-        t = rfl(t);
-        if (t >= (uint32_t)njobs) return;
+    uint32_t t = 0;
+    if ((threadIdx.x & 63) == 0) t = atomicAdd(ticket, 1u);
+    t = rfl(t);
+    PA_DBG(0, t + 1);
+    if (t < (uint32_t)njobs) {
         const StripJob job = jobs[t];
-        if (!run_strip<FILL>(job, err)) return;
+        run_strip<FILL>(job, err);
     }
+    PA_DBG(0, 0x1000 + t);
 }
 
 }  // namespace pa

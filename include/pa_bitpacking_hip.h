@@ -34,6 +34,7 @@ extern "C" {
 #define PA_E_HIP (-2)          /* HIP runtime failure / no GPU */
 #define PA_E_TIMEOUT (-3)      /* device-side bounded spin expired */
 #define PA_E_ARG (-4)
+#define PA_E_INTERNAL (-5)     /* engine invariant violated (where the reference would panic) */
 
 const char* pa_last_error(void);
 

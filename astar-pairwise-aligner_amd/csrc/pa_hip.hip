@@ -79,6 +79,58 @@ __global__ void build_b_kernel(const uint8_t* __restrict__ b, int m, uint64_t* _
     if (invalid) atomicOr(bad, 1u);
 }
 
+// Batched forms (one launch for all pairs of a pa_batch): blockIdx.y = pair.
+struct PairDesc {
+    unsigned long long a_off, b_off, code_off, prof_off;  // element offsets into the concatenated buffers
+    int n, m;
+};
+
+__global__ void encode_a_batch_kernel(const uint8_t* __restrict__ a_cat, uint32_t* __restrict__ codes_cat,
+                                      const PairDesc* __restrict__ desc, uint32_t* __restrict__ bad) {
+    const PairDesc d = desc[blockIdx.y];
+    const int nwords = (d.n + 15) / 16;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwords) return;
+    const uint8_t* a = a_cat + d.a_off;
+    uint32_t w = 0;
+    bool invalid = false;
+    for (int k = 0; k < 16; ++k) {
+        const int c = i * 16 + k;
+        if (c < d.n) {
+            const int r = rank_acgt(a[c]);
+            invalid |= r < 0;
+            w |= (uint32_t)(r & 3) << (2 * k);
+        }
+    }
+    codes_cat[d.code_off + i] = w;
+    if (invalid) atomicOr(bad, 1u);
+}
+
+__global__ void build_b_batch_kernel(const uint8_t* __restrict__ b_cat, uint64_t* __restrict__ prof_cat,
+                                     const PairDesc* __restrict__ desc, uint32_t* __restrict__ bad) {
+    const PairDesc d = desc[blockIdx.y];
+    const int nwords = (d.m + 63) / 64;
+    const int word = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (word >= nwords) return;
+    const uint8_t* b = b_cat + d.b_off;
+    const int lane = threadIdx.x & 63;
+    const int j = word * 64 + lane;
+    int r = 3;
+    bool invalid = false;
+    if (j < d.m) {
+        r = rank_acgt(b[j]);
+        invalid = r < 0;
+        r &= 3;
+    }
+    const uint64_t nb0 = __ballot(((r & 1) ^ 1) != 0);
+    const uint64_t nb1 = __ballot((((r >> 1) & 1) ^ 1) != 0);
+    if (lane == 0) {
+        prof_cat[2 * (d.prof_off + word)] = nb0;
+        prof_cat[2 * (d.prof_off + word) + 1] = nb1;
+    }
+    if (invalid) atomicOr(bad, 1u);
+}
+
 template __global__ void strip_kernel<false>(const StripJob*, int, uint32_t*, uint32_t*);
 template __global__ void strip_kernel<true>(const StripJob*, int, uint32_t*, uint32_t*);
 
@@ -149,6 +201,7 @@ void plan_rect(std::vector<StripJob>& jobs, const RectPlan& r) {
         const int words = std::min(kWordsPerStrip, w - s * kWordsPerStrip);
         j.nlanes = 2 * words;
         j.flags = r.v_init_one ? kJobVInitOne : 0;
+        j.tail_rows = -1;
         if (s == 0) {
             j.hin_arr = r.hin_arr;  // nullptr => +1
         } else {
@@ -160,6 +213,7 @@ void plan_rect(std::vector<StripJob>& jobs, const RectPlan& r) {
         } else {
             j.hout_arr = r.hout_arr;
             j.sum_out = r.sum_out;
+            j.tail_rows = r.tail_rows;
             j.exact_tail = (r.exact_end || r.hout_arr) ? 1 : 0;
         }
         if (r.values) {
@@ -177,10 +231,10 @@ size_t rect_granules(int n, int w) {
     return S > 1 ? (size_t)(S - 1) * G : 0;
 }
 
-bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_ticket_err, hipStream_t s) {
+bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_ticket_err, hipStream_t s, bool zero_ticket) {
     if (njobs == 0) return true;
     // d_ticket_err[0] = ticket, [1] = err
-    if (!hip_ok(hipMemsetAsync(d_ticket_err, 0, 2 * sizeof(uint32_t), s), "memset ticket")) return false;
+    if (zero_ticket && !hip_ok(hipMemsetAsync(d_ticket_err, 0, 2 * sizeof(uint32_t), s), "memset ticket")) return false;
     const int grid = njobs;  // one wave per job; jobs beyond residency queue behind their producers (ticket order)
     if (fill)
         hipLaunchKernelGGL(strip_kernel<true>, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_ticket_err, d_ticket_err + 1);
@@ -339,7 +393,8 @@ extern "C" int32_t pa_bp_fill(const uint64_t* a2, size_t n, const uint64_t* b2, 
 struct pa_batch {
     size_t pairs = 0;
     std::vector<size_t> n, m, a_off, b_off, code_off, prof_off, gran_off;
-    DeviceBuf d_a, d_b, d_codes, d_prof, d_v, d_gran, d_jobs, d_sums, d_misc;
+    DeviceBuf d_a, d_b, d_codes, d_prof, d_v, d_gran, d_jobs, d_sums, d_misc, d_desc;
+    size_t max_n = 0, max_m = 0;
     std::vector<StripJob> jobs;
     std::vector<int> last_job;  // per pair (or -1 when w == 0)
     size_t total_gran = 0;
@@ -412,8 +467,21 @@ extern "C" pa_batch* pa_batch_create(const uint8_t* const* a, const size_t* a_le
         r.sum_out = p->d_sums.as<int32_t>() + i;
         r.exact_end = false;
         r.v_init_one = true;
+        r.tail_rows = (int)b_len[i];
         plan_rect(p->jobs, r);
         p->last_job[i] = (int)p->jobs.size() - 1;
+    }
+    {
+        std::vector<PairDesc> desc(pairs);
+        for (size_t i = 0; i < pairs; ++i) {
+            desc[i] = PairDesc{p->a_off[i], p->b_off[i], p->code_off[i], p->prof_off[i], (int)a_len[i], (int)b_len[i]};
+            p->max_n = std::max(p->max_n, a_len[i]);
+            p->max_m = std::max(p->max_m, b_len[i]);
+        }
+        if (!p->d_desc.alloc(pairs * sizeof(PairDesc))) return nullptr;
+        if (pairs && !hip_ok(hipMemcpyAsync(p->d_desc.ptr, desc.data(), pairs * sizeof(PairDesc), hipMemcpyHostToDevice, p->stream), "H2D desc"))
+            return nullptr;
+        if (!hip_ok(hipStreamSynchronize(p->stream), "sync")) return nullptr;  // desc is a local
     }
     if (!p->d_jobs.alloc(p->jobs.size() * sizeof(StripJob))) return nullptr;
     if (!p->jobs.empty() &&
@@ -428,31 +496,32 @@ extern "C" int pa_batch_run(pa_batch* p, int32_t* cost_out, float* kernel_ms) {
     hipStream_t s = p->stream;
     // (1) profiles (BitProfile::build, once per pair: blocks.rs:112)
     if (!hip_ok(hipMemsetAsync(p->d_misc.ptr, 0, 16, s), "memset")) return PA_E_HIP;
-    for (size_t i = 0; i < p->pairs; ++i) {
-        if (!encode_a_device(p->d_a.as<uint8_t>() + p->a_off[i], (int)p->n[i], p->d_codes.as<uint32_t>() + p->code_off[i],
-                             p->d_misc.as<uint32_t>() + 3, s))
-            return PA_E_HIP;
-        if (!build_b_device(p->d_b.as<uint8_t>() + p->b_off[i], (int)p->m[i], p->d_prof.as<uint64_t>() + p->prof_off[i] * 2,
-                            p->d_misc.as<uint32_t>() + 3, s))
-            return PA_E_HIP;
+    for (size_t base = 0; base < p->pairs; base += 32768) {  // gridDim.y limit
+        const unsigned ny = (unsigned)std::min<size_t>(32768, p->pairs - base);
+        const PairDesc* dd = p->d_desc.as<PairDesc>() + base;
+        if (p->max_n) {
+            const unsigned nx = (unsigned)(((p->max_n + 15) / 16 + 255) / 256);
+            hipLaunchKernelGGL(encode_a_batch_kernel, dim3(nx, ny), dim3(256), 0, s, p->d_a.as<uint8_t>(), p->d_codes.as<uint32_t>(), dd,
+                               p->d_misc.as<uint32_t>() + 3);
+        }
+        if (p->max_m) {
+            const unsigned nx = (unsigned)(((p->max_m + 63) / 64 + 3) / 4);
+            hipLaunchKernelGGL(build_b_batch_kernel, dim3(nx, ny), dim3(256), 0, s, p->d_b.as<uint8_t>(), p->d_prof.as<uint64_t>(), dd,
+                               p->d_misc.as<uint32_t>() + 3);
+        }
+        if (!hip_ok(hipGetLastError(), "profile kernels")) return PA_E_HIP;
     }
     // (2) clear hand-off granules, (3) strips
     if (p->total_gran && !hip_ok(hipMemsetAsync(p->d_gran.ptr, 0, p->total_gran * 8, s), "memset gran")) return PA_E_HIP;
     if (!hip_ok(hipMemsetAsync(p->d_sums.ptr, 0, std::max<size_t>(p->pairs * 4, 16), s), "memset sums")) return PA_E_HIP;
+    // d_misc (ticket, err, -, bad-base flag) was zeroed above; the events bracket the strip kernel alone
     if (!hip_ok(hipEventRecord(p->ev0, s), "event")) return PA_E_HIP;
-    if (!launch_strips(p->d_jobs.as<StripJob>(), (int)p->jobs.size(), false, p->d_misc.as<uint32_t>(), s)) return PA_E_HIP;
+    if (!launch_strips(p->d_jobs.as<StripJob>(), (int)p->jobs.size(), false, p->d_misc.as<uint32_t>(), s, false)) return PA_E_HIP;
     if (!hip_ok(hipEventRecord(p->ev1, s), "event")) return PA_E_HIP;
     // (4) read back: bottom sums and each pair's last v word (for the rows beyond |b| in the last word)
     std::vector<int32_t> sums(p->pairs, 0);
-    std::vector<uint64_t> lastv(2 * p->pairs, 0);
     uint32_t misc[4] = {0, 0, 0, 0};
     if (p->pairs && !hip_ok(hipMemcpyAsync(sums.data(), p->d_sums.ptr, p->pairs * 4, hipMemcpyDeviceToHost, s), "D2H")) return PA_E_HIP;
-    for (size_t i = 0; i < p->pairs; ++i) {
-        const size_t w = (p->m[i] + 63) / 64;
-        if (w == 0 || p->n[i] == 0 || p->m[i] % 64 == 0) continue;
-        if (!hip_ok(hipMemcpyAsync(&lastv[2 * i], p->d_v.as<uint64_t>() + (p->prof_off[i] + w - 1) * 2, 16, hipMemcpyDeviceToHost, s), "D2H v"))
-            return PA_E_HIP;
-    }
     if (!hip_ok(hipMemcpyAsync(misc, p->d_misc.ptr, 16, hipMemcpyDeviceToHost, s), "D2H")) return PA_E_HIP;
     if (!hip_ok(hipStreamSynchronize(s), "sync")) return PA_E_HIP;
     if (misc[3]) {
@@ -472,13 +541,8 @@ extern "C" int pa_batch_run(pa_batch* p, int32_t* cost_out, float* kernel_ms) {
         if (n == 0) { cost_out[i] = (int32_t)m; continue; }
         if (w == 0) { cost_out[i] = (int32_t)n; continue; }
         // bot_val = rounded |b| + sum of bottom deltas (blocks.rs:171,255-267); cost = get(|b|) (domain.rs:520)
-        int32_t bot = (int32_t)(w * 64) + sums[i];
-        if (m % 64 != 0) {
-            const int j = (int)(w * 64 - m);  // value_of_suffix(j), encoding.rs:33-38
-            const uint64_t mask = ~((1ull << (64 - j)) - 1);
-            bot -= (int32_t)__builtin_popcountll(lastv[2 * i] & mask) - (int32_t)__builtin_popcountll(lastv[2 * i + 1] & mask);
-        }
-        cost_out[i] = bot;
+        // the strip kernel already removed the rows beyond |b| of the last word (StripJob::tail_rows)
+        cost_out[i] = (int32_t)(w * 64) + sums[i];
     }
     return 0;
 }

@@ -44,13 +44,14 @@ struct RectPlan {
     int32_t* sum_out = nullptr;
     bool exact_end = false;
     bool v_init_one = false;
+    int tail_rows = -1;  // see StripJob::tail_rows
     uint32_t* values = nullptr;  // fill mode
     int fill_stride = 0, fill_word0 = 0;
 };
 
 void plan_rect(std::vector<StripJob>& jobs, const RectPlan& r);
 size_t rect_granules(int n, int w);
-bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_ticket_err, hipStream_t s);
+bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_ticket_err, hipStream_t s, bool zero_ticket = true);
 bool encode_a_device(const uint8_t* d_a, int n, uint32_t* d_codes, uint32_t* d_bad, hipStream_t s);
 bool build_b_device(const uint8_t* d_b, int m, uint64_t* d_prof, uint32_t* d_bad, hipStream_t s);
 

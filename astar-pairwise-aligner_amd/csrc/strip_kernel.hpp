@@ -61,9 +61,13 @@ struct StripJob {
                               //    (simd.rs:184-225).
     int32_t flags;            // kJobVInitOne: start from V::one() instead of loading v (first column, blocks.rs:163)
     int32_t col0;             // absolute index of the rectangle's first column (into a_codes / hin_arr / hout_arr)
+    int32_t tail_rows;        // >= 0: |b|; the reported sum additionally subtracts the right-edge deltas of rows >= |b|
+                              //       (Block::index from the bottom, block.rs:110-120), so the host adds 64*words only
+                              // < 0: plain sum of the bottom-row deltas
+    int32_t pad_;
 };
 enum : int32_t { kJobVInitOne = 1 };
-static_assert(sizeof(StripJob) == 104, "StripJob layout");
+static_assert(sizeof(StripJob) == 112, "StripJob layout");
 
 enum : uint32_t {
     PA_ERR_NONE = 0,
@@ -71,6 +75,17 @@ enum : uint32_t {
 };
 
 constexpr uint32_t kSpinLimit = 1u << 21;
+
+// Every pointer of a StripJob is device global memory; say so, or the compiler emits flat_* accesses whose
+// out-of-order return forces s_waitcnt vmcnt(0) everywhere.
+#define PA_GLOBAL __attribute__((address_space(1)))
+typedef const PA_GLOBAL uint32_t* gcu32;
+typedef const PA_GLOBAL uint8_t* gcu8;
+typedef const PA_GLOBAL uint64_t* gcu64;
+typedef PA_GLOBAL uint32_t* gu32;
+typedef PA_GLOBAL uint8_t* gu8;
+typedef PA_GLOBAL uint64_t* gu64;
+typedef PA_GLOBAL int32_t* gi32;
 
 __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t old_, uint32_t src) {
     // v_mov_b32_dpp wave_shr:1 ; lane 0 has no source lane and keeps `old_`.
@@ -119,7 +134,7 @@ __device__ __forceinline__ void myers_step(uint32_t s_x, uint32_t& X, uint32_t& 
 template <bool PRED, bool PASS, bool FILL>
 __device__ __forceinline__ void run_chunk(const StripJob& job, int q, uint32_t XS, uint32_t& X, uint32_t& vp,
                                           uint32_t& vm, uint32_t nb0, uint32_t nb1, uint32_t& acc, int lane,
-                                          bool pass_lane, uint32_t* vout) {
+                                          bool pass_lane, gu32 vout) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const uint32_t s_x = (uint32_t)__builtin_amdgcn_readlane((int)XS, j);
@@ -128,7 +143,7 @@ __device__ __forceinline__ void run_chunk(const StripJob& job, int q, uint32_t X
         myers_step<PRED, PASS>(s_x, X, vp, vm, nb0, nb1, acc, active, pass_lane);
         if (FILL) {
             if (active && lane < job.nlanes) {
-                uint32_t* dst = vout + (size_t)col * (size_t)job.fill_stride * 4;
+                gu32 dst = vout + (size_t)col * (size_t)job.fill_stride * 4;
                 dst[0] = vp;
                 dst[2] = vm;
             }
@@ -136,13 +151,13 @@ __device__ __forceinline__ void run_chunk(const StripJob& job, int q, uint32_t X
     }
 }
 
-__device__ __forceinline__ uint64_t load_granule(const uint64_t* g) {
+__device__ __forceinline__ uint64_t load_granule(gcu64 g) {
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Resolve the (possibly prefetched) granule of chunk q; polls when the producer is not there yet.
 // Returns false (after a bounded number of polls) if the producer never delivered.
-__device__ __forceinline__ bool resolve_granule(const uint64_t* g, uint64_t pre, int q, uint32_t& bits) {
+__device__ __forceinline__ bool resolve_granule(gcu64 g, uint64_t pre, int q, uint32_t& bits) {
     uint32_t spins = 0;
     uint32_t tag = rfl((uint32_t)(pre >> 32));
     while (tag != (uint32_t)(q + 1) && spins < kSpinLimit) {
@@ -167,19 +182,21 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
     const int half = lane & 1;
 
     uint32_t vp = 0, vm = 0, nb0 = 0, nb1 = 0;
+    const gcu32 g_prof = (gcu32)job.b_prof;
+    const gu32 g_v = (gu32)job.v;
     if (real) {
-        nb0 = job.b_prof[word * 4 + half];
-        nb1 = job.b_prof[word * 4 + 2 + half];
+        nb0 = g_prof[word * 4 + half];
+        nb1 = g_prof[word * 4 + 2 + half];
         if (job.flags & kJobVInitOne) {
             vp = 0xFFFFFFFFu;
             vm = 0u;
         } else {
-            vp = job.v[word * 4 + half];
-            vm = job.v[word * 4 + 2 + half];
+            vp = g_v[word * 4 + half];
+            vm = g_v[word * 4 + 2 + half];
         }
     }
-    uint32_t* vout = nullptr;
-    if (FILL) vout = job.values + ((size_t)(job.fill_word0 + (lane >> 1)) * 4 + half);
+    gu32 vout = nullptr;
+    if (FILL) vout = (gu32)job.values + ((size_t)(job.fill_word0 + (lane >> 1)) * 4 + half);
 
     uint32_t X = 0, acc = 0;
     int32_t sum = 0;
@@ -187,39 +204,55 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
     const bool exact_tail = job.exact_tail != 0 && job.nlanes < 64;
 
     // Lane j (< 16) of XS carries the packed pipeline input of column 16q+j: base code and top delta.
+    // The three per-chunk loads (code word, top-delta byte, hand-off granule) are issued TWO chunks ahead and
+    // only decoded when their chunk starts, so the wave never waits on its own prefetch (counted vmcnt).
+    const gcu32 g_codes = (gcu32)job.a_codes;
+    const gcu8 g_hin = (gcu8)job.hin_arr;
+    const gcu64 g_gran = (gcu64)job.hin_gran;
     const int cj = lane & 15;
-    auto load_code = [&](int q) -> uint32_t {
-        const int c = 16 * q + cj;
-        if (c >= n) return 0u;
+    struct Pre {
+        uint32_t code_w;
+        uint32_t hin_b;
+        uint64_t gran;
+    };
+    // Branch-free on purpose: loads inside conditionals make the compiler fall back to s_waitcnt vmcnt(0),
+    // which would drain the prefetch every chunk.  Out-of-range chunks re-read a valid address and are ignored.
+    const bool has_hin = job.hin_arr != nullptr;
+    const bool has_gran = job.hin_gran != nullptr;
+    const gcu8 hin_src = has_hin ? g_hin : (gcu8)g_codes;
+    const gcu64 gran_src = has_gran ? g_gran : (gcu64)g_codes;
+    const int Gm1 = G > 0 ? G - 1 : 0;
+    auto issue = [&](int q) -> Pre {
+        Pre p;
+        int c = 16 * q + cj;
+        c = c < n ? c : n - 1;
         const int ca = job.col0 + c;
-        return (job.a_codes[ca >> 4] >> (2 * (ca & 15))) & 3u;
+        p.code_w = g_codes[ca >> 4];
+        p.hin_b = hin_src[has_hin ? ca : 0];
+        const int qq = q < Gm1 ? q : Gm1;
+        p.gran = __hip_atomic_load(gran_src + (has_gran ? qq : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return p;
     };
-    auto load_hin_arr = [&](int q) -> uint32_t {
-        const int c = 16 * q + cj;
-        if (c >= n || !job.hin_arr) return 1u;  // H::one() (blocks.rs:732)
-        return (uint32_t)job.hin_arr[job.col0 + c] & 3u;
-    };
-    uint64_t pre = 0;
-    if (job.hin_gran && G > 0) pre = load_granule(job.hin_gran);
-    uint32_t code_next = load_code(0);
-    uint32_t hin_next = load_hin_arr(0);
+    Pre pA = issue(0), pB = issue(1);
 
     // Steps t = 0 .. 16*(G+4)-1; lane l handles column t-l.  `acc` lags one step, so after chunk q
     // lane 63's acc holds the bottom-row deltas of columns 16(q-4) .. 16(q-4)+15 == granule q-4.
     bool alive = true;
     PA_DBG(1, 1);
-    for (int q = 0; q < G + 4 && alive; ++q) {
+    // One chunk = 16 columns.  `slot` holds this chunk's prefetched inputs and is refilled for chunk q+2
+    // (the loop is unrolled x2 over two slots so that in-flight loads are never moved between registers).
+    auto chunk = [&](int q, Pre& slot) {
         PA_DBG(2, q + 1);
-        uint32_t hin2 = hin_next;
-        if (q < G && job.hin_gran) {
+        const int ca = job.col0 + 16 * q + cj;
+        const uint32_t code = (16 * q + cj < n) ? ((slot.code_w >> (2 * (ca & 15))) & 3u) : 0u;
+        uint32_t hin2 = has_hin ? (slot.hin_b & 3u) : 1u;  // H::one() when there is no top row (blocks.rs:732)
+        if (q < G && has_gran) {
             uint32_t bits;
-            alive = resolve_granule(job.hin_gran, pre, q, bits);
-            if (q + 1 < G) pre = load_granule(job.hin_gran + q + 1);
+            alive = resolve_granule(g_gran, slot.gran, q, bits);
             hin2 = (bits >> sh) & 3u;
         }
-        const uint32_t XS = (code_next << 30) | hin2;
-        code_next = load_code(q + 1);
-        hin_next = load_hin_arr(q + 1);
+        const uint32_t XS = (code << 30) | hin2;
+        slot = issue(q + 2);
 
         const bool interior = !FILL && (q >= 4) && (q * 16 + 15 < n);
         if (interior) {
@@ -237,24 +270,28 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
             const uint32_t val = (uint32_t)__builtin_amdgcn_readlane((int)acc, 63) & mask;
             if (job.hout_gran) {
                 if (lane == 0)
-                    __hip_atomic_store(job.hout_gran + g, ((uint64_t)(uint32_t)(g + 1) << 32) | (uint64_t)val,
+                    __hip_atomic_store((gu64)job.hout_gran + g, ((uint64_t)(uint32_t)(g + 1) << 32) | (uint64_t)val,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (job.hout_arr) {
-                if (lane < 16 && lane < cols) job.hout_arr[job.col0 + 16 * g + lane] = (uint8_t)((val >> (2 * lane)) & 3u);
+                if (lane < 16 && lane < cols) ((gu8)job.hout_arr)[job.col0 + 16 * g + lane] = (uint8_t)((val >> (2 * lane)) & 3u);
             }
             sum += __builtin_popcount(val & 0x55555555u) - __builtin_popcount(val & 0xAAAAAAAAu);
         }
+    };
+    const int Q = G + 4;
+    for (int q = 0; q < Q && alive; q += 2) {
+        chunk(q, pA);
+        if (q + 1 < Q && alive) chunk(q + 1, pB);
     }
-
     PA_DBG(1, 2);
     if (!alive) {
-        if (lane == 0) __hip_atomic_store(err, (uint32_t)PA_ERR_SPIN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store((gu32)err, (uint32_t)PA_ERR_SPIN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     if (real) {
-        job.v[word * 4 + half] = vp;
-        job.v[word * 4 + 2 + half] = vm;
+        g_v[word * 4 + half] = vp;
+        g_v[word * 4 + 2 + half] = vm;
     }
     if (job.sum_out) {
         if (!exact_tail && job.nlanes < 64) {
@@ -264,7 +301,17 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
             for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
             sum -= c;
         }
-        if (lane == 0) *job.sum_out = sum;
+        if (job.tail_rows >= 0) {
+            const int row0 = 64 * word + 32 * half;  // first DP row of this lane
+            int over = row0 + 32 - job.tail_rows;    // rows of this lane at or beyond |b|
+            over = over < 0 ? 0 : (over > 32 ? 32 : over);
+            const uint32_t tm = over == 0 ? 0u : (over == 32 ? 0xFFFFFFFFu : ~((1u << (32 - over)) - 1u));
+            int32_t c = real ? (__builtin_popcount(vp & tm) - __builtin_popcount(vm & tm)) : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+            sum -= c;
+        }
+        if (lane == 0) *(gi32)job.sum_out = sum;
     }
     PA_DBG(1, 3);
 }

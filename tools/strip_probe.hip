@@ -40,6 +40,7 @@ int main(int argc, char** argv) {
         if (s > 0) j.hin_gran = d_gran + (size_t)(s - 1) * G;
         if (s + 1 < S) j.hout_gran = d_gran + (size_t)s * G; else j.sum_out = (int32_t*)d_misc + 2;
         j.exact_tail = 1;
+        j.tail_rows = -1;
         jobs[s] = j;
     }
     CK(hipMemcpy(d_jobs, jobs.data(), S * sizeof(StripJob), hipMemcpyHostToDevice));

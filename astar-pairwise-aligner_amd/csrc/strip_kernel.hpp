@@ -94,32 +94,35 @@ __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t old_, uint32_t src) {
 
 __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
-// Packed pipeline register X:  bit0 = h.p (delta +1), bit1 = h.m (delta -1), bit30 = code&1, bit31 = code>>1.
+// Packed pipeline register X:  bit31 = h.p (delta +1), bit30 = h.m (delta -1), bits[1:0] = base code, rest 0.
 // One Myers step on a 32-row lane (myers.rs:27-55 with 32-bit words; eq from profile.rs:141-144).
-// `acc` collects the lane's outgoing deltas delayed by one step (2 bits per column, oldest lowest).
+// `acc` collects the lane's outgoing deltas delayed by one step: newest column in bits [1:0] = (p,m),
+// i.e. after 16 steps column k of the chunk sits at bit 31-2k (p) / 30-2k (m).
+// 24 VALU instructions: v_alignbit shifts the incoming carry in without extracting it, v_bitop3 does the rest.
 template <bool PRED, bool PASS>
 __device__ __forceinline__ void myers_step(uint32_t s_x, uint32_t& X, uint32_t& vp, uint32_t& vm,
                                            uint32_t nb0, uint32_t nb1, uint32_t& acc, bool active,
-                                           bool pass_lane) {
-    acc = __builtin_amdgcn_alignbit(X, acc, 2);
+                                           bool pass_lane, uint32_t k40, uint32_t k80) {
+    acc = __builtin_amdgcn_alignbit(acc, X, 30);  // (acc << 2) | (X >> 30)
     const uint32_t Xin = dpp_wave_shr1(s_x, X);
-    const uint32_t hp0 = Xin & 1u;
-    const uint32_t hm0 = (Xin >> 1) & 1u;
-    const uint32_t a0 = (uint32_t)((int32_t)(Xin << 1) >> 31);
-    const uint32_t a1 = (uint32_t)((int32_t)Xin >> 31);
+    const uint32_t a0 = (uint32_t)__builtin_amdgcn_sbfe((int)Xin, 0, 1);
+    const uint32_t a1 = (uint32_t)__builtin_amdgcn_sbfe((int)Xin, 1, 1);
+    const uint32_t hm0 = (Xin >> 30) & 1u;
     const uint32_t x0 = a0 ^ nb0, x1 = a1 ^ nb1;
     const uint32_t eq = x0 & x1;
     const uint32_t vx = eq | vm;
     const uint32_t eq2 = eq | hm0;
     const uint32_t hx = (((eq2 & vp) + vp) ^ vp) | eq2;
-    uint32_t hp = vm | ~(hx | vp);
-    uint32_t hm = vp & hx;
-    const uint32_t pm = (hp >> 31) | ((hm >> 30) & 2u);
-    uint32_t Xo = (Xin & 0xC0000000u) | pm;
-    hp = (hp << 1) | hp0;
-    hm = (hm << 1) | hm0;
-    const uint32_t nvp = hm | ~(vx | hp);
-    const uint32_t nvm = hp & vx;
+    const uint32_t hp = vm | ~(hx | vp);
+    const uint32_t hm = vp & hx;
+    // two bit-field inserts (v_bfi / v_bitop3 each); bits 29:2 of X are always 0, so keeping Xin's other bits is
+    // exact.  k40 / k80 are opaque to the optimizer on purpose, otherwise it re-expands this into 5 ops.
+    const uint32_t xm = __builtin_amdgcn_bitop3_b32(k40, hm >> 1, Xin, 0xCA);  // k40 ? (hm >> 1) : Xin
+    uint32_t Xo = __builtin_amdgcn_bitop3_b32(k80, hp, xm, 0xCA);             // k80 ? hp : xm
+    const uint32_t hp2 = __builtin_amdgcn_alignbit(hp, Xin, 31);  // (hp << 1) | (Xin >> 31)
+    const uint32_t hm2 = (hm << 1) | hm0;
+    const uint32_t nvp = hm2 | ~(vx | hp2);
+    const uint32_t nvm = hp2 & vx;
     if (PASS) Xo = pass_lane ? Xin : Xo;
     if (PRED) {
         vp = active ? nvp : vp;
@@ -134,13 +137,13 @@ __device__ __forceinline__ void myers_step(uint32_t s_x, uint32_t& X, uint32_t& 
 template <bool PRED, bool PASS, bool FILL>
 __device__ __forceinline__ void run_chunk(const StripJob& job, int q, uint32_t XS, uint32_t& X, uint32_t& vp,
                                           uint32_t& vm, uint32_t nb0, uint32_t nb1, uint32_t& acc, int lane,
-                                          bool pass_lane, gu32 vout) {
+                                          bool pass_lane, gu32 vout, uint32_t k40, uint32_t k80) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const uint32_t s_x = (uint32_t)__builtin_amdgcn_readlane((int)XS, j);
         const int col = q * 16 + j - lane;
         const bool active = PRED ? ((unsigned)col < (unsigned)job.n) : true;
-        myers_step<PRED, PASS>(s_x, X, vp, vm, nb0, nb1, acc, active, pass_lane);
+        myers_step<PRED, PASS>(s_x, X, vp, vm, nb0, nb1, acc, active, pass_lane, k40, k80);
         if (FILL) {
             if (active && lane < job.nlanes) {
                 gu32 dst = vout + (size_t)col * (size_t)job.fill_stride * 4;
@@ -200,6 +203,8 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
 
     uint32_t X = 0, acc = 0;
     int32_t sum = 0;
+    uint32_t k40 = 0x40000000u, k80 = 0x80000000u;  // see myers_step
+    asm volatile("" : "+s"(k40), "+s"(k80));
     const uint32_t sh = 2u * (uint32_t)(lane & 15);
     const bool exact_tail = job.exact_tail != 0 && job.nlanes < 64;
 
@@ -245,28 +250,29 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
         PA_DBG(2, q + 1);
         const int ca = job.col0 + 16 * q + cj;
         const uint32_t code = (16 * q + cj < n) ? ((slot.code_w >> (2 * (ca & 15))) & 3u) : 0u;
-        uint32_t hin2 = has_hin ? (slot.hin_b & 3u) : 1u;  // H::one() when there is no top row (blocks.rs:732)
+        // top delta of this lane's column as (p << 31) | (m << 30); H::one() when there is no top row (blocks.rs:732)
+        uint32_t hin2 = has_hin ? (((slot.hin_b & 1u) << 31) | ((slot.hin_b & 2u) << 29)) : 0x80000000u;
         if (q < G && has_gran) {
             uint32_t bits;
             alive = resolve_granule(g_gran, slot.gran, q, bits);
-            hin2 = (bits >> sh) & 3u;
+            hin2 = (bits << sh) & 0xC0000000u;  // granule: column k at bits 31-2k (p), 30-2k (m)
         }
-        const uint32_t XS = (code << 30) | hin2;
+        const uint32_t XS = code | hin2;
         slot = issue(q + 2);
 
         const bool interior = !FILL && (q >= 4) && (q * 16 + 15 < n);
         if (interior) {
-            if (exact_tail) run_chunk<false, true, false>(job, q, XS, X, vp, vm, nb0, nb1, acc, lane, pass_lane, vout);
-            else run_chunk<false, false, false>(job, q, XS, X, vp, vm, nb0, nb1, acc, lane, pass_lane, vout);
+            if (exact_tail) run_chunk<false, true, false>(job, q, XS, X, vp, vm, nb0, nb1, acc, lane, pass_lane, vout, k40, k80);
+            else run_chunk<false, false, false>(job, q, XS, X, vp, vm, nb0, nb1, acc, lane, pass_lane, vout, k40, k80);
         } else {
-            if (exact_tail) run_chunk<true, true, FILL>(job, q, XS, X, vp, vm, nb0, nb1, acc, lane, pass_lane, vout);
-            else run_chunk<true, false, FILL>(job, q, XS, X, vp, vm, nb0, nb1, acc, lane, pass_lane, vout);
+            if (exact_tail) run_chunk<true, true, FILL>(job, q, XS, X, vp, vm, nb0, nb1, acc, lane, pass_lane, vout, k40, k80);
+            else run_chunk<true, false, FILL>(job, q, XS, X, vp, vm, nb0, nb1, acc, lane, pass_lane, vout, k40, k80);
         }
 
         const int g = q - 4;
         if (g >= 0) {  // g < G always holds here
             const int cols = n - 16 * g;
-            const uint32_t mask = cols >= 16 ? 0xFFFFFFFFu : ((1u << (2 * cols)) - 1u);
+            const uint32_t mask = cols >= 16 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (2 * cols));  // column k at bits 31-2k, 30-2k
             const uint32_t val = (uint32_t)__builtin_amdgcn_readlane((int)acc, 63) & mask;
             if (job.hout_gran) {
                 if (lane == 0)
@@ -274,9 +280,12 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (job.hout_arr) {
-                if (lane < 16 && lane < cols) ((gu8)job.hout_arr)[job.col0 + 16 * g + lane] = (uint8_t)((val >> (2 * lane)) & 3u);
+                if (lane < 16 && lane < cols) {
+                    const uint32_t tb = (val >> (30 - 2 * lane)) & 3u;  // bit1 = p, bit0 = m
+                    ((gu8)job.hout_arr)[job.col0 + 16 * g + lane] = (uint8_t)((tb >> 1) | ((tb & 1u) << 1));
+                }
             }
-            sum += __builtin_popcount(val & 0x55555555u) - __builtin_popcount(val & 0xAAAAAAAAu);
+            sum += __builtin_popcount(val & 0xAAAAAAAAu) - __builtin_popcount(val & 0x55555555u);
         }
     };
     const int Q = G + 4;

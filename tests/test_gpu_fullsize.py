@@ -1,0 +1,89 @@
+"""GPU tests at BASELINE.json's full sizes (configs C1..C5).
+
+Where the oracle finishes in seconds (one 100 kbp pair = 0.2 s of AVX2) results are compared bit-exactly;
+beyond that, size-independent properties of the edit distance are used: symmetry d(a,b) = d(b,a), identity
+d(a,a) = 0, d(a, a + suffix) = |suffix|, the k-substitution bound, idempotence of a second pass, and a checksum
+of costs against an oracle sample."""
+import numpy as np
+import pytest
+
+from tests.util_seq import gen_pair, mutate, rand_seq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import astar_pairwise_aligner_amd as pa
+
+    pa.require_gpu()
+    return pa
+
+
+def test_c1_1kbp_pairs_vs_plain_levenshtein(pa, oracle):
+    """C1: 1 kbp, 5 % uniform error, seeds 1..100 -- plumbing check against the plain O(nm) DP."""
+    pairs = [gen_pair(1000, 0.05, seed=s) for s in range(1, 101)]
+    costs, _ = pa.Batch(pairs).run()
+    assert costs.tolist() == [oracle.levenshtein(a, b) for a, b in pairs]
+
+
+def test_c2_100kbp_full_dp_bit_exact(pa, oracle):
+    """C2: 100 kbp x 100 kbp, 5 %, full DP, seeds 1..3: cost identical to the CPU port of the reference schedule."""
+    pairs = [gen_pair(100_000, 0.05, seed=s) for s in (1, 2, 3)]
+    batch = pa.Batch(pairs + [(b, a) for a, b in pairs] + [(pairs[0][0], pairs[0][0])])
+    costs, ms = batch.run()
+    want = [oracle.nw_cost(a, b, True) for a, b in pairs]
+    assert costs[:3].tolist() == want
+    assert costs[3:6].tolist() == want          # symmetry
+    assert costs[6] == 0                        # identity
+    costs2, _ = batch.run()                     # idempotent on resident inputs
+    assert np.array_equal(costs, costs2)
+
+
+def test_c3_100kbp_astarpa2_simple_with_trace(pa, oracle):
+    """C3: A*PA2-simple (GapCost band doubling, sparse blocks, DT trace) on a 100 kbp pair, traceback on."""
+    a, b = gen_pair(100_000, 0.05, seed=1)
+    want = oracle.nw_cost(a, b, True)
+    cost, cigar, stats = pa.AstarPa2Params.simple().make_aligner(True).align_with_stats(a, b)
+    assert cost == want
+    assert oracle.cigar_verify(cigar, a, b) == want
+    want_cost, want_cigar, want_stats = oracle.cpu_align(a, b, oracle.params_simple())
+    assert (cost, cigar) == (want_cost, want_cigar)
+    for k in ("num_blocks", "computed_lanes", "f_max_tries", "dt_trace_tries", "fill_tries"):
+        assert stats[k] == want_stats[k], k
+
+
+def test_c4_batch_10kbp_mixed_divergence(pa, oracle):
+    """C4 (scaled to one GPU test run): 2000 pairs of 10 kbp, divergence drawn from {1,5,10,15} % by pair index."""
+    divs = (0.01, 0.05, 0.10, 0.15)
+    pairs = [gen_pair(10_000, divs[i % 4], seed=i) for i in range(2000)]
+    costs, _ = pa.Batch(pairs).run()
+    sample = range(0, 2000, 40)
+    assert [int(costs[i]) for i in sample] == [oracle.nw_cost(*pairs[i], True) for i in sample]
+    # k edits never cost more than k; more divergence never makes these pairs closer on average
+    for i, (a, b) in enumerate(pairs[:200]):
+        assert 0 < costs[i] <= int(divs[i % 4] * len(a))
+    by_div = [np.mean(costs[j::4]) for j in range(4)]
+    assert by_div == sorted(by_div)
+
+
+def test_c4_properties_suffix_and_substitutions(pa):
+    a = rand_seq(50_000, seed=77)
+    suffix = rand_seq(1234, seed=78)
+    sub = bytearray(a)
+    for p in range(100, 50_000, 500):  # 100 isolated substitutions
+        sub[p] = ord("A") if sub[p] != ord("A") else ord("C")
+    costs, _ = pa.Batch([(a, a + suffix), (a + suffix, a), (a, bytes(sub)), (a, a)]).run()
+    assert costs.tolist() == [1234, 1234, 100, 0]
+
+
+def test_c5_long_pair_properties(pa, oracle):
+    """C5-shaped stress (1 Mbp here; the 10 Mbp run is in profiles/README.md): full DP through ~490 chained strips.
+    d(a,b) = d(b,a), bounded by the number of edits, and equal to the banded CPU engine's answer."""
+    a = rand_seq(1_000_000, seed=5)
+    b = mutate(a, 0.01, seed=5)
+    costs, _ = pa.Batch([(a, b), (b, a)]).run()
+    assert costs[0] == costs[1]
+    assert 0 < costs[0] <= 10_000
+    want, _, _ = oracle.cpu_align(a, b, oracle.params_simple(), trace=False)
+    assert costs[0] == want

@@ -136,7 +136,7 @@ struct Cigar {
 
 // ---- parameters (params.rs:8-42, blocks.rs:31-74, band.rs:5-63) -----------------------------------
 enum class DomainKind : int32_t { Full = 0, GapStart = 1, GapGap = 2, Astar = 3 };
-enum class HeuristicKind : int32_t { None = 0, Gap = 1 };  // NoCost (Dijkstra) / GapCost; SH/GCSH: SURVEY 8f "next"
+enum class HeuristicKind : int32_t { None = 0, Gap = 1, SH = 2 };  // NoCost (Dijkstra) / GapCost / SH; GCSH: SURVEY 8f "next"
 enum class DoublingKind : int32_t { None = 0, BandDoubling = 1, LinearSearch = 2 };
 enum class DoublingStart : int32_t { Zero = 0, Gap = 1, H0 = 2 };
 
@@ -153,6 +153,7 @@ struct BlockParams {
 struct AstarPa2Params {
     DomainKind domain = DomainKind::Astar;
     HeuristicKind heuristic = HeuristicKind::Gap;
+    I heuristic_k = 15;  // HeuristicParams.k (pa-heuristic/src/cli.rs:47-114): seed length for SH
     DoublingKind doubling = DoublingKind::BandDoubling;
     DoublingStart start = DoublingStart::H0;
     float factor = 2.0f;
@@ -226,6 +227,53 @@ struct GapCostH : Heuristic {  // distances.rs:131-168
         const int64_t d = (int64_t)(tn - i) - (int64_t)(tm - j);
         return (Cost)(d < 0 ? -d : d);
     }
+};
+
+// SH (seed heuristic), pa-heuristic/src/heuristic/sh.rs:47-106 + contour/sh_contours.rs:16-75, for exact matches
+// (r = 1, no local pruning, no transform filter -- the configuration astarpa2/src/tests.rs:68-79 runs).
+// `a` is cut into disjoint k-mers at i = 0,k,2k,.. (matches/qgrams.rs:99-109); a seed has score 1 iff its k-mer
+// occurs anywhere in b (matches/exact.rs:15-69; keys are 2-bit packed and truncated to u32 as there).
+// h(i,j) = potential(i) - score(i) = number of seeds starting at >= i without a match.  SHI does not override
+// prune_block / update_contours (heuristic.rs:150-157), so under A*PA2 it is static and column-only.
+struct SeedHeuristicH : Heuristic {
+    std::vector<Cost> h_by_i;  // size n+1
+    SeedHeuristicH(const uint8_t* a, I n, const uint8_t* b, I m, I k) {
+        h_by_i.assign((size_t)n + 1, 0);
+        if (k <= 0) k = 1;
+        const I nseeds = n >= k ? (n - k) / k + 1 : 0;
+        auto bits = [](uint8_t c) -> uint64_t { return (uint64_t)((c >> 1) & 3); };  // qgrams.rs:30-33
+        std::vector<std::pair<uint32_t, I>> keys;  // (key, seed index), sorted => multimap
+        keys.reserve((size_t)nseeds);
+        for (I sidx = 0; sidx < nseeds; ++sidx) {
+            uint64_t q = 0;
+            for (I t = 0; t < k; ++t) q = (q << 2) | bits(a[sidx * k + t]);
+            keys.emplace_back((uint32_t)q, sidx);
+        }
+        std::sort(keys.begin(), keys.end());
+        std::vector<uint8_t> matched((size_t)nseeds, 0);
+        if (m >= k && nseeds > 0) {
+            const uint64_t mask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+            uint64_t q = 0;
+            for (I j = 0; j < m; ++j) {
+                q = ((q << 2) | bits(b[j])) & mask;
+                if (j + 1 < k) continue;
+                const uint32_t key = (uint32_t)q;
+                auto it = std::lower_bound(keys.begin(), keys.end(), std::make_pair(key, (I)0));
+                for (; it != keys.end() && it->first == key; ++it) matched[(size_t)it->second] = 1;
+            }
+        }
+        // potential[i] - score(i): walk seeds from the right (seeds.rs:47-66, sh_contours.rs:40-47,63-75)
+        Cost unmatched = 0;
+        I next_seed = nseeds - 1;
+        for (I i = n; i >= 0; --i) {
+            if (next_seed >= 0 && i == next_seed * k) {
+                if (!matched[(size_t)next_seed]) unmatched += 1;
+                next_seed -= 1;
+            }
+            h_by_i[(size_t)i] = unmatched;
+        }
+    }
+    Cost h(I i, I) const override { return h_by_i[(size_t)i]; }
 };
 
 // unit-cost AffineCost formulas (pa-affine-types/src/cost_model.rs:387-401,453-525 with sub=ins=del=1)
@@ -860,6 +908,8 @@ class AstarPa2Instance {
         const double t0 = now_s();
         if (params.domain == DomainKind::Astar) {
             if (params.heuristic == HeuristicKind::Gap) heur = std::make_unique<GapCostH>(be.n(), be.m());
+            else if (params.heuristic == HeuristicKind::SH)
+                heur = std::make_unique<SeedHeuristicH>(be.a(), be.n(), be.b(), be.m(), params.heuristic_k);
             else heur = std::make_unique<NoCostH>();
         }
         stats.t_precomp = now_s() - t0;

@@ -74,7 +74,8 @@ enum : uint32_t {
     PA_ERR_SPIN_TIMEOUT = 1,  // a producer strip never delivered its granule
 };
 
-constexpr uint32_t kSpinLimit = 1u << 21;
+constexpr uint64_t kSpinTimeoutTicks = 30ull * 100000000ull;  // 30 s of the 100 MHz wall clock: a lost producer ends the
+                                                                 // wave with PA_ERR_SPIN_TIMEOUT instead of hanging the GPU
 
 // Every pointer of a StripJob is device global memory; say so, or the compiler emits flat_* accesses whose
 // out-of-order return forces s_waitcnt vmcnt(0) everywhere.
@@ -159,15 +160,18 @@ __device__ __forceinline__ uint64_t load_granule(gcu64 g) {
 }
 
 // Resolve the (possibly prefetched) granule of chunk q; polls when the producer is not there yet.
-// Returns false (after a bounded number of polls) if the producer never delivered.
+// Returns false (after a bounded wall-clock time) if the producer never delivered.
 __device__ __forceinline__ bool resolve_granule(gcu64 g, uint64_t pre, int q, uint32_t& bits) {
-    uint32_t spins = 0;
     uint32_t tag = rfl((uint32_t)(pre >> 32));
-    while (tag != (uint32_t)(q + 1) && spins < kSpinLimit) {
-        __builtin_amdgcn_s_sleep(1);
-        pre = load_granule(g + q);
-        tag = rfl((uint32_t)(pre >> 32));
-        ++spins;
+    if (tag != (uint32_t)(q + 1)) {  // slow path: the producer is not there yet
+        const uint64_t t0 = wall_clock64();
+        uint32_t spins = 0;
+        do {
+            __builtin_amdgcn_s_sleep(2);
+            pre = load_granule(g + q);
+            tag = rfl((uint32_t)(pre >> 32));
+            if ((++spins & 1023u) == 0 && wall_clock64() - t0 > kSpinTimeoutTicks) break;
+        } while (tag != (uint32_t)(q + 1));
     }
     bits = rfl((uint32_t)pre);
     return tag == (uint32_t)(q + 1);

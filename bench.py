@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=128, help="independent pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=146, help="independent pairs per GPU per step")
     ap.add_argument("--n", type=int, default=100_000, help="sequence length (bp)")
     ap.add_argument("--div", type=float, default=0.05, help="divergence (edit rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

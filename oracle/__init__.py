@@ -153,7 +153,7 @@ class BlockParamsC(C.Structure):
 
 
 class AstarPa2ParamsC(C.Structure):
-    _fields_ = [("domain", C.c_int32), ("heuristic", C.c_int32), ("doubling", C.c_int32), ("doubling_start", C.c_int32),
+    _fields_ = [("domain", C.c_int32), ("heuristic", C.c_int32), ("heuristic_k", C.c_int32), ("doubling", C.c_int32), ("doubling_start", C.c_int32),
                 ("factor", C.c_float), ("delta", C.c_float), ("block_width", C.c_int32), ("front", BlockParamsC),
                 ("sparse_h", C.c_int32), ("prune", C.c_int32)]
 
@@ -170,16 +170,16 @@ class AstarPa2StatsC(C.Structure):
 
 
 DOMAIN = {"full": 0, "gap_start": 1, "gap_gap": 2, "astar": 3}
-HEURISTIC = {"none": 0, "gap": 1}
+HEURISTIC = {"none": 0, "gap": 1, "sh": 2}
 DOUBLING = {"none": 0, "band": 1, "linear": 2}
 START = {"zero": 0, "gap": 1, "h0": 2}
 
 
-def make_params(domain="astar", heuristic="gap", doubling="band", start="h0", factor=2.0, delta=1.0, block_width=256,
+def make_params(domain="astar", heuristic="gap", k=15, doubling="band", start="h0", factor=2.0, delta=1.0, block_width=256,
                 sparse=True, simd=True, no_ilp=False, incremental_doubling=True, dt_trace=False, max_g=40, fr_drop=20,
                 sparse_h=False, prune=False) -> AstarPa2ParamsC:
     """Defaults follow BlockParams::default() (blocks.rs:62-74)."""
-    return AstarPa2ParamsC(DOMAIN[domain], HEURISTIC[heuristic], DOUBLING[doubling], START[start], factor, delta,
+    return AstarPa2ParamsC(DOMAIN[domain], HEURISTIC[heuristic], k, DOUBLING[doubling], START[start], factor, delta,
                            block_width, BlockParamsC(int(sparse), int(simd), int(no_ilp), int(incremental_doubling),
                                                      int(dt_trace), max_g, fr_drop), int(sparse_h), int(prune))
 
@@ -232,3 +232,12 @@ def cpu_align(a: bytes, b: bytes, params: AstarPa2ParamsC, trace: bool = True, s
         s = C.string_at(cig.value).decode()
         engine_lib().pa_cpu_free(cig)
     return cost.value, s, stats.as_dict()
+
+
+def sh_h(a: bytes, b: bytes, k: int) -> list[int]:
+    """SH heuristic h(i) for i = 0..len(a) as the engine computes it (test hook)."""
+    L = engine_lib()
+    L.pa_cpu_sh_h.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    out = np.zeros(len(a) + 1, np.int32)
+    L.pa_cpu_sh_h(_buf(a), len(a), _buf(b), len(b), k, _p(out))
+    return out.tolist()

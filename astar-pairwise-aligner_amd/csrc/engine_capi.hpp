@@ -11,6 +11,7 @@ inline AstarPa2Params params_from_c(const pa_astarpa2_params& c) {
     p.domain = (DomainKind)c.domain;
     p.heuristic = (HeuristicKind)c.heuristic;
     p.heuristic_k = c.heuristic_k;
+    p.heuristic_p = c.heuristic_p;
     p.doubling = (DoublingKind)c.doubling;
     p.start = (DoublingStart)c.doubling_start;
     p.factor = c.factor;
@@ -32,6 +33,7 @@ inline void params_to_c(const AstarPa2Params& p, pa_astarpa2_params* c) {
     c->domain = (int32_t)p.domain;
     c->heuristic = (int32_t)p.heuristic;
     c->heuristic_k = p.heuristic_k;
+    c->heuristic_p = p.heuristic_p;
     c->doubling = (int32_t)p.doubling;
     c->doubling_start = (int32_t)p.start;
     c->factor = p.factor;
@@ -72,7 +74,8 @@ inline void stats_to_c(const AstarPa2Stats& s, pa_astarpa2_stats* c) {
 }
 
 inline bool params_valid(const pa_astarpa2_params& c) {
-    return c.domain >= 0 && c.domain <= 3 && c.heuristic >= 0 && c.heuristic <= 2 && !(c.heuristic == PA_HEURISTIC_SH && (c.heuristic_k < 1 || c.heuristic_k > 31)) && c.doubling >= 0 && c.doubling <= 2 &&
+    return c.domain >= 0 && c.domain <= 3 && c.heuristic >= 0 && c.heuristic <= 3 && !(c.heuristic >= PA_HEURISTIC_SH && (c.heuristic_k < 1 || c.heuristic_k > 31)) &&
+           c.heuristic_p >= 0 && c.doubling >= 0 && c.doubling <= 2 &&
            c.doubling_start >= 0 && c.doubling_start <= 2 && c.block_width >= 1 &&
            !(c.doubling == PA_DOUBLING_NONE && c.domain != PA_DOMAIN_FULL) &&
            !(c.doubling == PA_DOUBLING_LINEAR && c.delta < 1.0f) && c.front.max_g >= 0 &&

@@ -251,7 +251,7 @@ using namespace pa;
 
 extern "C" void pa_params_nw(pa_astarpa2_params* p) { engine::params_to_c(engine::AstarPa2Params::nw(), p); }
 extern "C" void pa_params_simple(pa_astarpa2_params* p) { engine::params_to_c(engine::AstarPa2Params::simple(), p); }
-extern "C" void pa_params_full(pa_astarpa2_params* p) { engine::params_to_c(engine::AstarPa2Params::simple(), p); }
+extern "C" void pa_params_full(pa_astarpa2_params* p) { engine::params_to_c(engine::AstarPa2Params::full(), p); }
 
 extern "C" int pa_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params* params,
                         int trace, int32_t* cost_out, char** cigar_out, pa_astarpa2_stats* stats_out) {

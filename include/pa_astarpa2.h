@@ -18,7 +18,7 @@ extern "C" {
 #endif
 
 enum { PA_DOMAIN_FULL = 0, PA_DOMAIN_GAP_START = 1, PA_DOMAIN_GAP_GAP = 2, PA_DOMAIN_ASTAR = 3 }; /* params.rs:231-242 */
-enum { PA_HEURISTIC_NONE = 0, PA_HEURISTIC_GAP = 1, PA_HEURISTIC_SH = 2 }; /* NoCost (Dijkstra) / GapCost (distances.rs) / SH (sh.rs) */
+enum { PA_HEURISTIC_NONE = 0, PA_HEURISTIC_GAP = 1, PA_HEURISTIC_SH = 2, PA_HEURISTIC_GCSH = 3 }; /* NoCost / GapCost / SH / GCSH (pa-heuristic) */
 enum { PA_DOUBLING_NONE = 0, PA_DOUBLING_BAND = 1, PA_DOUBLING_LINEAR = 2 };                     /* band.rs:26-44 */
 enum { PA_START_ZERO = 0, PA_START_GAP = 1, PA_START_H0 = 2 };                                   /* band.rs:5-10 */
 
@@ -35,7 +35,8 @@ typedef struct pa_block_params { /* BlockParams, blocks.rs:31-60 */
 typedef struct pa_astarpa2_params { /* AstarPa2Params, params.rs:8-42 */
     int32_t domain;
     int32_t heuristic;
-    int32_t heuristic_k; /* HeuristicParams.k: seed length of SH (exact matches, r = 1) */
+    int32_t heuristic_k; /* HeuristicParams.k: seed length of SH / GCSH (exact matches, r = 1) */
+    int32_t heuristic_p; /* HeuristicParams.p: local-pruning look-ahead of GCSH, 0 = off */
     int32_t doubling;
     int32_t doubling_start;
     float factor; /* BandDoubling */
@@ -54,8 +55,7 @@ typedef struct pa_astarpa2_stats { /* AstarPa2Stats + BlockStats + TraceStats */
     double t_compute, t_dt, t_fill, t_precomp, t_j_range, t_fixed_j_range, t_pruning, t_contours_update;
 } pa_astarpa2_stats;
 
-/* Presets, params.rs:46-128.  `full` currently selects the `simple` parameter set: the GCSH heuristic
- * (pa-heuristic) is not restated yet; the returned cost is identical either way. */
+/* Presets, params.rs:46-128 (full = GCSH k=12 r=1 p=14 Prune::Start, incremental doubling, pruning). */
 void pa_params_nw(pa_astarpa2_params* p);
 void pa_params_simple(pa_astarpa2_params* p);
 void pa_params_full(pa_astarpa2_params* p);

@@ -153,7 +153,7 @@ class BlockParamsC(C.Structure):
 
 
 class AstarPa2ParamsC(C.Structure):
-    _fields_ = [("domain", C.c_int32), ("heuristic", C.c_int32), ("heuristic_k", C.c_int32), ("doubling", C.c_int32), ("doubling_start", C.c_int32),
+    _fields_ = [("domain", C.c_int32), ("heuristic", C.c_int32), ("heuristic_k", C.c_int32), ("heuristic_p", C.c_int32), ("doubling", C.c_int32), ("doubling_start", C.c_int32),
                 ("factor", C.c_float), ("delta", C.c_float), ("block_width", C.c_int32), ("front", BlockParamsC),
                 ("sparse_h", C.c_int32), ("prune", C.c_int32)]
 
@@ -170,16 +170,16 @@ class AstarPa2StatsC(C.Structure):
 
 
 DOMAIN = {"full": 0, "gap_start": 1, "gap_gap": 2, "astar": 3}
-HEURISTIC = {"none": 0, "gap": 1, "sh": 2}
+HEURISTIC = {"none": 0, "gap": 1, "sh": 2, "gcsh": 3}
 DOUBLING = {"none": 0, "band": 1, "linear": 2}
 START = {"zero": 0, "gap": 1, "h0": 2}
 
 
-def make_params(domain="astar", heuristic="gap", k=15, doubling="band", start="h0", factor=2.0, delta=1.0, block_width=256,
+def make_params(domain="astar", heuristic="gap", k=15, p=0, doubling="band", start="h0", factor=2.0, delta=1.0, block_width=256,
                 sparse=True, simd=True, no_ilp=False, incremental_doubling=True, dt_trace=False, max_g=40, fr_drop=20,
                 sparse_h=False, prune=False) -> AstarPa2ParamsC:
     """Defaults follow BlockParams::default() (blocks.rs:62-74)."""
-    return AstarPa2ParamsC(DOMAIN[domain], HEURISTIC[heuristic], k, DOUBLING[doubling], START[start], factor, delta,
+    return AstarPa2ParamsC(DOMAIN[domain], HEURISTIC[heuristic], k, p, DOUBLING[doubling], START[start], factor, delta,
                            block_width, BlockParamsC(int(sparse), int(simd), int(no_ilp), int(incremental_doubling),
                                                      int(dt_trace), max_g, fr_drop), int(sparse_h), int(prune))
 
@@ -196,6 +196,11 @@ def params_simple():  # params.rs:70-96
 
 class EnginePanic(RuntimeError):
     pass
+
+
+def params_full():  # params.rs:98-128
+    return make_params(domain="astar", heuristic="gcsh", k=12, p=14, doubling="band", start="h0", factor=2.0, block_width=256,
+                       sparse=True, incremental_doubling=True, dt_trace=True, max_g=40, fr_drop=10, sparse_h=True, prune=True)
 
 
 _elib = None
@@ -241,3 +246,18 @@ def sh_h(a: bytes, b: bytes, k: int) -> list[int]:
     out = np.zeros(len(a) + 1, np.int32)
     L.pa_cpu_sh_h(_buf(a), len(a), _buf(b), len(b), k, _p(out))
     return out.tolist()
+
+
+def gcsh_probe(a: bytes, b: bytes, k: int, p: int, queries):
+    """GCSH h at `queries` [(i, j), ..] and the list of kept match starts (test hook)."""
+    L = engine_lib()
+    L.pa_cpu_gcsh_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.pa_cpu_gcsh_probe.restype = C.c_int
+    qi = np.array([q[0] for q in queries], np.int32)
+    qj = np.array([q[1] for q in queries], np.int32)
+    out = np.zeros(len(queries), np.int32)
+    cap = 1 << 20
+    mo = np.zeros((cap, 2), np.int32)
+    cnt = L.pa_cpu_gcsh_probe(_buf(a), len(a), _buf(b), len(b), k, p, _p(qi), _p(qj), len(queries), _p(out), _p(mo), cap)
+    return out.tolist(), [tuple(x) for x in mo[:cnt].tolist()]

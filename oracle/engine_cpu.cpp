@@ -124,3 +124,19 @@ extern "C" void pa_cpu_sh_h(const uint8_t* a, size_t n, const uint8_t* b, size_t
     SeedHeuristicH h(a, (I)n, b, (I)m, (I)k);
     for (size_t i = 0; i <= n; ++i) out[i] = h.h((I)i, 0);
 }
+
+// Test hook: GCSH h(i, j) at the given positions (before any pruning), plus the kept matches.
+extern "C" int pa_cpu_gcsh_probe(const uint8_t* a, size_t n, const uint8_t* b, size_t m, int k, int p, const int32_t* qi,
+                                 const int32_t* qj, size_t nq, int32_t* h_out, int32_t* match_out, size_t match_cap) {
+    GcshHeuristic h(a, (I)n, b, (I)m, (I)k, p, true);
+    for (size_t t = 0; t < nq; ++t) h_out[t] = h.h(qi[t], qj[t]);
+    size_t cnt = 0;
+    for (const auto& mt : h.by_start) {
+        if (cnt < match_cap) {
+            match_out[2 * cnt] = mt.i;
+            match_out[2 * cnt + 1] = mt.j;
+        }
+        cnt++;
+    }
+    return (int)cnt;
+}

@@ -26,6 +26,14 @@ def configs(o):
                                              "incremental_doubling": False}),
         "sh_k12_w256": o.make_params(domain="astar", heuristic="sh", k=12, doubling="band", start="h0", block_width=256,
                                      sparse=True, incremental_doubling=True, dt_trace=True, max_g=40, fr_drop=10, sparse_h=True),
+        # tests.rs:81-105 `nw_prune` / `dt_trace`: GCSH(exact k, Pruning::start) with block_width 256 (k=15 there; the
+        # grid is short, so also run small k to get real chains), and the `full` preset (params.rs:98-128)
+        "gcsh_k15_prune": o.make_params(**{**nw, **band, "domain": "astar", "heuristic": "gcsh", "k": 15, "block_width": 256}),
+        "gcsh_k6_dt": o.make_params(**{**nw, **band, "domain": "astar", "heuristic": "gcsh", "k": 6, "block_width": 64,
+                                       "dt_trace": True}),
+        "gcsh_k5_p3_noprune": o.make_params(**{**nw, **band, "domain": "astar", "heuristic": "gcsh", "k": 5, "p": 3,
+                                               "block_width": 32, "prune": False}),
+        "preset_full": o.params_full(),
         "incremental_doubling": o.make_params(**{**nw, **band, "domain": "astar", "heuristic": "gap", "block_width": 64,
                                                  "dt_trace": True, "incremental_doubling": True}),
         "gap_start": o.make_params(**{**nw, **band, "domain": "gap_start", "block_width": 64}),
@@ -41,7 +49,7 @@ def configs(o):
 
 CONFIG_NAMES = ["full", "band_doubling_gapgap", "dt_trace_gapgap", "band_doubling_dijkstra", "band_doubling_edlib",
                 "band_doubling_w1", "incremental_doubling", "gap_start", "linear_search", "preset_nw", "preset_simple",
-                "simple_scalar_noilp", "band_doubling_sh", "sh_k12_w256"]
+                "simple_scalar_noilp", "band_doubling_sh", "sh_k12_w256", "gcsh_k15_prune", "gcsh_k6_dt", "gcsh_k5_p3_noprune", "preset_full"]
 
 
 def check(o, a, b, params, label, self_check=False):
@@ -154,3 +162,69 @@ def test_sh_heuristic_matches_definition(oracle):
     a = rand_seq(200, seed=9)
     assert set(oracle.sh_h(a, a, 10)) == {0}
     assert oracle.sh_h(a, b"", 10)[0] == 20
+
+
+def _gcsh_reference_h(a, b, k, queries):
+    """Definition of GCSH (no local pruning): chain score over exact matches in the gap-transformed partial order."""
+    n, m = len(a), len(b)
+    seeds = list(range(0, n - k + 1, k))
+    pot = [sum(1 for s in seeds if s >= i) for i in range(n + 1)]
+    T = lambda i, j: (i - j - pot[i], j - i - pot[i])
+    le = lambda p, q: p[0] <= q[0] and p[1] <= q[1]
+    tt = T(n, m)
+    kmers = {}
+    for s in seeds:
+        kmers.setdefault(a[s:s + k], []).append(s)
+    matches = sorted({(i, j) for j in range(m - k + 1) for i in kmers.get(b[j:j + k], []) if le(T(i, j), tt)})
+    layer = {}
+    points = []  # (T(start), layer)
+
+    def score(q):
+        return max([l for p, l in points if le(q, p)], default=0)
+
+    for (i, j) in reversed(matches):
+        e = T(i + k, j + k)
+        if not le(e, tt):
+            continue
+        points.append((T(i, j), score(e) + 1))
+    out = []
+    for (i, j) in queries:
+        v = score(T(i, j))
+        out.append(max(abs((n - i) - (m - j)), pot[i]) if v == 0 else pot[i] - v)
+    return out, matches
+
+
+def test_gcsh_matches_definition(oracle):
+    import random
+
+    rnd = random.Random(5)
+    for n, e, k, seed in [(120, 0.05, 4, 1), (300, 0.1, 5, 2), (400, 0.02, 6, 3), (200, 0.3, 3, 4), (64, 0.0, 8, 5)]:
+        a, b = gen_pair(n, e, seed)
+        queries = [(rnd.randrange(len(a) + 1), rnd.randrange(len(b) + 1)) for _ in range(300)] + [(0, 0), (len(a), len(b))]
+        want_h, want_matches = _gcsh_reference_h(a, b, k, queries)
+        got_h, got_matches = oracle.gcsh_probe(a, b, k, 0, queries)
+        assert got_matches == want_matches
+        assert got_h == want_h
+        # admissible: h(0,0) never exceeds the true distance
+        assert got_h[-2] <= oracle.levenshtein(a, b)
+
+
+def test_gcsh_local_pruning_only_removes_matches(oracle):
+    a, b = gen_pair(3000, 0.08, 7)
+    _, all_m = oracle.gcsh_probe(a, b, 6, 0, [(0, 0)])
+    h_p, kept = oracle.gcsh_probe(a, b, 6, 5, [(0, 0)])
+    assert set(kept) <= set(all_m) and len(kept) < len(all_m)
+    assert h_p[0] <= oracle.levenshtein(a, b)
+
+
+def test_full_preset_medium_pairs(oracle):
+    """A*PA2-full (GCSH k=12 p=14, pruning, incremental doubling) where seeds really chain."""
+    for n, e, seed in [(5000, 0.02, 1), (20000, 0.05, 2), (50000, 0.01, 3), (8000, 0.12, 4), (30000, 0.0, 5)]:
+        a, b = gen_pair(n, e, seed)
+        want = oracle.nw_cost(a, b, True)
+        cost, cigar, stats = oracle.cpu_align(a, b, oracle.params_full(), self_check=(n <= 20000))
+        assert cost == want
+        assert oracle.cigar_verify(cigar, a, b) == want
+        simple = oracle.cpu_align(a, b, oracle.params_simple(), trace=False)[2]
+        # the seed heuristic must not need more band than the gap heuristic
+        assert stats["computed_lanes"] <= simple["computed_lanes"] * 1.05 + 64

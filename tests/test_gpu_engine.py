@@ -27,7 +27,7 @@ def gpu_params(pa, oc):
 
     f = oc.front
     return pa.AstarPa2Params(
-        domain=inv(al.DOMAIN, oc.domain), heuristic=inv(al.HEURISTIC, oc.heuristic), k=oc.heuristic_k, doubling=inv(al.DOUBLING, oc.doubling),
+        domain=inv(al.DOMAIN, oc.domain), heuristic=inv(al.HEURISTIC, oc.heuristic), k=oc.heuristic_k, p=oc.heuristic_p, doubling=inv(al.DOUBLING, oc.doubling),
         doubling_start=inv(al.START, oc.doubling_start), factor=oc.factor, delta=oc.delta, block_width=oc.block_width,
         front=pa.BlockParams(bool(f.sparse), bool(f.simd), bool(f.no_ilp), bool(f.incremental_doubling), bool(f.dt_trace),
                              f.max_g, f.fr_drop), sparse_h=bool(oc.sparse_h), prune=bool(oc.prune))
@@ -54,13 +54,13 @@ def test_c_abi_example(pa, oracle):
 def test_presets_on_pa_test_pairs(pa, oracle):
     for a, b in PA_TEST_PAIRS:
         want = oracle.levenshtein(a, b)
-        for oc in (oracle.params_nw(), oracle.params_simple()):
+        for oc in (oracle.params_nw(), oracle.params_simple(), oracle.params_full()):
             cost, cigar = both(pa, oracle, a, b, oc)
             assert cost == want and oracle.cigar_verify(cigar, a, b) == want
 
 
 @pytest.mark.parametrize("name", ["preset_simple", "preset_nw", "incremental_doubling", "dt_trace_gapgap", "band_doubling_dijkstra",
-                                  "band_doubling_sh", "sh_k12_w256"])
+                                  "band_doubling_sh", "sh_k12_w256", "gcsh_k6_dt", "preset_full"])
 def test_configs_small_grid(pa, oracle, name):
     from tests.test_engine_cpu import configs
 
@@ -77,7 +77,7 @@ def test_simple_medium_pairs(pa, oracle):
     """Several band-doubling iterations, multi-strip bands, DT trace + block re-fill."""
     for n, e, seed in [(3000, 0.05, 1), (10000, 0.10, 2), (20000, 0.03, 3), (5000, 0.30, 4)]:
         a, b = gen_pair(n, e, seed)
-        for oc in (oracle.params_simple(),):
+        for oc in (oracle.params_simple(), oracle.params_full()):
             cost, cigar = both(pa, oracle, a, b, oc)
             assert cost == oracle.nw_cost(a, b, True)
             assert oracle.cigar_verify(cigar, a, b) == cost

@@ -51,6 +51,12 @@ def test_c3_100kbp_astarpa2_simple_with_trace(pa, oracle):
     assert (cost, cigar) == (want_cost, want_cigar)
     for k in ("num_blocks", "computed_lanes", "f_max_tries", "dt_trace_tries", "fill_tries"):
         assert stats[k] == want_stats[k], k
+    # A*PA2-full: GCSH seed heuristic (k=12, p=14) with pruning and incremental doubling
+    cost_f, cigar_f, stats_f = pa.AstarPa2Params.full().make_aligner(True).align_with_stats(a, b)
+    want_f = oracle.cpu_align(a, b, oracle.params_full())
+    assert (cost_f, cigar_f) == (want_f[0], want_f[1]) and cost_f == want
+    assert oracle.cigar_verify(cigar_f, a, b) == want
+    assert stats_f["computed_lanes"] == want_f[2]["computed_lanes"] < stats["computed_lanes"]
 
 
 def test_c4_batch_10kbp_mixed_divergence(pa, oracle):

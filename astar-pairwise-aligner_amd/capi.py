@@ -17,7 +17,7 @@ U64P = C.POINTER(C.c_uint64)
 EXPORTED_SYMBOLS = [
     "astarpa2_simple", "astarpa2_full", "astarpa", "astarpa_gcsh", "astarpa_free_cigar",
     "pa_last_error", "pa_device_count", "pa_set_device",
-    "pa_bp_profile_build", "pa_bp_compute", "pa_bp_fill",
+    "pa_bp_profile_build", "pa_bp_compute", "pa_bp_fill", "pa_search",
     "pa_batch_create", "pa_batch_run", "pa_batch_stats", "pa_batch_destroy",
     "pa_align",
 ]
@@ -53,6 +53,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_bp_compute.restype = C.c_int32
     L.pa_bp_fill.argtypes = [vp, sz, vp, sz, vp, vp, vp]
     L.pa_bp_fill.restype = C.c_int32
+    L.pa_search.argtypes = [vp, sz, vp, sz, C.c_float, vp]
+    L.pa_search.restype = C.c_int
     L.pa_batch_create.argtypes = [vp, vp, vp, vp, sz]
     L.pa_batch_create.restype = vp
     L.pa_batch_run.argtypes = [vp, vp, C.POINTER(C.c_float)]
@@ -116,6 +118,17 @@ def fill(a2, b2, h2, v2):
     if r == -(2 ** 31):
         raise PaError(last_error())
     return r, values
+
+
+def search(pattern: bytes, text: bytes, unmatched_cost: float) -> list[int]:
+    """pa_bitpacking::search(pattern, text, unmatched_cost).out on the GPU (search.rs:46-120)."""
+    out = np.zeros(len(pattern) + len(text) + 1, np.int32)
+    rc = load().pa_search(_buf(pattern), len(pattern), _buf(text), len(text), unmatched_cost, _p(out))
+    if rc == -1:
+        raise ValueError("unknown base")
+    if rc != 0:
+        raise PaError(f"pa_search rc={rc}: {last_error()}")
+    return out.tolist()
 
 
 class Batch:

@@ -3,6 +3,7 @@
 #include "pa_hip_internal.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -131,8 +132,9 @@ __global__ void build_b_batch_kernel(const uint8_t* __restrict__ b_cat, uint64_t
     if (invalid) atomicOr(bad, 1u);
 }
 
-template __global__ void strip_kernel<false>(const StripJob*, int, uint32_t*, uint32_t*);
-template __global__ void strip_kernel<true>(const StripJob*, int, uint32_t*, uint32_t*);
+template __global__ void strip_kernel<false, false>(const StripJob*, int, uint32_t*, uint32_t*);
+template __global__ void strip_kernel<true, false>(const StripJob*, int, uint32_t*, uint32_t*);
+template __global__ void strip_kernel<false, true>(const StripJob*, int, uint32_t*, uint32_t*);
 
 // ---- device context -----------------------------------------------------------------------------
 
@@ -231,15 +233,17 @@ size_t rect_granules(int n, int w) {
     return S > 1 ? (size_t)(S - 1) * G : 0;
 }
 
-bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_ticket_err, hipStream_t s, bool zero_ticket) {
+bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_ticket_err, hipStream_t s, bool zero_ticket, bool scatter) {
     if (njobs == 0) return true;
     // d_ticket_err[0] = ticket, [1] = err
     if (zero_ticket && !hip_ok(hipMemsetAsync(d_ticket_err, 0, 2 * sizeof(uint32_t), s), "memset ticket")) return false;
     const int grid = njobs;  // one wave per job; jobs beyond residency queue behind their producers (ticket order)
-    if (fill)
-        hipLaunchKernelGGL(strip_kernel<true>, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_ticket_err, d_ticket_err + 1);
+    if (scatter)
+        hipLaunchKernelGGL((strip_kernel<false, true>), dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_ticket_err, d_ticket_err + 1);
+    else if (fill)
+        hipLaunchKernelGGL((strip_kernel<true, false>), dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_ticket_err, d_ticket_err + 1);
     else
-        hipLaunchKernelGGL(strip_kernel<false>, dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_ticket_err, d_ticket_err + 1);
+        hipLaunchKernelGGL((strip_kernel<false, false>), dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_ticket_err, d_ticket_err + 1);
     return hip_ok(hipGetLastError(), "strip_kernel launch");
 }
 
@@ -386,6 +390,150 @@ extern "C" int32_t pa_bp_compute(const uint64_t* a2, size_t n, const uint64_t* b
 extern "C" int32_t pa_bp_fill(const uint64_t* a2, size_t n, const uint64_t* b2, size_t w, uint64_t* h2, uint64_t* v2,
                               uint64_t* values) {
     return rect_host(a2, n, b2, w, h2, v2, 1, values);
+}
+
+// ---- semi-global search (pa_bitpacking::search, pa-bitpacking/src/search.rs:46-120) ------------------------------
+
+// One thread per 16 columns: text ASCII -> packed CC codes (A0 C1 T2 G3, either case; profile.rs:30-38).
+__global__ void encode_text_cc_kernel(const uint8_t* __restrict__ a, int n, uint32_t* __restrict__ codes, int nwords,
+                                      uint32_t* __restrict__ bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwords) return;
+    uint32_t w = 0;
+    bool invalid = false;
+    for (int k = 0; k < 16; ++k) {
+        const int c = i * 16 + k;
+        if (c < n) {
+            const uint8_t ch = a[c] & 0xDF;  // upper-case
+            const int r = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'T' ? 2 : ch == 'G' ? 3 : -1;
+            invalid |= r < 0;
+            w |= (uint32_t)(r & 3) << (2 * k);
+        }
+    }
+    codes[i] = w;
+    if (invalid) atomicOr(bad, 1u);
+}
+
+extern "C" int pa_search(const uint8_t* pattern, size_t plen, const uint8_t* text, size_t tlen, float unmatched_cost,
+                         int32_t* out) {
+    if (!ensure_device()) return PA_E_HIP;
+    if (!(unmatched_cost >= 0.0f && unmatched_cost <= 1.0f) || plen > (size_t)(1u << 30) || tlen > (size_t)(1u << 30)) {
+        set_error("pa_search: bad argument");
+        return PA_E_ARG;
+    }
+    const size_t w = (plen + 63) / 64, n = tlen;
+    // ScatterProfile of the pattern on the host (profile.rs:39-63): wildcards N/* (any), Y (C|T), R (A|G);
+    // padding rows match everything.
+    std::vector<uint64_t> prof(4 * std::max<size_t>(w, 1), 0);
+    for (size_t j = 0; j < plen; ++j) {
+        int mask;
+        switch (pattern[j]) {
+            case 'a': case 'A': mask = 1; break;
+            case 'c': case 'C': mask = 2; break;
+            case 't': case 'T': mask = 4; break;
+            case 'g': case 'G': mask = 8; break;
+            case 'n': case 'N': case '*': mask = 15; break;
+            case 'y': case 'Y': mask = 6; break;
+            case 'r': case 'R': mask = 9; break;
+            default: set_error("Unknown base in pattern"); return PA_E_INVALID_BASE;
+        }
+        for (int c = 0; c < 4; ++c)
+            if (mask & (1 << c)) prof[4 * (j / 64) + c] |= 1ull << (j % 64);
+    }
+    for (size_t j = plen; j < w * 64; ++j)
+        for (int c = 0; c < 4; ++c) prof[4 * (j / 64) + c] |= 1ull << (j % 64);
+    // left column: every ceil(i / unmatched_cost)-th row costs 1 (search.rs:57-65)
+    std::vector<uint64_t> v0(2 * std::max<size_t>(w, 1), 0);
+    if (unmatched_cost > 0.0f) {
+        for (size_t i = 0;; ++i) {
+            const size_t idx = (size_t)std::ceil((float)i / unmatched_cost);
+            if (idx >= plen) break;
+            v0[2 * (idx / 64)] |= 1ull << (idx % 64);
+        }
+    }
+    std::vector<uint64_t> v(v0);
+    std::vector<uint8_t> hrow(std::max<size_t>(n, 1), 0);
+    if (n > 0 && w > 0) {
+        const size_t cw = (n + 15) / 16 + 2, ngran = rect_granules((int)n, (int)w);
+        DeviceBuf d_text, d_codes, d_prof, d_v, d_hin, d_hout, d_gran, d_jobs, d_misc;
+        if (!d_text.alloc(n) || !d_codes.alloc(cw * 4) || !d_prof.alloc(w * 32) || !d_v.alloc(w * 16) || !d_hin.alloc(n) ||
+            !d_hout.alloc(n) || !d_gran.alloc(ngran * 8) || !d_misc.alloc(16))
+            return PA_E_HIP;
+        hipStream_t s = 0;
+        bool ok = hip_ok(hipMemcpyAsync(d_text.ptr, text, n, hipMemcpyHostToDevice, s), "H2D") &&
+                  hip_ok(hipMemsetAsync(d_codes.ptr, 0, cw * 4, s), "memset") && hip_ok(hipMemsetAsync(d_misc.ptr, 0, 16, s), "memset") &&
+                  hip_ok(hipMemsetAsync(d_hin.ptr, 0, n, s), "memset h") &&  // zeros along the top: start anywhere in the text
+                  hip_ok(hipMemsetAsync(d_gran.ptr, 0, std::max<size_t>(ngran * 8, 16), s), "memset gran") &&
+                  hip_ok(hipMemcpyAsync(d_prof.ptr, prof.data(), w * 32, hipMemcpyHostToDevice, s), "H2D") &&
+                  hip_ok(hipMemcpyAsync(d_v.ptr, v.data(), w * 16, hipMemcpyHostToDevice, s), "H2D");
+        if (!ok) return PA_E_HIP;
+        const int nwords = (int)((n + 15) / 16);
+        hipLaunchKernelGGL(encode_text_cc_kernel, dim3((nwords + 255) / 256), dim3(256), 0, s, d_text.as<uint8_t>(), (int)n,
+                           d_codes.as<uint32_t>(), nwords, d_misc.as<uint32_t>() + 3);
+        std::vector<StripJob> jobs;
+        RectPlan r;
+        r.a_codes = d_codes.as<uint32_t>();
+        r.b_prof = d_prof.as<uint32_t>();
+        r.v = d_v.as<uint32_t>();
+        r.n = (int)n;
+        r.w0 = 0;
+        r.w1 = (int)w;
+        r.hin_arr = d_hin.as<uint8_t>();
+        r.hout_arr = d_hout.as<uint8_t>();
+        r.gran = d_gran.as<uint64_t>();
+        r.gran_stride = (n + 15) / 16;
+        r.sum_out = d_misc.as<int32_t>() + 2;
+        r.exact_end = true;  // scatter_profile::compute(.., exact_end = true, ..), search.rs:71
+        plan_rect(jobs, r);
+        if (!d_jobs.alloc(jobs.size() * sizeof(StripJob))) return PA_E_HIP;
+        uint32_t misc[4] = {0, 0, 0, 0};
+        ok = hip_ok(hipMemcpyAsync(d_jobs.ptr, jobs.data(), jobs.size() * sizeof(StripJob), hipMemcpyHostToDevice, s), "H2D jobs") &&
+             launch_strips(d_jobs.as<StripJob>(), (int)jobs.size(), false, d_misc.as<uint32_t>(), s, false, /*scatter=*/true) &&
+             hip_ok(hipMemcpyAsync(misc, d_misc.ptr, 16, hipMemcpyDeviceToHost, s), "D2H") &&
+             hip_ok(hipMemcpyAsync(v.data(), d_v.ptr, w * 16, hipMemcpyDeviceToHost, s), "D2H") &&
+             hip_ok(hipMemcpyAsync(hrow.data(), d_hout.ptr, n, hipMemcpyDeviceToHost, s), "D2H") && hip_ok(hipStreamSynchronize(s), "sync");
+        if (!ok) return PA_E_HIP;
+        if (misc[3]) {
+            set_error("text must be actgACTG only");
+            return PA_E_INVALID_BASE;
+        }
+        if (misc[1] != PA_ERR_NONE) {
+            set_error("device spin timeout (err=%u)", misc[1]);
+            return PA_E_TIMEOUT;
+        }
+    } else if (w > 0) {
+        // empty text: nothing to compute
+    }
+    // Assemble the bottom row then the right column in reverse (search.rs:73-100).
+    auto value = [](uint64_t p, uint64_t m) { return (int32_t)__builtin_popcountll(p) - (int32_t)__builtin_popcountll(m); };
+    auto suffix = [](uint64_t p, uint64_t m, int j) {
+        const uint64_t mask = ~((1ull << (64 - j)) - 1);
+        return (int32_t)__builtin_popcountll(p & mask) - (int32_t)__builtin_popcountll(m & mask);
+    };
+    const size_t padding = w * 64 - plen;
+    int32_t bsum = 0;
+    for (size_t j = 0; j < w; ++j) bsum += value(v0[2 * j], v0[2 * j + 1]);
+    size_t k = 0, skipped = 0;
+    out[k++] = bsum;
+    for (size_t i = 0; i < n; ++i) {
+        bsum += (int32_t)(hrow[i] & 1) - (int32_t)((hrow[i] >> 1) & 1);
+        if (skipped < padding) skipped++;
+        else out[k++] = bsum;
+    }
+    for (size_t jj = w; jj-- > 0;) {
+        for (int j = 1; j <= 64; ++j) {
+            const int32_t val = bsum - suffix(v[2 * jj], v[2 * jj + 1], j) + suffix(v0[2 * jj], v0[2 * jj + 1], j);
+            if (skipped < padding) skipped++;
+            else out[k++] = val;
+        }
+        bsum -= value(v[2 * jj], v[2 * jj + 1]);
+        bsum += value(v0[2 * jj], v0[2 * jj + 1]);
+    }
+    if (k != plen + tlen + 1) {
+        set_error("pa_search: internal length mismatch");
+        return PA_E_INTERNAL;
+    }
+    return 0;
 }
 
 // ---- batched full DP ----------------------------------------------------------------------------

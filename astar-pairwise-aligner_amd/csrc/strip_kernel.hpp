@@ -41,7 +41,8 @@ namespace pa {
 struct StripJob {
     const uint32_t* a_codes;  // 2-bit base codes (A0 C1 G2 T3) of the WHOLE sequence a, 16 per u32: column i at bits
                               // 2*(i%16)+{0,1} of word i/16; the rectangle starts at absolute column `col0`
-    const uint32_t* b_prof;   // BitProfile of b: u32 view of (nb0:u64, nb1:u64) per 64-row word (profile.rs:112-133)
+    const uint32_t* b_prof;   // BitProfile of b: u32 view of (nb0:u64, nb1:u64) per 64-row word (profile.rs:112-133);
+                              // scatter kernels: u32 view of [u64; 4] match masks per word (profile.rs:25-75)
     uint32_t* v;              // V(p:u64, m:u64) per 64-row word, u32 view, updated in place (encoding.rs:5-6)
     const uint64_t* hin_gran; // granules from the strip above (tag = chunk+1), or nullptr
     const uint8_t* hin_arr;   // top-row deltas, one byte per ABSOLUTE column (bit0 = +1, bit1 = -1), or nullptr => all +1
@@ -100,17 +101,32 @@ __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin
 // `acc` collects the lane's outgoing deltas delayed by one step: newest column in bits [1:0] = (p,m),
 // i.e. after 16 steps column k of the chunk sits at bit 31-2k (p) / 30-2k (m).
 // 24 VALU instructions: v_alignbit shifts the incoming carry in without extracting it, v_bitop3 does the rest.
-template <bool PRED, bool PASS>
+// SCATTER: eq comes from a ScatterProfile (profile.rs:25-75): four match masks per word, selected by the text code
+// (A0 C1 T2 G3), so pattern wildcards (N, *, Y, R) work; one extra select op per step.
+template <bool PRED, bool PASS, bool SCATTER>
 __device__ __forceinline__ void myers_step(uint32_t s_x, uint32_t& X, uint32_t& vp, uint32_t& vm,
-                                           uint32_t nb0, uint32_t nb1, uint32_t& acc, bool active,
+                                           uint32_t nb0, uint32_t nb1, uint32_t nb2, uint32_t nb3, uint32_t& acc, bool active,
                                            bool pass_lane, uint32_t k40, uint32_t k80) {
+#if !(defined(PA_ABLATE) && (PA_ABLATE & 4))
     acc = __builtin_amdgcn_alignbit(acc, X, 30);  // (acc << 2) | (X >> 30)
+#endif
+#if defined(PA_ABLATE) && (PA_ABLATE & 2)
+    const uint32_t Xin = X ^ s_x;  // ablation: no cross-lane shift
+#else
     const uint32_t Xin = dpp_wave_shr1(s_x, X);
+#endif
     const uint32_t a0 = (uint32_t)__builtin_amdgcn_sbfe((int)Xin, 0, 1);
     const uint32_t a1 = (uint32_t)__builtin_amdgcn_sbfe((int)Xin, 1, 1);
     const uint32_t hm0 = (Xin >> 30) & 1u;
-    const uint32_t x0 = a0 ^ nb0, x1 = a1 ^ nb1;
-    const uint32_t eq = x0 & x1;
+    uint32_t eq;
+    if (SCATTER) {
+        const uint32_t e01 = __builtin_amdgcn_bitop3_b32(a0, nb1, nb0, 0xCA);  // a0 ? mask[1] : mask[0]
+        const uint32_t e23 = __builtin_amdgcn_bitop3_b32(a0, nb3, nb2, 0xCA);
+        eq = __builtin_amdgcn_bitop3_b32(a1, e23, e01, 0xCA);
+    } else {
+        const uint32_t x0 = a0 ^ nb0, x1 = a1 ^ nb1;
+        eq = x0 & x1;
+    }
     const uint32_t vx = eq | vm;
     const uint32_t eq2 = eq | hm0;
     const uint32_t hx = (((eq2 & vp) + vp) ^ vp) | eq2;
@@ -135,16 +151,20 @@ __device__ __forceinline__ void myers_step(uint32_t s_x, uint32_t& X, uint32_t& 
     X = Xo;
 }
 
-template <bool PRED, bool PASS, bool FILL>
+template <bool PRED, bool PASS, bool FILL, bool SCATTER>
 __device__ __forceinline__ void run_chunk(const StripJob& job, int q, uint32_t XS, uint32_t& X, uint32_t& vp,
-                                          uint32_t& vm, uint32_t nb0, uint32_t nb1, uint32_t& acc, int lane,
+                                          uint32_t& vm, uint32_t nb0, uint32_t nb1, uint32_t nb2, uint32_t nb3, uint32_t& acc, int lane,
                                           bool pass_lane, gu32 vout, uint32_t k40, uint32_t k80) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
+#if defined(PA_ABLATE) && (PA_ABLATE & 1)
+        const uint32_t s_x = rfl(XS) + (uint32_t)j;  // ablation: one readfirstlane per chunk instead of a readlane per step
+#else
         const uint32_t s_x = (uint32_t)__builtin_amdgcn_readlane((int)XS, j);
+#endif
         const int col = q * 16 + j - lane;
         const bool active = PRED ? ((unsigned)col < (unsigned)job.n) : true;
-        myers_step<PRED, PASS>(s_x, X, vp, vm, nb0, nb1, acc, active, pass_lane, k40, k80);
+        myers_step<PRED, PASS, SCATTER>(s_x, X, vp, vm, nb0, nb1, nb2, nb3, acc, active, pass_lane, k40, k80);
         if (FILL) {
             if (active && lane < job.nlanes) {
                 gu32 dst = vout + (size_t)col * (size_t)job.fill_stride * 4;
@@ -178,7 +198,7 @@ __device__ __forceinline__ bool resolve_granule(gcu64 g, uint64_t pre, int q, ui
 }
 
 // Process one strip.  On a spin timeout the error word is set and the strip stops early.
-template <bool FILL>
+template <bool FILL, bool SCATTER>
 __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
     const int lane = (int)(threadIdx.x & 63);
     const int n = job.n;
@@ -188,12 +208,19 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
     const int word = job.word0 + (lane >> 1);
     const int half = lane & 1;
 
-    uint32_t vp = 0, vm = 0, nb0 = 0, nb1 = 0;
+    uint32_t vp = 0, vm = 0, nb0 = 0, nb1 = 0, nb2 = 0, nb3 = 0;
     const gcu32 g_prof = (gcu32)job.b_prof;
     const gu32 g_v = (gu32)job.v;
     if (real) {
-        nb0 = g_prof[word * 4 + half];
-        nb1 = g_prof[word * 4 + 2 + half];
+        if (SCATTER) {  // [B; 4] per word
+            nb0 = g_prof[word * 8 + half];
+            nb1 = g_prof[word * 8 + 2 + half];
+            nb2 = g_prof[word * 8 + 4 + half];
+            nb3 = g_prof[word * 8 + 6 + half];
+        } else {
+            nb0 = g_prof[word * 4 + half];
+            nb1 = g_prof[word * 4 + 2 + half];
+        }
         if (job.flags & kJobVInitOne) {
             vp = 0xFFFFFFFFu;
             vm = 0u;
@@ -266,11 +293,11 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
 
         const bool interior = !FILL && (q >= 4) && (q * 16 + 15 < n);
         if (interior) {
-            if (exact_tail) run_chunk<false, true, false>(job, q, XS, X, vp, vm, nb0, nb1, acc, lane, pass_lane, vout, k40, k80);
-            else run_chunk<false, false, false>(job, q, XS, X, vp, vm, nb0, nb1, acc, lane, pass_lane, vout, k40, k80);
+            if (exact_tail) run_chunk<false, true, false, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc, lane, pass_lane, vout, k40, k80);
+            else run_chunk<false, false, false, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc, lane, pass_lane, vout, k40, k80);
         } else {
-            if (exact_tail) run_chunk<true, true, FILL>(job, q, XS, X, vp, vm, nb0, nb1, acc, lane, pass_lane, vout, k40, k80);
-            else run_chunk<true, false, FILL>(job, q, XS, X, vp, vm, nb0, nb1, acc, lane, pass_lane, vout, k40, k80);
+            if (exact_tail) run_chunk<true, true, FILL, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc, lane, pass_lane, vout, k40, k80);
+            else run_chunk<true, false, FILL, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc, lane, pass_lane, vout, k40, k80);
         }
 
         const int g = q - 4;
@@ -332,7 +359,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
 // One 64-thread block = one wavefront = one strip job, claimed by ticket (jobs are listed producer before
 // consumer, so a consumer's producer has always started; no assumption about dispatch order).
 // `ticket` and `err` must be zeroed (and every hin/hout granule buffer cleared) before the launch.
-template <bool FILL>
+template <bool FILL, bool SCATTER = false>
 __global__ __launch_bounds__(64) void strip_kernel(const StripJob* __restrict__ jobs, int njobs,
                                                    uint32_t* ticket, uint32_t* err) {
     uint32_t t = 0;
@@ -341,7 +368,7 @@ __global__ __launch_bounds__(64) void strip_kernel(const StripJob* __restrict__ 
     PA_DBG(0, t + 1);
     if (t < (uint32_t)njobs) {
         const StripJob job = jobs[t];
-        run_strip<FILL>(job, err);
+        run_strip<FILL, SCATTER>(job, err);
     }
     PA_DBG(0, 0x1000 + t);
 }

@@ -200,6 +200,18 @@ def main():
         }
         out["speedup_vs_cpu_1core"] = round(value / out["cpu_baseline"]["value"], 1)
 
+    # PMC-derived HBM traffic of the dominant kernel (separate rocprofv3 --pmc passes, tools/pmc_run.sh; committed
+    # summary in profiles/pmc_latest.json).  Traffic is per strip wave, so it scales with the batch.
+    pmc = ROOT / "profiles" / "pmc_latest.json"
+    if pmc.exists():
+        try:
+            pj = json.loads(pmc.read_text())
+            out["roofline"]["traffic"] = round(pj["hbm_bytes_per_strip"] * st["strips"], 1)
+            out["roofline"]["traffic_note"] = ("FETCH_SIZE+WRITE_SIZE (KiB*1024) per strip wave from profiles/pmc_latest.json x strips; "
+                                                "dominated by the 8-byte sc1 hand-off granules, each moving a 32-64 B sector")
+        except Exception as e:  # a malformed summary must not break the bench line
+            out["roofline"]["traffic_note"] = f"pmc summary unreadable: {e}"
+
     print(json.dumps(out))
     batch.close()
     if dist is not None:

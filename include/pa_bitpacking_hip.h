@@ -58,6 +58,12 @@ int32_t pa_bp_compute(const uint64_t* a2, size_t n, const uint64_t* b2, size_t w
 int32_t pa_bp_fill(const uint64_t* a2, size_t n, const uint64_t* b2, size_t w, uint64_t* h2, uint64_t* v2,
                    uint64_t* values);
 
+/* pa_bitpacking::search(pattern, text, unmatched_cost).out (pa-bitpacking/src/search.rs:46-120; pa_python/src/lib.rs:4-7):
+ * semi-global search of a short pattern (may contain N, n or an asterisk = any base, Y/y = C or T, R/r = A or G) in a text (actgACTG).
+ * out[|pattern| + |text| + 1] = costs along the bottom row, then up the right column.  Runs the ScatterProfile
+ * variant of the strip kernel (simd/scatter_profile.rs). */
+int pa_search(const uint8_t* pattern, size_t plen, const uint8_t* text, size_t tlen, float unmatched_cost, int32_t* out);
+
 /* ---- batched full-DP (cost only) on device-resident pairs ------------------------------------------ */
 /* What `AstarPa2Params::nw().make_aligner(false).cost(a,b)` computes (astarpa2/src/params.rs:46-68,
  * blocks.rs:252-277) for many independent pairs at once. */

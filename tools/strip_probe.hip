@@ -44,7 +44,7 @@ int main(int argc, char** argv) {
         jobs[s] = j;
     }
     CK(hipMemcpy(d_jobs, jobs.data(), S * sizeof(StripJob), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(strip_kernel<false>, dim3(S), dim3(64), 0, 0, d_jobs, S, d_misc, d_misc + 1);
+    hipLaunchKernelGGL((strip_kernel<false, false>), dim3(S), dim3(64), 0, 0, d_jobs, S, d_misc, d_misc + 1);
     CK(hipGetLastError());
     hipEvent_t ev; CK(hipEventCreate(&ev)); CK(hipEventRecord(ev, 0));
     const auto t0 = std::chrono::steady_clock::now();

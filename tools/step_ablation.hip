@@ -50,7 +50,15 @@ int main(int argc, char** argv) {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             if (ms < best) best = ms;
         }
+        // shader-clock measurement: a tiny kernel run right after (same DVFS state is not guaranteed, so also time-stamp
+        // inside the strip kernel through PA_DBG-free means: use wall clock ratio of a calibration kernel)
+        unsigned long long* d_clk; unsigned long long clk[2];
+        CK(hipMalloc(&d_clk, 16));
+        hipLaunchKernelGGL(clock_probe, dim3(8192), dim3(64), 0, 0, d_clk);
+        CK(hipMemcpy(clk, d_clk, 16, hipMemcpyDeviceToHost));
+        const double ghz = (double)clk[0] / ((double)clk[1] * 10.0);
         const double steps_per_simd = (double)W * (n + 64);
+        printf("[clock under full VALU load right after: %.2f GHz] ", ghz);
         printf("ablate=%d W=%d waves/SIMD  kernel %.3f ms  %.1f ns per step per SIMD  (%.1f ns per step per wave)\n", PA_ABLATE, W, best,
                best * 1e6 / steps_per_simd, best * 1e6 / (n + 64));
     }

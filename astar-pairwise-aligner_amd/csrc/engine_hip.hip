@@ -97,7 +97,7 @@ struct HipBackend {
         const size_t w = w1 - w0;
         const bool fill = values_host != nullptr;
         const size_t ngran = rect_granules(n, (int)w);
-        const size_t G = (size_t)(n + 15) / 16;
+        const size_t G = (size_t)(n + 31) / 32;
         if (d_gran.size < ngran * 8 && !d_gran.alloc(std::max<size_t>(ngran * 8 * 2, 4096))) fail(PA_E_HIP);
         if (fill && d_values.size < (size_t)n * w * 16 && !d_values.alloc((size_t)n * w * 16 * 2)) fail(PA_E_HIP);
         const size_t S = (w + kWordsPerStrip - 1) / kWordsPerStrip;

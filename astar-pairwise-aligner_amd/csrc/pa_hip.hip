@@ -229,7 +229,7 @@ void plan_rect(std::vector<StripJob>& jobs, const RectPlan& r) {
 
 size_t rect_granules(int n, int w) {
     const int S = (w + kWordsPerStrip - 1) / kWordsPerStrip;
-    const size_t G = (size_t)(n + 15) / 16;
+    const size_t G = (size_t)(n + 31) / 32;  // one 8-byte granule per 32 columns per strip boundary
     return S > 1 ? (size_t)(S - 1) * G : 0;
 }
 
@@ -347,7 +347,7 @@ static int32_t rect_host(const uint64_t* a2, size_t n, const uint64_t* b2, size_
     r.hin_arr = d_hin.as<uint8_t>();
     r.hout_arr = d_hout.as<uint8_t>();
     r.gran = d_gran.as<uint64_t>();
-    r.gran_stride = cw;
+    r.gran_stride = (n + 31) / 32;
     r.sum_out = d_misc.as<int32_t>() + 2;
     r.exact_end = exact_end != 0 || values != nullptr;
     if (!exact_end && !values) r.hout_arr = nullptr;  // padded-tail path: the bottom row itself is not an output
@@ -481,7 +481,7 @@ extern "C" int pa_search(const uint8_t* pattern, size_t plen, const uint8_t* tex
         r.hin_arr = d_hin.as<uint8_t>();
         r.hout_arr = d_hout.as<uint8_t>();
         r.gran = d_gran.as<uint64_t>();
-        r.gran_stride = (n + 15) / 16;
+        r.gran_stride = (n + 31) / 32;
         r.sum_out = d_misc.as<int32_t>() + 2;
         r.exact_end = true;  // scatter_profile::compute(.., exact_end = true, ..), search.rs:71
         plan_rect(jobs, r);
@@ -611,7 +611,7 @@ extern "C" pa_batch* pa_batch_create(const uint8_t* const* a, const size_t* a_le
         r.w0 = 0;
         r.w1 = w;
         r.gran = p->d_gran.as<uint64_t>() + p->gran_off[i];
-        r.gran_stride = (a_len[i] + 15) / 16;
+        r.gran_stride = (a_len[i] + 31) / 32;
         r.sum_out = p->d_sums.as<int32_t>() + i;
         r.exact_end = false;
         r.v_init_one = true;

@@ -12,9 +12,11 @@
 //    delta (2 bits) and the column's 2-bit base code travel lane->lane+1 in ONE packed register
 //    through a DPP `wave_shr:1` move -- no LDS, no barrier.
 //  * Strips of one rectangle are chained top->bottom.  The bottom row of strip s (2 bits/column) is
-//    handed to strip s+1 through 8-byte {tag,payload} granules (16 columns each) in global memory,
-//    written with one agent-scope relaxed atomic store and polled with agent-scope relaxed loads
-//    ("the data is the flag"; MI355X_MICROARCH.md, handoff R2).  No fences, no L2 writeback.
+//    handed to strip s+1 through 8-byte granules of 32 columns each in global memory, written with one
+//    agent-scope relaxed atomic store and polled with agent-scope relaxed loads ("the data is the
+//    flag"; MI355X_MICROARCH.md, handoff R2).  A granule needs no tag: every 2-bit delta field is stored
+//    +1 (1..3), so a written granule is never zero and the buffer is zeroed before each launch.
+//    No fences, no L2 writeback.
 //  * Work items are claimed through an atomic ticket, so a consumer's producer always started
 //    earlier => forward progress without assuming dispatch order.  Every spin is bounded.
 //  * HBM traffic is tiny by construction (0.25 B/column of `a`, 16 B/word of profile, 32 B/word of v,
@@ -44,7 +46,7 @@ struct StripJob {
     const uint32_t* b_prof;   // BitProfile of b: u32 view of (nb0:u64, nb1:u64) per 64-row word (profile.rs:112-133);
                               // scatter kernels: u32 view of [u64; 4] match masks per word (profile.rs:25-75)
     uint32_t* v;              // V(p:u64, m:u64) per 64-row word, u32 view, updated in place (encoding.rs:5-6)
-    const uint64_t* hin_gran; // granules from the strip above (tag = chunk+1), or nullptr
+    const uint64_t* hin_gran; // granules from the strip above (32 columns each, see kGranuleBias), or nullptr
     const uint8_t* hin_arr;   // top-row deltas, one byte per ABSOLUTE column (bit0 = +1, bit1 = -1), or nullptr => all +1
     uint64_t* hout_gran;      // granules for the strip below, or nullptr
     uint8_t* hout_arr;        // bottom-row deltas out, one byte per ABSOLUTE column, or nullptr
@@ -151,20 +153,23 @@ __device__ __forceinline__ void myers_step(uint32_t s_x, uint32_t& X, uint32_t& 
     X = Xo;
 }
 
+// One chunk = 32 columns = 32 unrolled steps.  Lane j (< 32) of XS carries the packed pipeline input of column 32q+j.
+// The lagged accumulator of steps 0..15 is acc_lo, of steps 16..31 acc_hi (static, so no register moves).
 template <bool PRED, bool PASS, bool FILL, bool SCATTER>
 __device__ __forceinline__ void run_chunk(const StripJob& job, int q, uint32_t XS, uint32_t& X, uint32_t& vp,
-                                          uint32_t& vm, uint32_t nb0, uint32_t nb1, uint32_t nb2, uint32_t nb3, uint32_t& acc, int lane,
-                                          bool pass_lane, gu32 vout, uint32_t k40, uint32_t k80) {
+                                          uint32_t& vm, uint32_t nb0, uint32_t nb1, uint32_t nb2, uint32_t nb3,
+                                          uint32_t& acc_lo, uint32_t& acc_hi, int lane, bool pass_lane, gu32 vout,
+                                          uint32_t k40, uint32_t k80) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < 32; ++j) {
 #if defined(PA_ABLATE) && (PA_ABLATE & 1)
         const uint32_t s_x = rfl(XS) + (uint32_t)j;  // ablation: one readfirstlane per chunk instead of a readlane per step
 #else
         const uint32_t s_x = (uint32_t)__builtin_amdgcn_readlane((int)XS, j);
 #endif
-        const int col = q * 16 + j - lane;
+        const int col = q * 32 + j - lane;
         const bool active = PRED ? ((unsigned)col < (unsigned)job.n) : true;
-        myers_step<PRED, PASS, SCATTER>(s_x, X, vp, vm, nb0, nb1, nb2, nb3, acc, active, pass_lane, k40, k80);
+        myers_step<PRED, PASS, SCATTER>(s_x, X, vp, vm, nb0, nb1, nb2, nb3, j < 16 ? acc_lo : acc_hi, active, pass_lane, k40, k80);
         if (FILL) {
             if (active && lane < job.nlanes) {
                 gu32 dst = vout + (size_t)col * (size_t)job.fill_stride * 4;
@@ -175,26 +180,33 @@ __device__ __forceinline__ void run_chunk(const StripJob& job, int q, uint32_t X
     }
 }
 
+// Hand-off granule: 32 columns x 2 bits, low word = columns 0..15, high word = 16..31; inside a word column k sits at
+// bits 31-2k (p) / 30-2k (m).  (p,m) is never (1,1), so adding 1 to every field never carries and makes each field
+// non-zero: a written granule is distinguishable from the zeroed buffer without a tag.
+constexpr uint64_t kGranuleBias = 0x5555555555555555ull;
+
 __device__ __forceinline__ uint64_t load_granule(gcu64 g) {
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Resolve the (possibly prefetched) granule of chunk q; polls when the producer is not there yet.
 // Returns false (after a bounded wall-clock time) if the producer never delivered.
-__device__ __forceinline__ bool resolve_granule(gcu64 g, uint64_t pre, int q, uint32_t& bits) {
-    uint32_t tag = rfl((uint32_t)(pre >> 32));
-    if (tag != (uint32_t)(q + 1)) {  // slow path: the producer is not there yet
+__device__ __forceinline__ bool resolve_granule(gcu64 g, uint64_t pre, int q, uint32_t& lo, uint32_t& hi) {
+    uint32_t l = rfl((uint32_t)pre);
+    if (l == 0u) {  // slow path: the producer is not there yet
         const uint64_t t0 = wall_clock64();
         uint32_t spins = 0;
         do {
             __builtin_amdgcn_s_sleep(2);
             pre = load_granule(g + q);
-            tag = rfl((uint32_t)(pre >> 32));
+            l = rfl((uint32_t)pre);
             if ((++spins & 1023u) == 0 && wall_clock64() - t0 > kSpinTimeoutTicks) break;
-        } while (tag != (uint32_t)(q + 1));
+        } while (l == 0u);
     }
-    bits = rfl((uint32_t)pre);
-    return tag == (uint32_t)(q + 1);
+    const uint32_t h = rfl((uint32_t)(pre >> 32));
+    lo = l - 0x55555555u;
+    hi = h - 0x55555555u;
+    return l != 0u;
 }
 
 // Process one strip.  On a spin timeout the error word is set and the strip stops early.
@@ -202,7 +214,7 @@ template <bool FILL, bool SCATTER>
 __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
     const int lane = (int)(threadIdx.x & 63);
     const int n = job.n;
-    const int G = (n + 15) >> 4;  // 16-column chunks == granules
+    const int C = (n + 31) >> 5;  // 32-column chunks == granules
     const bool real = lane < job.nlanes;
     const bool pass_lane = !real;
     const int word = job.word0 + (lane >> 1);
@@ -232,98 +244,126 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
     gu32 vout = nullptr;
     if (FILL) vout = (gu32)job.values + ((size_t)(job.fill_word0 + (lane >> 1)) * 4 + half);
 
-    uint32_t X = 0, acc = 0;
+    uint32_t X = 0, acc_lo = 0, acc_hi = 0;
     int32_t sum = 0;
     uint32_t k40 = 0x40000000u, k80 = 0x80000000u;  // see myers_step
     asm volatile("" : "+s"(k40), "+s"(k80));
-    const uint32_t sh = 2u * (uint32_t)(lane & 15);
+    const int cj = lane & 15;
+    const bool upper = (lane & 16) != 0;          // lanes 16..31 build columns 16..31 of the chunk
+    const uint32_t sh = 2u * (uint32_t)cj;
     const bool exact_tail = job.exact_tail != 0 && job.nlanes < 64;
 
-    // Lane j (< 16) of XS carries the packed pipeline input of column 16q+j: base code and top delta.
-    // The three per-chunk loads (code word, top-delta byte, hand-off granule) are issued TWO chunks ahead and
-    // only decoded when their chunk starts, so the wave never waits on its own prefetch (counted vmcnt).
-    const gcu32 g_codes = (gcu32)job.a_codes;
+    // Per-chunk inputs.  The packed sequence is read with SCALAR loads (constant address space -> s_load, tracked by
+    // lgkmcnt, so it never waits behind the granule stores); the granule and the optional top-row bytes are vector
+    // loads issued one chunk ahead.  Everything is branch-free so the compiler can use counted s_waitcnt.
+    typedef const __attribute__((address_space(4))) uint32_t* ccu32;
+    const ccu32 c_codes = (ccu32)job.a_codes;
     const gcu8 g_hin = (gcu8)job.hin_arr;
     const gcu64 g_gran = (gcu64)job.hin_gran;
-    const int cj = lane & 15;
-    struct Pre {
-        uint32_t code_w;
-        uint32_t hin_b;
-        uint64_t gran;
-    };
-    // Branch-free on purpose: loads inside conditionals make the compiler fall back to s_waitcnt vmcnt(0),
-    // which would drain the prefetch every chunk.  Out-of-range chunks re-read a valid address and are ignored.
     const bool has_hin = job.hin_arr != nullptr;
     const bool has_gran = job.hin_gran != nullptr;
-    const gcu8 hin_src = has_hin ? g_hin : (gcu8)g_codes;
-    const gcu64 gran_src = has_gran ? g_gran : (gcu64)g_codes;
-    const int Gm1 = G > 0 ? G - 1 : 0;
-    auto issue = [&](int q) -> Pre {
-        Pre p;
-        int c = 16 * q + cj;
-        c = c < n ? c : n - 1;
-        const int ca = job.col0 + c;
-        p.code_w = g_codes[ca >> 4];
-        p.hin_b = hin_src[has_hin ? ca : 0];
-        const int qq = q < Gm1 ? q : Gm1;
-        p.gran = __hip_atomic_load(gran_src + (has_gran ? qq : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return p;
+    const gcu8 hin_src = has_hin ? g_hin : (gcu8)job.a_codes;
+    const gcu64 gran_src = has_gran ? g_gran : (gcu64)job.a_codes;
+    const int Cm1 = C > 0 ? C - 1 : 0;
+    const int last_word = (job.col0 + n - 1) >> 4;  // last valid dword of a_codes for this rectangle
+    // raw code words of columns col0+32q .. +31 (three dwords cover any alignment of col0); shifted only at decode time
+    struct RawCodes {
+        uint32_t w0, w1, w2;
     };
-    Pre pA = issue(0), pB = issue(1);
+    auto load_codes = [&](int q) -> RawCodes {
+        const int c0 = job.col0 + 32 * (q < Cm1 ? q : Cm1);
+        const int i0 = c0 >> 4;
+        const int i1 = i0 + 1 < last_word ? i0 + 1 : last_word;
+        const int i2 = i0 + 2 < last_word ? i0 + 2 : last_word;
+        return RawCodes{c_codes[i0], c_codes[i1], c_codes[i2]};
+    };
+    auto decode_codes = [&](const RawCodes& r, int q) -> uint64_t {  // column k of the chunk at bits 2k+1:2k
+        const unsigned s2 = 2u * (unsigned)((job.col0 + 32 * (q < Cm1 ? q : Cm1)) & 15);
+        const uint64_t lo64 = (uint64_t)r.w0 | ((uint64_t)r.w1 << 32);
+        return s2 == 0 ? lo64 : ((lo64 >> s2) | ((uint64_t)r.w2 << (64 - s2)));
+    };
+    auto load_hin_byte = [&](int q) -> uint32_t {  // lanes 0..31: top delta byte of column 32q + lane
+        int c = 32 * q + (lane & 31);
+        c = c < n ? c : n - 1;
+        return (uint32_t)hin_src[has_hin ? job.col0 + c : 0];
+    };
+    auto load_gran = [&](int q) -> uint64_t {
+        const int qq = q < Cm1 ? q : Cm1;
+        return __hip_atomic_load(gran_src + (has_gran ? qq : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // Publish granule g (columns 32g..32g+31 of the bottom row) from lane 63's lagged accumulators.
+    auto publish = [&](int g) {
+        const int cols = n - 32 * g;  // >= 1
+        uint32_t vlo = (uint32_t)__builtin_amdgcn_readlane((int)acc_lo, 63);
+        uint32_t vhi = (uint32_t)__builtin_amdgcn_readlane((int)acc_hi, 63);
+        if (cols < 32) {  // ragged last granule only: clear the columns past n (column k at bits 31-2k, 30-2k)
+            const int cl = cols >= 16 ? 16 : cols, ch = cols > 16 ? cols - 16 : 0;
+            vlo &= cl >= 16 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (2 * cl));
+            vhi &= ch == 0 ? 0u : ~(0xFFFFFFFFu >> (2 * ch));
+        }
+        if (job.hout_gran) {
+            if (lane == 0)
+                __hip_atomic_store((gu64)job.hout_gran + g, (((uint64_t)vhi << 32) | (uint64_t)vlo) + kGranuleBias,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (job.hout_arr) {
+            if (lane < 32 && lane < cols) {
+                const uint32_t tb = ((upper ? vhi : vlo) >> (30 - 2 * cj)) & 3u;  // bit1 = p, bit0 = m
+                ((gu8)job.hout_arr)[job.col0 + 32 * g + lane] = (uint8_t)((tb >> 1) | ((tb & 1u) << 1));
+            }
+        }
+        sum += __builtin_popcount(vlo & 0xAAAAAAAAu) + __builtin_popcount(vhi & 0xAAAAAAAAu) -
+               __builtin_popcount(vlo & 0x55555555u) - __builtin_popcount(vhi & 0x55555555u);
+    };
 
-    // Steps t = 0 .. 16*(G+4)-1; lane l handles column t-l.  `acc` lags one step, so after chunk q
-    // lane 63's acc holds the bottom-row deltas of columns 16(q-4) .. 16(q-4)+15 == granule q-4.
+    RawCodes codes_next = load_codes(0);
+    uint64_t gran_next = load_gran(0);
+    uint32_t hinb_next = load_hin_byte(0);
+
+    // Steps t = 0 .. 32*(C+2)-1; lane l handles column t-l.  The accumulators lag one step, so after chunk q lane 63's
+    // (acc_lo, acc_hi) hold the bottom-row deltas of columns 32(q-2) .. 32(q-2)+31 == granule q-2.
+    // Order inside an iteration: decode inputs (the only waits) -> publish the previous chunk's granule -> prefetch the
+    // next chunk -> 32 steps.  Nothing conditional is ever younger than a prefetch, so its wait stays cheap.
     bool alive = true;
     PA_DBG(1, 1);
-    // One chunk = 16 columns.  `slot` holds this chunk's prefetched inputs and is refilled for chunk q+2
-    // (the loop is unrolled x2 over two slots so that in-flight loads are never moved between registers).
-    auto chunk = [&](int q, Pre& slot) {
+    const int Q = C + 2;
+    for (int q = 0; q < Q && alive; ++q) {
         PA_DBG(2, q + 1);
-        const int ca = job.col0 + 16 * q + cj;
-        const uint32_t code = (16 * q + cj < n) ? ((slot.code_w >> (2 * (ca & 15))) & 3u) : 0u;
+        // ---- decode this chunk's inputs (both prefetched values are consumed here so the only vector-memory wait of
+        //      the iteration sits before the publish store, never after it) ----
+        {
+            uint32_t g_lo = (uint32_t)gran_next, g_hi = (uint32_t)(gran_next >> 32);
+            asm volatile("" : "+v"(g_lo), "+v"(g_hi), "+v"(hinb_next));
+            gran_next = ((uint64_t)g_hi << 32) | g_lo;
+        }
+        const uint64_t codes64 = decode_codes(codes_next, q);
+        const uint32_t cw = upper ? (uint32_t)(codes64 >> 32) : (uint32_t)codes64;
+        const uint32_t code = (32 * q + (lane & 31) < n) ? ((cw >> sh) & 3u) : 0u;
         // top delta of this lane's column as (p << 31) | (m << 30); H::one() when there is no top row (blocks.rs:732)
-        uint32_t hin2 = has_hin ? (((slot.hin_b & 1u) << 31) | ((slot.hin_b & 2u) << 29)) : 0x80000000u;
-        if (q < G && has_gran) {
-            uint32_t bits;
-            alive = resolve_granule(g_gran, slot.gran, q, bits);
-            hin2 = (bits << sh) & 0xC0000000u;  // granule: column k at bits 31-2k (p), 30-2k (m)
+        uint32_t hin2 = has_hin ? (((hinb_next & 1u) << 31) | ((hinb_next & 2u) << 29)) : 0x80000000u;
+        if (q < C && has_gran) {
+            uint32_t glo, ghi;
+            alive = resolve_granule(g_gran, gran_next, q, glo, ghi);
+            hin2 = ((upper ? ghi : glo) << sh) & 0xC0000000u;
         }
         const uint32_t XS = code | hin2;
-        slot = issue(q + 2);
+        // ---- publish the granule completed by the previous chunk (q-1) ----
+        if (q >= 3) publish(q - 3);
+        // ---- prefetch the next chunk ----
+        codes_next = load_codes(q + 1);
+        gran_next = load_gran(q + 1);
+        hinb_next = load_hin_byte(q + 1);
 
-        const bool interior = !FILL && (q >= 4) && (q * 16 + 15 < n);
+        const bool interior = !FILL && (q >= 2) && (q * 32 + 31 < n);
         if (interior) {
-            if (exact_tail) run_chunk<false, true, false, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc, lane, pass_lane, vout, k40, k80);
-            else run_chunk<false, false, false, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc, lane, pass_lane, vout, k40, k80);
+            if (exact_tail) run_chunk<false, true, false, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80);
+            else run_chunk<false, false, false, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80);
         } else {
-            if (exact_tail) run_chunk<true, true, FILL, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc, lane, pass_lane, vout, k40, k80);
-            else run_chunk<true, false, FILL, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc, lane, pass_lane, vout, k40, k80);
+            if (exact_tail) run_chunk<true, true, FILL, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80);
+            else run_chunk<true, false, FILL, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80);
         }
-
-        const int g = q - 4;
-        if (g >= 0) {  // g < G always holds here
-            const int cols = n - 16 * g;
-            const uint32_t mask = cols >= 16 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> (2 * cols));  // column k at bits 31-2k, 30-2k
-            const uint32_t val = (uint32_t)__builtin_amdgcn_readlane((int)acc, 63) & mask;
-            if (job.hout_gran) {
-                if (lane == 0)
-                    __hip_atomic_store((gu64)job.hout_gran + g, ((uint64_t)(uint32_t)(g + 1) << 32) | (uint64_t)val,
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (job.hout_arr) {
-                if (lane < 16 && lane < cols) {
-                    const uint32_t tb = (val >> (30 - 2 * lane)) & 3u;  // bit1 = p, bit0 = m
-                    ((gu8)job.hout_arr)[job.col0 + 16 * g + lane] = (uint8_t)((tb >> 1) | ((tb & 1u) << 1));
-                }
-            }
-            sum += __builtin_popcount(val & 0xAAAAAAAAu) - __builtin_popcount(val & 0x55555555u);
-        }
-    };
-    const int Q = G + 4;
-    for (int q = 0; q < Q && alive; q += 2) {
-        chunk(q, pA);
-        if (q + 1 < Q && alive) chunk(q + 1, pB);
     }
+    if (alive) publish(C - 1);  // the last granule (completed by chunk Q-1 = C+1)
     PA_DBG(1, 2);
     if (!alive) {
         if (lane == 0) __hip_atomic_store((gu32)err, (uint32_t)PA_ERR_SPIN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -21,7 +21,7 @@ int main(int argc, char** argv) {
     unsigned int* dbg_dev = nullptr;
     CK(hipHostGetDevicePointer((void**)&dbg_dev, dbg_host, 0));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_pa_dbg), &dbg_dev, sizeof(dbg_dev)));
-    const int cw = (n + 15) / 16 + 2, S = (w + 31) / 32, G = (n + 15) / 16;
+    const int cw = (n + 15) / 16 + 2, S = (w + 31) / 32, G = (n + 31) / 32;
     std::vector<uint32_t> codes(cw, 0x1B1B1B1B);
     std::vector<uint64_t> prof(2 * w, 0x0123456789ABCDEFull), v(2 * w);
     for (int j = 0; j < w; ++j) { v[2 * j] = ~0ull; v[2 * j + 1] = 0; }

@@ -132,9 +132,14 @@ __global__ void build_b_batch_kernel(const uint8_t* __restrict__ b_cat, uint64_t
     if (invalid) atomicOr(bad, 1u);
 }
 
-template __global__ void strip_kernel<false, false>(const StripJob*, int, uint32_t*, uint32_t*);
-template __global__ void strip_kernel<true, false>(const StripJob*, int, uint32_t*, uint32_t*);
-template __global__ void strip_kernel<false, true>(const StripJob*, int, uint32_t*, uint32_t*);
+template __global__ void strip_kernel<1, false, false>(const StripJob*, int, uint32_t*, uint32_t*);
+template __global__ void strip_kernel<1, true, false>(const StripJob*, int, uint32_t*, uint32_t*);
+template __global__ void strip_kernel<1, false, true>(const StripJob*, int, uint32_t*, uint32_t*);
+template __global__ void strip_kernel<2, false, false>(const StripJob*, int, uint32_t*, uint32_t*);
+template __global__ void strip_kernel<4, false, false>(const StripJob*, int, uint32_t*, uint32_t*);
+template __global__ void pair_kernel<1>(const StripJob*, const int32_t*, int, uint32_t*);
+template __global__ void pair_kernel<2>(const StripJob*, const int32_t*, int, uint32_t*);
+template __global__ void pair_kernel<4>(const StripJob*, const int32_t*, int, uint32_t*);
 
 // ---- device context -----------------------------------------------------------------------------
 
@@ -187,10 +192,11 @@ bool build_b_device(const uint8_t* d_b, int m, uint64_t* d_prof, uint32_t* d_bad
     return hip_ok(hipGetLastError(), "build_b_kernel");
 }
 
-// Plan the chained strips of one rectangle: words [w0, w1) x n columns.
+// Plan the chained strips of one rectangle: words [w0, w1) x n columns, r.k subwords per lane (32*k words per strip).
 void plan_rect(std::vector<StripJob>& jobs, const RectPlan& r) {
     const int w = r.w1 - r.w0;
-    const int S = (w + kWordsPerStrip - 1) / kWordsPerStrip;
+    const int wps = kWordsPerStrip * r.k;
+    const int S = (w + wps - 1) / wps;
     for (int s = 0; s < S; ++s) {
         StripJob j;
         std::memset(&j, 0, sizeof j);
@@ -199,18 +205,18 @@ void plan_rect(std::vector<StripJob>& jobs, const RectPlan& r) {
         j.v = r.v;
         j.n = r.n;
         j.col0 = r.col0;
-        j.word0 = r.w0 + s * kWordsPerStrip;
-        const int words = std::min(kWordsPerStrip, w - s * kWordsPerStrip);
+        j.word0 = r.w0 + s * wps;
+        const int words = std::min(wps, w - s * wps);
         j.nlanes = 2 * words;
         j.flags = r.v_init_one ? kJobVInitOne : 0;
         j.tail_rows = -1;
         if (s == 0) {
             j.hin_arr = r.hin_arr;  // nullptr => +1
         } else {
-            j.hin_gran = r.gran + (size_t)(s - 1) * r.gran_stride;
+            j.hin_gran = r.gran + (size_t)(r.pingpong ? ((s - 1) & 1) : (s - 1)) * r.gran_stride;
         }
         if (s + 1 < S) {
-            j.hout_gran = r.gran + (size_t)s * r.gran_stride;
+            j.hout_gran = r.gran + (size_t)(r.pingpong ? (s & 1) : s) * r.gran_stride;
             j.exact_tail = 1;  // full strips anyway
         } else {
             j.hout_arr = r.hout_arr;
@@ -221,30 +227,92 @@ void plan_rect(std::vector<StripJob>& jobs, const RectPlan& r) {
         if (r.values) {
             j.values = r.values;
             j.fill_stride = r.fill_stride;
-            j.fill_word0 = r.fill_word0 + s * kWordsPerStrip;
+            j.fill_word0 = r.fill_word0 + s * wps;
         }
         jobs.push_back(j);
     }
 }
 
-size_t rect_granules(int n, int w) {
-    const int S = (w + kWordsPerStrip - 1) / kWordsPerStrip;
+size_t rect_granules(int n, int w, int k, bool pingpong) {
+    const int wps = kWordsPerStrip * k;
+    const int S = (w + wps - 1) / wps;
     const size_t G = (size_t)(n + 31) / 32;  // one 8-byte granule per 32 columns per strip boundary
-    return S > 1 ? (size_t)(S - 1) * G : 0;
+    const int rows = pingpong ? std::min(S - 1, 2) : S - 1;
+    return S > 1 ? (size_t)rows * G : 0;
 }
 
-bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_ticket_err, hipStream_t s, bool zero_ticket, bool scatter) {
+// Residency cap.  Every strip of a rectangle advances at the pace of the most crowded SIMD it touches, and the
+// dispatcher does not balance SIMDs by itself.  Blocks are 4 wavefronts (one per SIMD of a CU); an unused dynamic-LDS
+// request sized so that only `W = ceil(blocks / CUs)` blocks fit in a CU's 160 KB makes W the hard maximum of
+// wavefronts per SIMD instead of an average.
+static unsigned residency_lds_bytes(int blocks) {
+    static const bool off = getenv("PA_STRIP_NO_LDS_CAP") != nullptr;
+    if (off) return 0;
+    const int cus = g_device_props_cus > 0 ? g_device_props_cus : 256;
+    const int W = (blocks + cus - 1) / cus;
+    if (W > 7) return 0;  // beyond the register-file limit nothing is gained
+    const unsigned lds_total = 160u * 1024u;
+    return ((lds_total / (unsigned)(W + 1)) + 1024u) & ~1023u;  // W blocks fit, W + 1 do not
+}
+
+template <class Kern>
+static bool launch_one(Kern kern, int grid, int block_waves, unsigned lds, hipStream_t s, const StripJob* d_jobs, int njobs,
+                       uint32_t* d_ticket_err) {
+    static bool attr_set = false;  // one static per kernel instantiation
+    if (!attr_set) {
+        if (!hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                    "hipFuncSetAttribute(max dynamic LDS)"))
+            return false;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * block_waves), lds, s, d_jobs, njobs, d_ticket_err, d_ticket_err + 1);
+    return hip_ok(hipGetLastError(), "strip_kernel launch");
+}
+
+bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_ticket_err, hipStream_t s, bool zero_ticket, bool scatter,
+                   int k, int block_waves) {
     if (njobs == 0) return true;
     // d_ticket_err[0] = ticket, [1] = err
     if (zero_ticket && !hip_ok(hipMemsetAsync(d_ticket_err, 0, 2 * sizeof(uint32_t), s), "memset ticket")) return false;
-    const int grid = njobs;  // one wave per job; jobs beyond residency queue behind their producers (ticket order)
-    if (scatter)
-        hipLaunchKernelGGL((strip_kernel<false, true>), dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_ticket_err, d_ticket_err + 1);
-    else if (fill)
-        hipLaunchKernelGGL((strip_kernel<true, false>), dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_ticket_err, d_ticket_err + 1);
-    else
-        hipLaunchKernelGGL((strip_kernel<false, false>), dim3(grid), dim3(64), 0, s, d_jobs, njobs, d_ticket_err, d_ticket_err + 1);
-    return hip_ok(hipGetLastError(), "strip_kernel launch");
+    if (block_waves != 1 && block_waves != kStripBlockWaves) block_waves = kStripBlockWaves;
+    const int grid = (njobs + block_waves - 1) / block_waves;  // one wave per job; jobs beyond residency queue behind their
+                                                               // producers (ticket order)
+    const unsigned lds = block_waves == kStripBlockWaves ? residency_lds_bytes(grid) : 0;
+    if ((scatter || fill) && k != 1) {
+        set_error("fill / scatter strips are built for k = 1 only");
+        return false;
+    }
+    if (scatter) return launch_one(strip_kernel<1, false, true>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
+    if (fill) return launch_one(strip_kernel<1, true, false>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
+    if (k == 1) return launch_one(strip_kernel<1, false, false>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
+    if (k == 2) return launch_one(strip_kernel<2, false, false>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
+    if (k == 4) return launch_one(strip_kernel<4, false, false>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
+    set_error("unsupported strip height k=%d", k);
+    return false;
+}
+
+template <int K>
+static bool launch_pairs_k(const StripJob* d_jobs, const int32_t* d_first, int npairs, uint32_t* d_err, hipStream_t s, int grid, unsigned lds) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (!hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                    "hipFuncSetAttribute(max dynamic LDS)"))
+            return false;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((pair_kernel<K>), dim3(grid), dim3(64 * kStripBlockWaves), lds, s, d_jobs, d_first, npairs, d_err);
+    return hip_ok(hipGetLastError(), "pair_kernel launch");
+}
+
+bool launch_pairs(const StripJob* d_jobs, const int32_t* d_first, int npairs, uint32_t* d_ticket_err, hipStream_t s, int k) {
+    if (npairs == 0) return true;
+    const int grid = (npairs + kStripBlockWaves - 1) / kStripBlockWaves;
+    const unsigned lds = residency_lds_bytes(grid);
+    if (k == 1) return launch_pairs_k<1>(d_jobs, d_first, npairs, d_ticket_err + 1, s, grid, lds);
+    if (k == 2) return launch_pairs_k<2>(d_jobs, d_first, npairs, d_ticket_err + 1, s, grid, lds);
+    if (k == 4) return launch_pairs_k<4>(d_jobs, d_first, npairs, d_ticket_err + 1, s, grid, lds);
+    set_error("unsupported strip height k=%d", k);
+    return false;
 }
 
 }  // namespace pa
@@ -546,6 +614,10 @@ struct pa_batch {
     std::vector<StripJob> jobs;
     std::vector<int> last_job;  // per pair (or -1 when w == 0)
     size_t total_gran = 0;
+    int k = 1;  // 32-row subwords per lane of this batch's strips
+    bool sequential = false;  // one wavefront per pair (pair_kernel) instead of chained strips
+    int block_waves = 1;
+    DeviceBuf d_first;  // sequential: first job of every pair (+ end)
     double cells = 0, word_updates = 0, algo_bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -556,11 +628,83 @@ struct pa_batch {
     }
 };
 
+// Shape of a cost-only batch.  Measured on MI355X (profiles/r01_runs/k_sweep*.log, chain_probe2.log; ns per strip step):
+//  * more 32-row subwords per lane (k) = fewer VALU instructions per DP cell (the kernel's bound) but slower steps and
+//    more padding in the last strip of a pair;
+//  * chained strips of one pair advance at the pace of the most crowded SIMD they touch, so a chained batch costs
+//    about (wavefronts per SIMD + 1) saturated steps per column, or one lone step when every strip has its own SIMD;
+//  * one wavefront can instead run a whole pair, strip after strip (sequential mode): no coupling at all, the best
+//    shape as soon as there is about one pair per SIMD.
+// The estimates below only rank the six candidates.  PA_STRIP_K=1|2|4 and PA_BATCH_MODE=seq|chain restrict them.
+struct BatchShape {
+    int k = 1;
+    bool sequential = false;
+    int block_waves = 1;
+};
+static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, size_t pairs) {
+    static const double kLone[3] = {52.9, 76.5, 121.0}, kSatChain[3] = {50.8, 65.0, 112.5};
+    static const double kShare[4] = {1.0, 0.85, 0.80, 0.78};  // per-wavefront step cost at 1, 2, 3, >= 4 wavefronts per SIMD
+    static const int kK[3] = {1, 2, 4};
+    const double simds = (double)(g_device_props_cus > 0 ? g_device_props_cus : 256) * 4.0;
+    int env_k = 0, env_mode = 0;
+    if (const char* e = getenv("PA_STRIP_K")) {
+        const int k = atoi(e);
+        if (k == 1 || k == 2 || k == 4) env_k = k;
+    }
+    if (const char* e = getenv("PA_BATCH_MODE")) env_mode = !strcmp(e, "seq") ? 2 : (!strcmp(e, "chain") ? 1 : 0);
+    BatchShape best_shape;
+    double best = -1;
+    for (int t = 0; t < 3; ++t) {
+        const int k = kK[t];
+        if (env_k && k != env_k) continue;
+        double strips = 0, live = 0, colsteps = 0, longest = 0;  // colsteps = sum over strips of their columns
+        for (size_t i = 0; i < pairs; ++i) {
+            if (a_len[i] == 0 || b_len[i] == 0) continue;
+            const double S = (double)(((b_len[i] + 63) / 64 + (size_t)(kWordsPerStrip * k) - 1) / (size_t)(kWordsPerStrip * k));
+            strips += S;
+            live += 1;
+            colsteps += S * (double)a_len[i];
+            longest = std::max(longest, S * (double)a_len[i]);
+        }
+        if (live == 0) return best_shape;
+        if (env_mode != 2) {  // chained strips
+            const double avg = strips / simds;
+            const double per_col = avg <= 1.0 ? kLone[t] : (avg + 1.0) * kSatChain[t];
+            const double cost = per_col * colsteps / strips;
+            if (best < 0 || cost < best) {
+                best = cost;
+                best_shape.k = k;
+                best_shape.sequential = false;
+                best_shape.block_waves = strips <= simds ? kStripBlockWaves : 1;
+            }
+        }
+        if (env_mode != 1) {  // one wavefront per pair
+            const double W = std::max(1.0, std::ceil(live / simds));
+            const double share = kShare[(int)std::min(W, 4.0) - 1];
+            // W pairs share every busy SIMD for as long as the longest of them runs; huge batches stream and balance
+            const double cost = std::max(std::min(W, 7.0) * longest, colsteps / std::min(live, simds)) * kLone[t] * share;
+            if (best < 0 || cost < best) {
+                best = cost;
+                best_shape.k = k;
+                best_shape.sequential = true;
+                best_shape.block_waves = kStripBlockWaves;
+            }
+        }
+    }
+    return best_shape;
+}
+
 extern "C" pa_batch* pa_batch_create(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b,
                                      const size_t* b_len, size_t pairs) {
     if (!ensure_device()) return nullptr;
     auto p = std::make_unique<pa_batch>();
     p->pairs = pairs;
+    {
+        const BatchShape sh = choose_batch_shape(a_len, b_len, pairs);
+        p->k = sh.k;
+        p->sequential = sh.sequential;
+        p->block_waves = sh.block_waves;
+    }
     size_t ta = 0, tb = 0, tc = 0, tp = 0, tg = 0;
     for (size_t i = 0; i < pairs; ++i) {
         if (a_len[i] > (size_t)(1u << 30) || b_len[i] > (size_t)(1u << 30)) {
@@ -579,7 +723,7 @@ extern "C" pa_batch* pa_batch_create(const uint8_t* const* a, const size_t* a_le
         tb += (b_len[i] + 15) & ~size_t(15);
         tc += (a_len[i] + 15) / 16;
         tp += w;
-        tg += rect_granules((int)a_len[i], (int)w);
+        tg += rect_granules((int)a_len[i], (int)w, p->k, p->sequential);
         p->cells += (double)a_len[i] * (double)b_len[i];
         p->word_updates += (double)a_len[i] * (double)w;
         // algorithmic HBM bytes, cost-only rectangle: 0.75 B/column + 48 B/word
@@ -600,7 +744,10 @@ extern "C" pa_batch* pa_batch_create(const uint8_t* const* a, const size_t* a_le
     }
     // Jobs: pair-major, strips of a pair consecutive (ticket order == dependency order).
     p->last_job.assign(pairs, -1);
+    std::vector<int32_t> first(pairs + 1, 0);
     for (size_t i = 0; i < pairs; ++i) {
+        first[i] = (int32_t)p->jobs.size();
+        first[i + 1] = first[i];
         const int w = (int)((b_len[i] + 63) / 64);
         if (w == 0 || a_len[i] == 0) continue;
         RectPlan r;
@@ -616,8 +763,16 @@ extern "C" pa_batch* pa_batch_create(const uint8_t* const* a, const size_t* a_le
         r.exact_end = false;
         r.v_init_one = true;
         r.tail_rows = (int)b_len[i];
+        r.k = p->k;
+        r.pingpong = p->sequential;
         plan_rect(p->jobs, r);
         p->last_job[i] = (int)p->jobs.size() - 1;
+        first[i + 1] = (int32_t)p->jobs.size();
+    }
+    if (p->sequential) {
+        if (!p->d_first.alloc(first.size() * 4)) return nullptr;
+        if (!hip_ok(hipMemcpyAsync(p->d_first.ptr, first.data(), first.size() * 4, hipMemcpyHostToDevice, p->stream), "H2D first")) return nullptr;
+        if (!hip_ok(hipStreamSynchronize(p->stream), "sync")) return nullptr;  // `first` is a local
     }
     {
         std::vector<PairDesc> desc(pairs);
@@ -664,7 +819,12 @@ extern "C" int pa_batch_run(pa_batch* p, int32_t* cost_out, float* kernel_ms) {
     if (!hip_ok(hipMemsetAsync(p->d_sums.ptr, 0, std::max<size_t>(p->pairs * 4, 16), s), "memset sums")) return PA_E_HIP;
     // d_misc (ticket, err, -, bad-base flag) was zeroed above; the events bracket the strip kernel alone
     if (!hip_ok(hipEventRecord(p->ev0, s), "event")) return PA_E_HIP;
-    if (!launch_strips(p->d_jobs.as<StripJob>(), (int)p->jobs.size(), false, p->d_misc.as<uint32_t>(), s, false)) return PA_E_HIP;
+    if (p->sequential) {
+        if (!launch_pairs(p->d_jobs.as<StripJob>(), p->d_first.as<int32_t>(), (int)p->pairs, p->d_misc.as<uint32_t>(), s, p->k)) return PA_E_HIP;
+    } else if (!launch_strips(p->d_jobs.as<StripJob>(), (int)p->jobs.size(), false, p->d_misc.as<uint32_t>(), s, false, false, p->k,
+                              p->block_waves)) {
+        return PA_E_HIP;
+    }
     if (!hip_ok(hipEventRecord(p->ev1, s), "event")) return PA_E_HIP;
     // (4) read back: bottom sums and each pair's last v word (for the rows beyond |b| in the last word)
     std::vector<int32_t> sums(p->pairs, 0);

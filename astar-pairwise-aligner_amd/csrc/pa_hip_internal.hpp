@@ -11,7 +11,7 @@
 
 namespace pa {
 
-constexpr int kWordsPerStrip = 32;  // 64 lanes x 32 rows = 32 reference words (2048 rows)
+constexpr int kWordsPerStrip = 32;  // per subword-per-lane: a strip of k subwords/lane covers 32*k reference words (2048*k rows)
 
 void set_error(const char* fmt, ...);
 bool hip_ok(hipError_t e, const char* what);
@@ -47,12 +47,15 @@ struct RectPlan {
     int tail_rows = -1;  // see StripJob::tail_rows
     uint32_t* values = nullptr;  // fill mode
     int fill_stride = 0, fill_word0 = 0;
+    bool pingpong = false;  // sequential-pairs mode: two granule rows per rectangle, strip s writes row s&1
+    int k = 1;  // 32-row subwords per lane (1: lowest latency; 2, 4: fewer instructions per cell, cost-only strips)
 };
 
 void plan_rect(std::vector<StripJob>& jobs, const RectPlan& r);
-size_t rect_granules(int n, int w);
+size_t rect_granules(int n, int w, int k = 1, bool pingpong = false);
 bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_ticket_err, hipStream_t s, bool zero_ticket = true,
-                   bool scatter = false);
+                   bool scatter = false, int k = 1, int block_waves = kStripBlockWaves);
+bool launch_pairs(const StripJob* d_jobs, const int32_t* d_first, int npairs, uint32_t* d_ticket_err, hipStream_t s, int k);
 bool encode_a_device(const uint8_t* d_a, int n, uint32_t* d_codes, uint32_t* d_bad, hipStream_t s);
 bool build_b_device(const uint8_t* d_b, int m, uint64_t* d_prof, uint32_t* d_bad, hipStream_t s);
 

@@ -54,7 +54,7 @@ struct StripJob {
     int32_t* sum_out;         // *sum_out = sum of bottom-row deltas over the n columns (if non-null)
     int32_t n;                // columns
     int32_t word0;            // first 64-row word of this strip (index into b_prof / v)
-    int32_t nlanes;           // real lanes: 2 * (words in this strip), 2..64, even
+    int32_t nlanes;           // real 32-row subwords: 2 * (words in this strip), 2..128K, even (K subwords per lane)
     int32_t fill_stride;      // words per column in `values`
     int32_t fill_word0;       // word index of this strip inside a `values` column
     int32_t exact_tail;       // nlanes<64 only.  1: lanes >= nlanes forward h unchanged, so lane 63 carries the true
@@ -99,82 +99,102 @@ __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t old_, uint32_t src) {
 __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
 // Packed pipeline register X:  bit31 = h.p (delta +1), bit30 = h.m (delta -1), bits[1:0] = base code, rest 0.
-// One Myers step on a 32-row lane (myers.rs:27-55 with 32-bit words; eq from profile.rs:141-144).
+// One Myers step on a lane of K 32-row subwords (myers.rs:27-55 on a 32K-bit word; eq from profile.rs:141-144).
 // `acc` collects the lane's outgoing deltas delayed by one step: newest column in bits [1:0] = (p,m),
 // i.e. after 16 steps column k of the chunk sits at bit 31-2k (p) / 30-2k (m).
-// 24 VALU instructions: v_alignbit shifts the incoming carry in without extracting it, v_bitop3 does the rest.
+// Instruction budget: 10 "plumbing" ops per lane-step (accumulate, cross-lane shift, field extracts, repack) + 12 per
+// subword (+1 for the carry-in of subword 0).  The chip is VALU-issue bound at ~4 cycles per wave instruction per SIMD
+// (profiles/r01_runs/issue_probe*.log), so instructions per DP cell is THE cost: K = 1, 2, 4 cost 23, 17.5, 14.75
+// instructions per 2048 cells.  Larger K trades per-step latency (single-pair speed) for throughput.
 // SCATTER: eq comes from a ScatterProfile (profile.rs:25-75): four match masks per word, selected by the text code
-// (A0 C1 T2 G3), so pattern wildcards (N, *, Y, R) work; one extra select op per step.
-template <bool PRED, bool PASS, bool SCATTER>
-__device__ __forceinline__ void myers_step(uint32_t s_x, uint32_t& X, uint32_t& vp, uint32_t& vm,
-                                           uint32_t nb0, uint32_t nb1, uint32_t nb2, uint32_t nb3, uint32_t& acc, bool active,
-                                           bool pass_lane, uint32_t k40, uint32_t k80) {
-#if !(defined(PA_ABLATE) && (PA_ABLATE & 4))
+// (A0 C1 T2 G3), so pattern wildcards (N, *, Y, R) work.
+template <int K, bool PRED, bool PASS, bool SCATTER>
+__device__ __forceinline__ void myers_step(uint32_t s_x, uint32_t& X, uint32_t (&vp)[K], uint32_t (&vm)[K],
+                                           const uint32_t (&nb0)[K], const uint32_t (&nb1)[K], const uint32_t (&nb2)[K],
+                                           const uint32_t (&nb3)[K], uint32_t& acc, bool active, bool pass_lane, uint32_t k40,
+                                           uint32_t k80) {
     acc = __builtin_amdgcn_alignbit(acc, X, 30);  // (acc << 2) | (X >> 30)
-#endif
-#if defined(PA_ABLATE) && (PA_ABLATE & 2)
-    const uint32_t Xin = X ^ s_x;  // ablation: no cross-lane shift
-#else
     const uint32_t Xin = dpp_wave_shr1(s_x, X);
-#endif
     const uint32_t a0 = (uint32_t)__builtin_amdgcn_sbfe((int)Xin, 0, 1);
     const uint32_t a1 = (uint32_t)__builtin_amdgcn_sbfe((int)Xin, 1, 1);
     const uint32_t hm0 = (Xin >> 30) & 1u;
-    uint32_t eq;
-    if (SCATTER) {
-        const uint32_t e01 = __builtin_amdgcn_bitop3_b32(a0, nb1, nb0, 0xCA);  // a0 ? mask[1] : mask[0]
-        const uint32_t e23 = __builtin_amdgcn_bitop3_b32(a0, nb3, nb2, 0xCA);
-        eq = __builtin_amdgcn_bitop3_b32(a1, e23, e01, 0xCA);
-    } else {
-        const uint32_t x0 = a0 ^ nb0, x1 = a1 ^ nb1;
-        eq = x0 & x1;
+    uint32_t eq[K], vx[K], sm[K], hp[K], hm[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (SCATTER) {
+            const uint32_t e01 = __builtin_amdgcn_bitop3_b32(a0, nb1[k], nb0[k], 0xCA);  // a0 ? mask[1] : mask[0]
+            const uint32_t e23 = __builtin_amdgcn_bitop3_b32(a0, nb3[k], nb2[k], 0xCA);
+            eq[k] = __builtin_amdgcn_bitop3_b32(a1, e23, e01, 0xCA);
+        } else {
+            eq[k] = (a0 ^ nb0[k]) & (a1 ^ nb1[k]);
+        }
+        vx[k] = eq[k] | vm[k];
     }
-    const uint32_t vx = eq | vm;
-    const uint32_t eq2 = eq | hm0;
-    const uint32_t hx = (((eq2 & vp) + vp) ^ vp) | eq2;
-    const uint32_t hp = vm | ~(hx | vp);
-    const uint32_t hm = vp & hx;
-    // two bit-field inserts (v_bfi / v_bitop3 each); bits 29:2 of X are always 0, so keeping Xin's other bits is
-    // exact.  k40 / k80 are opaque to the optimizer on purpose, otherwise it re-expands this into 5 ops.
-    const uint32_t xm = __builtin_amdgcn_bitop3_b32(k40, hm >> 1, Xin, 0xCA);  // k40 ? (hm >> 1) : Xin
-    uint32_t Xo = __builtin_amdgcn_bitop3_b32(k80, hp, xm, 0xCA);             // k80 ? hp : xm
-    const uint32_t hp2 = __builtin_amdgcn_alignbit(hp, Xin, 31);  // (hp << 1) | (Xin >> 31)
-    const uint32_t hm2 = (hm << 1) | hm0;
-    const uint32_t nvp = hm2 | ~(vx | hp2);
-    const uint32_t nvm = hp2 & vx;
-    if (PASS) Xo = pass_lane ? Xin : Xo;
-    if (PRED) {
-        vp = active ? nvp : vp;
-        vm = active ? nvm : vm;
+    eq[0] |= hm0;
+    // (eq & vp) + vp over the whole 32K-bit word
+    if (K == 1) {
+        sm[0] = (eq[0] & vp[0]) + vp[0];
     } else {
-        vp = nvp;
-        vm = nvm;
+        uint32_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            uint32_t co;
+            sm[k] = __builtin_addc(eq[k] & vp[k], vp[k], carry, &co);
+            carry = co;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t hx = (sm[k] ^ vp[k]) | eq[k];
+        hp[k] = vm[k] | ~(hx | vp[k]);
+        hm[k] = vp[k] & hx;
+    }
+    // two bit-field inserts (v_bitop3 each); bits 29:2 of X are always 0, so keeping Xin's other bits is exact.
+    // k40 / k80 are opaque to the optimizer on purpose, otherwise it re-expands this into 5 ops.
+    const uint32_t xm = __builtin_amdgcn_bitop3_b32(k40, hm[K - 1] >> 1, Xin, 0xCA);  // k40 ? (hm >> 1) : Xin
+    uint32_t Xo = __builtin_amdgcn_bitop3_b32(k80, hp[K - 1], xm, 0xCA);             // k80 ? hp : xm
+    if (PASS) Xo = pass_lane ? Xin : Xo;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t hp2 = __builtin_amdgcn_alignbit(hp[k], k == 0 ? Xin : hp[k - 1], 31);  // (hp << 1) | carry-in
+        const uint32_t hm2 = k == 0 ? ((hm[0] << 1) | hm0) : __builtin_amdgcn_alignbit(hm[k], hm[k - 1], 31);
+        const uint32_t nvp = __builtin_amdgcn_bitop3_b32(hm2, vx[k], hp2, 0xF1);  // hm2 | ~(vx | hp2)
+        const uint32_t nvm = hp2 & vx[k];
+        if (PRED) {
+            vp[k] = active ? nvp : vp[k];
+            vm[k] = active ? nvm : vm[k];
+        } else {
+            vp[k] = nvp;
+            vm[k] = nvm;
+        }
     }
     X = Xo;
 }
 
 // One chunk = 32 columns = 32 unrolled steps.  Lane j (< 32) of XS carries the packed pipeline input of column 32q+j.
 // The lagged accumulator of steps 0..15 is acc_lo, of steps 16..31 acc_hi (static, so no register moves).
-template <bool PRED, bool PASS, bool FILL, bool SCATTER>
-__device__ __forceinline__ void run_chunk(const StripJob& job, int q, uint32_t XS, uint32_t& X, uint32_t& vp,
-                                          uint32_t& vm, uint32_t nb0, uint32_t nb1, uint32_t nb2, uint32_t nb3,
-                                          uint32_t& acc_lo, uint32_t& acc_hi, int lane, bool pass_lane, gu32 vout,
-                                          uint32_t k40, uint32_t k80) {
+template <int K, bool PRED, bool PASS, bool FILL, bool SCATTER>
+__device__ __forceinline__ void run_chunk(const StripJob& job, int q, uint32_t XS, uint32_t& X, uint32_t (&vp)[K],
+                                          uint32_t (&vm)[K], const uint32_t (&nb0)[K], const uint32_t (&nb1)[K],
+                                          const uint32_t (&nb2)[K], const uint32_t (&nb3)[K], uint32_t& acc_lo,
+                                          uint32_t& acc_hi, int lane, bool pass_lane, gu32 vout, uint32_t k40, uint32_t k80) {
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
-#if defined(PA_ABLATE) && (PA_ABLATE & 1)
-        const uint32_t s_x = rfl(XS) + (uint32_t)j;  // ablation: one readfirstlane per chunk instead of a readlane per step
-#else
         const uint32_t s_x = (uint32_t)__builtin_amdgcn_readlane((int)XS, j);
-#endif
         const int col = q * 32 + j - lane;
         const bool active = PRED ? ((unsigned)col < (unsigned)job.n) : true;
-        myers_step<PRED, PASS, SCATTER>(s_x, X, vp, vm, nb0, nb1, nb2, nb3, j < 16 ? acc_lo : acc_hi, active, pass_lane, k40, k80);
+        myers_step<K, PRED, PASS, SCATTER>(s_x, X, vp, vm, nb0, nb1, nb2, nb3, j < 16 ? acc_lo : acc_hi, active, pass_lane, k40, k80);
         if (FILL) {
-            if (active && lane < job.nlanes) {
-                gu32 dst = vout + (size_t)col * (size_t)job.fill_stride * 4;
-                dst[0] = vp;
-                dst[2] = vm;
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int sub = lane * K + k;
+                    if (sub < job.nlanes) {
+                        gu32 dst = vout + (size_t)col * (size_t)job.fill_stride * 4 + (size_t)(sub >> 1) * 4 + (sub & 1);
+                        dst[0] = vp[k];
+                        dst[2] = vm[k];
+                    }
+                }
             }
         }
     }
@@ -210,48 +230,52 @@ __device__ __forceinline__ bool resolve_granule(gcu64 g, uint64_t pre, int q, ui
 }
 
 // Process one strip.  On a spin timeout the error word is set and the strip stops early.
-template <bool FILL, bool SCATTER>
+// K = 32-row subwords per lane: the strip covers 64*K subwords = 32*K reference words.
+template <int K, bool FILL, bool SCATTER>
 __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
     const int lane = (int)(threadIdx.x & 63);
     const int n = job.n;
     const int C = (n + 31) >> 5;  // 32-column chunks == granules
-    const bool real = lane < job.nlanes;
-    const bool pass_lane = !real;
-    const int word = job.word0 + (lane >> 1);
-    const int half = lane & 1;
+    const bool pass_lane = lane * K >= job.nlanes;  // the whole lane is below the rectangle
 
-    uint32_t vp = 0, vm = 0, nb0 = 0, nb1 = 0, nb2 = 0, nb3 = 0;
+    uint32_t vp[K], vm[K], nb0[K], nb1[K], nb2[K], nb3[K];
     const gcu32 g_prof = (gcu32)job.b_prof;
     const gu32 g_v = (gu32)job.v;
-    if (real) {
-        if (SCATTER) {  // [B; 4] per word
-            nb0 = g_prof[word * 8 + half];
-            nb1 = g_prof[word * 8 + 2 + half];
-            nb2 = g_prof[word * 8 + 4 + half];
-            nb3 = g_prof[word * 8 + 6 + half];
-        } else {
-            nb0 = g_prof[word * 4 + half];
-            nb1 = g_prof[word * 4 + 2 + half];
-        }
-        if (job.flags & kJobVInitOne) {
-            vp = 0xFFFFFFFFu;
-            vm = 0u;
-        } else {
-            vp = g_v[word * 4 + half];
-            vm = g_v[word * 4 + 2 + half];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int sub = lane * K + k;  // subword of this strip: word = word0 + sub/2, half = sub&1
+        const int word = job.word0 + (sub >> 1), half = sub & 1;
+        vp[k] = vm[k] = nb0[k] = nb1[k] = nb2[k] = nb3[k] = 0;
+        if (sub < job.nlanes) {
+            if (SCATTER) {  // [B; 4] per word
+                nb0[k] = g_prof[word * 8 + half];
+                nb1[k] = g_prof[word * 8 + 2 + half];
+                nb2[k] = g_prof[word * 8 + 4 + half];
+                nb3[k] = g_prof[word * 8 + 6 + half];
+            } else {
+                nb0[k] = g_prof[word * 4 + half];
+                nb1[k] = g_prof[word * 4 + 2 + half];
+            }
+            if (job.flags & kJobVInitOne) {
+                vp[k] = 0xFFFFFFFFu;
+                vm[k] = 0u;
+            } else {
+                vp[k] = g_v[word * 4 + half];
+                vm[k] = g_v[word * 4 + 2 + half];
+            }
         }
     }
     gu32 vout = nullptr;
-    if (FILL) vout = (gu32)job.values + ((size_t)(job.fill_word0 + (lane >> 1)) * 4 + half);
+    if (FILL) vout = (gu32)job.values + (size_t)job.fill_word0 * 4;
 
     uint32_t X = 0, acc_lo = 0, acc_hi = 0;
     int32_t sum = 0;
-    uint32_t k40 = 0x40000000u, k80 = 0x80000000u;  // see myers_step
-    asm volatile("" : "+s"(k40), "+s"(k80));
+    uint32_t k40 = 0x40000000u, k80 = 0x80000000u;  // see myers_step; kept in VGPRs (SGPR operands halve the issue rate)
+    asm volatile("" : "+v"(k40), "+v"(k80));
     const int cj = lane & 15;
     const bool upper = (lane & 16) != 0;          // lanes 16..31 build columns 16..31 of the chunk
     const uint32_t sh = 2u * (uint32_t)cj;
-    const bool exact_tail = job.exact_tail != 0 && job.nlanes < 64;
+    const bool exact_tail = job.exact_tail != 0 && job.nlanes < 64 * K;
 
     // Per-chunk inputs.  The packed sequence is read with SCALAR loads (constant address space -> s_load, tracked by
     // lgkmcnt, so it never waits behind the granule stores); the granule and the optional top-row bytes are vector
@@ -356,11 +380,11 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
 
         const bool interior = !FILL && (q >= 2) && (q * 32 + 31 < n);
         if (interior) {
-            if (exact_tail) run_chunk<false, true, false, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80);
-            else run_chunk<false, false, false, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80);
+            if (exact_tail) run_chunk<K, false, true, false, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80);
+            else run_chunk<K, false, false, false, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80);
         } else {
-            if (exact_tail) run_chunk<true, true, FILL, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80);
-            else run_chunk<true, false, FILL, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80);
+            if (exact_tail) run_chunk<K, true, true, FILL, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80);
+            else run_chunk<K, true, false, FILL, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80);
         }
     }
     if (alive) publish(C - 1);  // the last granule (completed by chunk Q-1 = C+1)
@@ -369,38 +393,47 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
         if (lane == 0) __hip_atomic_store((gu32)err, (uint32_t)PA_ERR_SPIN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-    if (real) {
-        g_v[word * 4 + half] = vp;
-        g_v[word * 4 + 2 + half] = vm;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int sub = lane * K + k;
+        if (sub < job.nlanes) {
+            const int word = job.word0 + (sub >> 1), half = sub & 1;
+            g_v[word * 4 + half] = vp[k];
+            g_v[word * 4 + 2 + half] = vm[k];
+        }
     }
     if (job.sum_out) {
-        if (!exact_tail && job.nlanes < 64) {
+        int32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int sub = lane * K + k;
+            const bool real = sub < job.nlanes;
             // zero pad rows: subtract their right-edge value (simd.rs:202-224)
-            int32_t c = real ? 0 : (__builtin_popcount(vp) - __builtin_popcount(vm));
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-            sum -= c;
+            if (!exact_tail && !real) c += __builtin_popcount(vp[k]) - __builtin_popcount(vm[k]);
+            if (job.tail_rows >= 0 && real) {
+                const int row0 = 64 * job.word0 + 32 * sub;  // first DP row of this subword
+                int over = row0 + 32 - job.tail_rows;         // its rows at or beyond |b|
+                over = over < 0 ? 0 : (over > 32 ? 32 : over);
+                const uint32_t tm = over == 0 ? 0u : (over == 32 ? 0xFFFFFFFFu : ~((1u << (32 - over)) - 1u));
+                c += __builtin_popcount(vp[k] & tm) - __builtin_popcount(vm[k] & tm);
+            }
         }
-        if (job.tail_rows >= 0) {
-            const int row0 = 64 * word + 32 * half;  // first DP row of this lane
-            int over = row0 + 32 - job.tail_rows;    // rows of this lane at or beyond |b|
-            over = over < 0 ? 0 : (over > 32 ? 32 : over);
-            const uint32_t tm = over == 0 ? 0u : (over == 32 ? 0xFFFFFFFFu : ~((1u << (32 - over)) - 1u));
-            int32_t c = real ? (__builtin_popcount(vp & tm) - __builtin_popcount(vm & tm)) : 0;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-            sum -= c;
-        }
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        sum -= c;
         if (lane == 0) *(gi32)job.sum_out = sum;
     }
     PA_DBG(1, 3);
 }
 
-// One 64-thread block = one wavefront = one strip job, claimed by ticket (jobs are listed producer before
-// consumer, so a consumer's producer has always started; no assumption about dispatch order).
+// One wavefront = one strip job, claimed by ticket (jobs are listed producer before consumer, so a consumer's producer
+// has always started; no assumption about dispatch order).  Blocks are kStripBlockWaves wavefronts so that the
+// dispatcher spreads them over the four SIMDs of a CU evenly: every strip of a pair advances at the pace of the most
+// crowded SIMD, so balance is worth more than anything else at 1-4 wavefronts per SIMD.
 // `ticket` and `err` must be zeroed (and every hin/hout granule buffer cleared) before the launch.
-template <bool FILL, bool SCATTER = false>
-__global__ __launch_bounds__(64) void strip_kernel(const StripJob* __restrict__ jobs, int njobs,
+constexpr int kStripBlockWaves = 4;
+template <int K, bool FILL, bool SCATTER = false>
+__global__ __launch_bounds__(64 * kStripBlockWaves) void strip_kernel(const StripJob* __restrict__ jobs, int njobs,
                                                    uint32_t* ticket, uint32_t* err) {
     uint32_t t = 0;
     if ((threadIdx.x & 63) == 0) t = atomicAdd(ticket, 1u);
@@ -408,9 +441,28 @@ __global__ __launch_bounds__(64) void strip_kernel(const StripJob* __restrict__ 
     PA_DBG(0, t + 1);
     if (t < (uint32_t)njobs) {
         const StripJob job = jobs[t];
-        run_strip<FILL, SCATTER>(job, err);
+        run_strip<K, FILL, SCATTER>(job, err);
     }
     PA_DBG(0, 0x1000 + t);
+}
+
+// Sequential-pairs variant: one wavefront runs ALL strips of one rectangle top to bottom (jobs[first[p]] ..
+// jobs[first[p+1]-1]); the bottom row of strip s goes through the same granule rows (two per rectangle, ping-pong) but
+// is produced and consumed by the same wavefront, so nothing ever polls.  With >= one rectangle per SIMD this removes the
+// strip-to-strip coupling that costs chained strips 40-70 % at 2-7 wavefronts per SIMD (profiles/r01_runs/chain_probe2.log).
+template <int K>
+__global__ __launch_bounds__(64 * kStripBlockWaves) void pair_kernel(const StripJob* __restrict__ jobs,
+                                                                      const int32_t* __restrict__ first, int npairs,
+                                                                      uint32_t* err) {
+    const int p = (int)rfl((uint32_t)(blockIdx.x * kStripBlockWaves + (threadIdx.x >> 6)));
+    if (p >= npairs) return;
+    const int j0 = first[p], j1 = first[p + 1];
+    for (int j = j0; j < j1; ++j) {
+        const StripJob job = jobs[j];
+        run_strip<K, false, false>(job, err);
+        // the next strip reads what this one stored (granules, through the L2): drain and order the stores first
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    }
 }
 
 }  // namespace pa

@@ -1,7 +1,7 @@
-"""How much does the strip-to-strip hand-off cost?  Same wave count and columns, different chain lengths:
-rows = 2048*S per pair (S chained strips), `pairs` chosen so that pairs*S ~ 7154 waves (7 per SIMD)."""
+"""How much do SIMD sharing and the strip-to-strip hand-off cost?  Same columns, W wavefronts per SIMD, chains of S strips:
+rows = 2048*K*S per pair, pairs = 1024*W/S.  Usage: PA_STRIP_K=4 python tools/chain_probe.py W:S [W:S ...]"""
+import os
 import sys
-import time
 
 sys.path.insert(0, ".")
 import astar_pairwise_aligner_amd as pa
@@ -9,9 +9,11 @@ from astar_pairwise_aligner_amd.generate import random_sequence
 
 pa.require_gpu()
 n = 100_000
-for S in (1, 2, 7, 49):
-    pairs = 7154 // S
-    base = [(random_sequence(n, seed=s + 1), random_sequence(2048 * S, seed=1000 + s)) for s in range(min(pairs, 16))]
+K = int(os.environ.get("PA_STRIP_K", "1"))
+for arg in sys.argv[1:]:
+    W, S = (int(x) for x in arg.split(":"))
+    pairs = 1024 * W // S
+    base = [(random_sequence(n, seed=s + 1), random_sequence(2048 * K * S, seed=1000 + s)) for s in range(min(pairs, 8))]
     ps = [base[i % len(base)] for i in range(pairs)]
     b = pa.Batch(ps)
     st = b.stats()
@@ -20,7 +22,6 @@ for S in (1, 2, 7, 49):
     for _ in range(3):
         costs, ms = b.run()
         best = min(best, ms)
-    steps = st["strips"] * (n + 64)
-    print(f"chain S={S:3d} pairs={pairs:5d} strips={int(st['strips'])} kernel_ms={best:.3f} GCUPS={st['cells']/best/1e6:.0f} "
-          f"ns per strip-step per SIMD={best*1e6/ (steps/1024):.1f}", flush=True)
+    print(f"K={K} W={W} chain S={S:3d} pairs={pairs:5d} strips={int(st['strips'])} kernel_ms={best:.3f} GCUPS={st['cells']/best/1e6:.0f} "
+          f"ns per wave-step={best*1e6/(n+64):.1f}  per SIMD-share={best*1e6/(n+64)/max(1.0, st['strips']/1024):.1f}", flush=True)
     b.close()

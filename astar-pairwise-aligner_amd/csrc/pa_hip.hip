@@ -140,6 +140,7 @@ template __global__ void strip_kernel<4, false, false>(const StripJob*, int, uin
 template __global__ void pair_kernel<1>(const StripJob*, const int32_t*, int, uint32_t*);
 template __global__ void pair_kernel<2>(const StripJob*, const int32_t*, int, uint32_t*);
 template __global__ void pair_kernel<4>(const StripJob*, const int32_t*, int, uint32_t*);
+template __global__ void pair_kernel<8>(const StripJob*, const int32_t*, int, uint32_t*);
 
 // ---- device context -----------------------------------------------------------------------------
 
@@ -192,21 +193,41 @@ bool build_b_device(const uint8_t* d_b, int m, uint64_t* d_prof, uint32_t* d_bad
     return hip_ok(hipGetLastError(), "build_b_kernel");
 }
 
-// Plan the chained strips of one rectangle: words [w0, w1) x n columns, r.k subwords per lane (32*k words per strip).
+// How a rectangle of w words is cut into strips.  Chained strips all have the kernel's height (32*k words).  A sequential
+// pair may finish with up to kMaxTail1[k] short strips of 32 words when that is cheaper than one mostly empty tall strip
+// (a k = 1 step costs about 0.67 / 0.43 / 0.25 of a k = 2 / 4 / 8 step).
+StripPlan strip_plan(int w, int k, bool sequential) {
+    StripPlan p;
+    const int wps = kWordsPerStrip * k;
+    p.full = w / wps;
+    const int r = w - p.full * wps;
+    if (r == 0) return p;
+    const int max_tail1 = !sequential ? 0 : (k == 2 ? 1 : (k == 4 ? 2 : (k == 8 ? 3 : 0)));
+    const int t1 = (r + kWordsPerStrip - 1) / kWordsPerStrip;
+    if (t1 <= max_tail1) p.tail1 = t1;
+    else p.full += 1;
+    return p;
+}
+
+// Plan the strips of one rectangle: words [w0, w1) x n columns, r.k subwords per lane.
 void plan_rect(std::vector<StripJob>& jobs, const RectPlan& r) {
     const int w = r.w1 - r.w0;
     const int wps = kWordsPerStrip * r.k;
-    const int S = (w + wps - 1) / wps;
+    const StripPlan sp = strip_plan(w, r.k, r.pingpong);
+    const int S = sp.strips();
+    int word = 0;
     for (int s = 0; s < S; ++s) {
         StripJob j;
         std::memset(&j, 0, sizeof j);
+        const bool tall = s < sp.full;
+        j.k = tall ? r.k : 1;
         j.a_codes = r.a_codes;
         j.b_prof = r.b_prof;
         j.v = r.v;
         j.n = r.n;
         j.col0 = r.col0;
-        j.word0 = r.w0 + s * wps;
-        const int words = std::min(wps, w - s * wps);
+        j.word0 = r.w0 + word;
+        const int words = std::min(tall ? wps : kWordsPerStrip, w - word);
         j.nlanes = 2 * words;
         j.flags = r.v_init_one ? kJobVInitOne : 0;
         j.tail_rows = -1;
@@ -227,15 +248,15 @@ void plan_rect(std::vector<StripJob>& jobs, const RectPlan& r) {
         if (r.values) {
             j.values = r.values;
             j.fill_stride = r.fill_stride;
-            j.fill_word0 = r.fill_word0 + s * wps;
+            j.fill_word0 = r.fill_word0 + word;
         }
+        word += words;
         jobs.push_back(j);
     }
 }
 
 size_t rect_granules(int n, int w, int k, bool pingpong) {
-    const int wps = kWordsPerStrip * k;
-    const int S = (w + wps - 1) / wps;
+    const int S = strip_plan(w, k, pingpong).strips();
     const size_t G = (size_t)(n + 31) / 32;  // one 8-byte granule per 32 columns per strip boundary
     const int rows = pingpong ? std::min(S - 1, 2) : S - 1;
     return S > 1 ? (size_t)rows * G : 0;
@@ -311,6 +332,7 @@ bool launch_pairs(const StripJob* d_jobs, const int32_t* d_first, int npairs, ui
     if (k == 1) return launch_pairs_k<1>(d_jobs, d_first, npairs, d_ticket_err + 1, s, grid, lds);
     if (k == 2) return launch_pairs_k<2>(d_jobs, d_first, npairs, d_ticket_err + 1, s, grid, lds);
     if (k == 4) return launch_pairs_k<4>(d_jobs, d_first, npairs, d_ticket_err + 1, s, grid, lds);
+    if (k == 8) return launch_pairs_k<8>(d_jobs, d_first, npairs, d_ticket_err + 1, s, grid, lds);
     set_error("unsupported strip height k=%d", k);
     return false;
 }
@@ -642,32 +664,38 @@ struct BatchShape {
     int block_waves = 1;
 };
 static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, size_t pairs) {
-    static const double kLone[3] = {52.9, 76.5, 121.0}, kSatChain[3] = {50.8, 65.0, 112.5};
+    static const double kLone[4] = {52.9, 76.5, 121.0, 210.0}, kSatChain[3] = {50.8, 65.0, 112.5};
     static const double kShare[4] = {1.0, 0.85, 0.80, 0.78};  // per-wavefront step cost at 1, 2, 3, >= 4 wavefronts per SIMD
-    static const int kK[3] = {1, 2, 4};
+    static const int kK[4] = {1, 2, 4, 8};  // k = 8 is built for the sequential kernel only
     const double simds = (double)(g_device_props_cus > 0 ? g_device_props_cus : 256) * 4.0;
     int env_k = 0, env_mode = 0;
     if (const char* e = getenv("PA_STRIP_K")) {
         const int k = atoi(e);
-        if (k == 1 || k == 2 || k == 4) env_k = k;
+        if (k == 1 || k == 2 || k == 4 || k == 8) env_k = k;
     }
     if (const char* e = getenv("PA_BATCH_MODE")) env_mode = !strcmp(e, "seq") ? 2 : (!strcmp(e, "chain") ? 1 : 0);
     BatchShape best_shape;
     double best = -1;
-    for (int t = 0; t < 3; ++t) {
+    for (int t = 0; t < 4; ++t) {
         const int k = kK[t];
         if (env_k && k != env_k) continue;
-        double strips = 0, live = 0, colsteps = 0, longest = 0;  // colsteps = sum over strips of their columns
+        // colsteps = sum over strips of their columns; the sequential figures count a short tail strip as the fraction
+        // of a tall step it costs
+        double strips = 0, live = 0, colsteps = 0, seq_colsteps = 0, seq_longest = 0;
         for (size_t i = 0; i < pairs; ++i) {
             if (a_len[i] == 0 || b_len[i] == 0) continue;
-            const double S = (double)(((b_len[i] + 63) / 64 + (size_t)(kWordsPerStrip * k) - 1) / (size_t)(kWordsPerStrip * k));
+            const int w = (int)((b_len[i] + 63) / 64);
+            const double S = (double)strip_plan(w, k, false).strips();
+            const StripPlan sq = strip_plan(w, k, true);
+            const double Sq = (double)sq.full + (double)sq.tail1 * kLone[0] / kLone[t];
             strips += S;
             live += 1;
             colsteps += S * (double)a_len[i];
-            longest = std::max(longest, S * (double)a_len[i]);
+            seq_colsteps += Sq * (double)a_len[i];
+            seq_longest = std::max(seq_longest, Sq * (double)a_len[i]);
         }
         if (live == 0) return best_shape;
-        if (env_mode != 2) {  // chained strips
+        if (env_mode != 2 && k <= 4) {  // chained strips
             const double avg = strips / simds;
             const double per_col = avg <= 1.0 ? kLone[t] : (avg + 1.0) * kSatChain[t];
             const double cost = per_col * colsteps / strips;
@@ -682,7 +710,7 @@ static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, s
             const double W = std::max(1.0, std::ceil(live / simds));
             const double share = kShare[(int)std::min(W, 4.0) - 1];
             // W pairs share every busy SIMD for as long as the longest of them runs; huge batches stream and balance
-            const double cost = std::max(std::min(W, 7.0) * longest, colsteps / std::min(live, simds)) * kLone[t] * share;
+            const double cost = std::max(std::min(W, 7.0) * seq_longest, seq_colsteps / std::min(live, simds)) * kLone[t] * share;
             if (best < 0 || cost < best) {
                 best = cost;
                 best_shape.k = k;

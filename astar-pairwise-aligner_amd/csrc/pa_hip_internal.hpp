@@ -47,11 +47,18 @@ struct RectPlan {
     int tail_rows = -1;  // see StripJob::tail_rows
     uint32_t* values = nullptr;  // fill mode
     int fill_stride = 0, fill_word0 = 0;
-    bool pingpong = false;  // sequential-pairs mode: two granule rows per rectangle, strip s writes row s&1
+    bool pingpong = false;  // sequential-pairs mode: two granule rows per rectangle, strip s writes row s&1;
+                            // the ragged bottom is planned as short k = 1 strips (strip_plan)
     int k = 1;  // 32-row subwords per lane (1: lowest latency; 2, 4: fewer instructions per cell, cost-only strips)
 };
 
 void plan_rect(std::vector<StripJob>& jobs, const RectPlan& r);
+// Strips of a rectangle of w words: `full` strips of 32*k words, then `tail1` strips of up to 32 words (sequential mode only).
+struct StripPlan {
+    int full = 0, tail1 = 0;
+    int strips() const { return full + tail1; }
+};
+StripPlan strip_plan(int w, int k, bool sequential);
 size_t rect_granules(int n, int w, int k = 1, bool pingpong = false);
 bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_ticket_err, hipStream_t s, bool zero_ticket = true,
                    bool scatter = false, int k = 1, int block_waves = kStripBlockWaves);

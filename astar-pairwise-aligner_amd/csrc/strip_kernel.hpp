@@ -67,7 +67,7 @@ struct StripJob {
     int32_t tail_rows;        // >= 0: |b|; the reported sum additionally subtracts the right-edge deltas of rows >= |b|
                               //       (Block::index from the bottom, block.rs:110-120), so the host adds 64*words only
                               // < 0: plain sum of the bottom-row deltas
-    int32_t pad_;
+    int32_t k;                // pair_kernel only: subwords per lane of THIS strip (1 = short tail strip, else the kernel's K)
 };
 enum : int32_t { kJobVInitOne = 1 };
 static_assert(sizeof(StripJob) == 112, "StripJob layout");
@@ -459,7 +459,9 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void pair_kernel(const Strip
     const int j0 = first[p], j1 = first[p + 1];
     for (int j = j0; j < j1; ++j) {
         const StripJob job = jobs[j];
-        run_strip<K, false, false>(job, err);
+        // the ragged bottom of a pair runs as short 32-row-per-lane strips instead of one mostly empty tall one
+        if (K > 1 && job.k == 1) run_strip<1, false, false>(job, err);
+        else run_strip<K, false, false>(job, err);
         // the next strip reads what this one stored (granules, through the L2): drain and order the stores first
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     }

@@ -38,6 +38,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         return LIB_PATH
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-I", str(PKG_DIR.parent / "include"), "-o", str(LIB_PATH)] + [str(s) for s in sources()]
+    cmd += os.environ.get("PA_HIPCC_EXTRA", "").split()  # experiments only (e.g. -DPA_PHASE_BARRIERS)
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

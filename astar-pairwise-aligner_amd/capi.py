@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "astarpa2_simple", "astarpa2_full", "astarpa", "astarpa_gcsh", "astarpa_free_cigar",
     "pa_last_error", "pa_device_count", "pa_set_device",
     "pa_bp_profile_build", "pa_bp_compute", "pa_bp_fill", "pa_search",
-    "pa_batch_create", "pa_batch_run", "pa_batch_stats", "pa_batch_destroy",
+    "pa_batch_create", "pa_batch_run", "pa_batch_stats", "pa_batch_shape", "pa_batch_destroy",
     "pa_align",
 ]
 
@@ -60,6 +60,7 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_batch_run.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.pa_batch_run.restype = C.c_int
     L.pa_batch_stats.argtypes = [vp] + [C.POINTER(C.c_double)] * 4
+    L.pa_batch_shape.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.pa_batch_destroy.argtypes = [vp]
     for name in ("astarpa2_simple", "astarpa2_full", "astarpa"):
         if hasattr(L, name):
@@ -163,6 +164,13 @@ class Batch:
         vals = [C.c_double(0) for _ in range(4)]
         load().pa_batch_stats(self._h, *[C.byref(v) for v in vals])
         return dict(zip(("cells", "word_updates", "strips", "algo_bytes"), (v.value for v in vals)))
+
+    def shape(self) -> dict:
+        """How the batch was laid out: strip height k, chained strips or one wavefront per pair, VALU instructions per pass."""
+        k, seq, vi = C.c_int(0), C.c_int(0), C.c_double(0)
+        load().pa_batch_shape(self._h, C.byref(k), C.byref(seq), C.byref(vi))
+        return {"k": k.value, "sequential": bool(seq.value), "valu_instructions": vi.value,
+                "kernel": f"pa::pair_kernel<{k.value}>" if seq.value else f"pa::strip_kernel<{k.value}, false, false>"}
 
     def close(self):
         if self._h:

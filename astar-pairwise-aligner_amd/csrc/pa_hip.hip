@@ -890,4 +890,17 @@ extern "C" void pa_batch_stats(const pa_batch* p, double* cells, double* word_up
     if (algo_bytes) *algo_bytes = p->algo_bytes;
 }
 
+extern "C" void pa_batch_shape(const pa_batch* p, int* k, int* sequential, double* valu_instructions) {
+    if (k) *k = p->k;
+    if (sequential) *sequential = p->sequential ? 1 : 0;
+    if (valu_instructions) {
+        double t = 0;
+        for (const StripJob& j : p->jobs) {
+            const int kj = p->sequential ? j.k : p->k;
+            t += 32.0 * (double)((j.n + 31) / 32 + 2) * (11.0 + 12.0 * kj);  // run_strip: (C + 2) chunks of 32 steps
+        }
+        *valu_instructions = t;
+    }
+}
+
 extern "C" void pa_batch_destroy(pa_batch* p) { delete p; }

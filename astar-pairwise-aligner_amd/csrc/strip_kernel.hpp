@@ -37,6 +37,15 @@ extern __device__ unsigned int* g_pa_dbg;
 #define PA_DBG(slot, value) do { } while (0)
 #endif
 
+// Scheduling fence between the phases of a tall (K >= 8) Myers step.  Runs of "simple" VALU ops (VOP2 logic/add,
+// 3-VGPR v_bitop3) issue at about twice the rate of ops with carries, SGPR operands, DPP or v_alignbit/v_bfe, but only
+// when they are not interleaved with those (profiles/r01_runs/issue_probe3.log); keeping the phases apart is worth ~5 %
+// at K = 8 and nothing or less below.
+#define PA_PHASE()                                        \
+    do {                                                  \
+        if (K >= 8) __builtin_amdgcn_sched_barrier(0);    \
+    } while (0)
+
 namespace pa {
 
 // One strip job = one wavefront.  All pointers are device pointers.
@@ -126,11 +135,12 @@ __device__ __forceinline__ void myers_step(uint32_t s_x, uint32_t& X, uint32_t (
             const uint32_t e23 = __builtin_amdgcn_bitop3_b32(a0, nb3[k], nb2[k], 0xCA);
             eq[k] = __builtin_amdgcn_bitop3_b32(a1, e23, e01, 0xCA);
         } else {
-            eq[k] = (a0 ^ nb0[k]) & (a1 ^ nb1[k]);
+            eq[k] = __builtin_amdgcn_bitop3_b32(a0, nb0[k], a1 ^ nb1[k], 0x28);  // (a0 ^ nb0) & (a1 ^ nb1) in two ops
         }
         vx[k] = eq[k] | vm[k];
     }
     eq[0] |= hm0;
+    PA_PHASE();
     // (eq & vp) + vp over the whole 32K-bit word
     if (K == 1) {
         sm[0] = (eq[0] & vp[0]) + vp[0];
@@ -143,12 +153,14 @@ __device__ __forceinline__ void myers_step(uint32_t s_x, uint32_t& X, uint32_t (
             carry = co;
         }
     }
+    PA_PHASE();
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const uint32_t hx = (sm[k] ^ vp[k]) | eq[k];
         hp[k] = vm[k] | ~(hx | vp[k]);
         hm[k] = vp[k] & hx;
     }
+    PA_PHASE();
     // two bit-field inserts (v_bitop3 each); bits 29:2 of X are always 0, so keeping Xin's other bits is exact.
     // k40 / k80 are opaque to the optimizer on purpose, otherwise it re-expands this into 5 ops.
     const uint32_t xm = __builtin_amdgcn_bitop3_b32(k40, hm[K - 1] >> 1, Xin, 0xCA);  // k40 ? (hm >> 1) : Xin

@@ -5,10 +5,10 @@ Metric (BASELINE.json): DP cell-updates/sec (GCUPS) + pairs/sec on 100 kbp x 100
 divergence, full bit-parallel DP, cost only (configs[1], "C2").
 
 A *step* is one pass of the hot path over one batch of synthetic pairs that is already resident in HBM
-as ASCII: BitProfile build kernels -> clear hand-off granules -> the persistent strip kernel (every
-64-lane strip of every pair) -> read the edit distances back.  `--pairs P` sets the batch per GPU
-(default fills the chip with independent 100 kbp pairs; P=1 is the literal single-pair C2 case, which
-is latency bound on ~49 wavefronts and is reported next to the batch number as `single_pair`).
+as ASCII: BitProfile build kernels -> clear hand-off granules -> the strip kernel (every 64-lane strip
+of every pair) -> read the edit distances back.  `--pairs P` sets the batch per GPU (default 2048 =
+two pairs per SIMD, where one wavefront runs a whole pair; P=1 is the literal single-pair C2 case, which
+is latency bound on ~49 chained wavefronts and is reported next to the batch number as `single_pair`).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -31,8 +31,10 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # CUs x SIMDs x lanes/clk x max clock: 32-bit integer VALU lane-ops/s
-U32_OPS_PER_WORD_UPDATE = 46  # 23 u64 logic/add/shift ops per 64-row word update = 46 32-bit ops
+# The kernel's real bound is VALU issue: 256 CUs x 4 SIMDs x 2.4 GHz, one wave64 instruction per 2 clocks at best.
+# Measured issue rates per opcode class and for mixed streams: profiles/r01_runs/issue_probe*.log.
+VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2
+VALU_MIXED_CEILING = 256 * 4 / 1.6e-9
 
 
 def parse_args():
@@ -40,7 +42,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=146, help="independent pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=2048, help="independent pairs per GPU per step")
     ap.add_argument("--n", type=int, default=100_000, help="sequence length (bp)")
     ap.add_argument("--div", type=float, default=0.05, help="divergence (edit rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -83,6 +85,7 @@ def main():
     pairs = [generate_pair(args.n, args.div, seed=rank * args.pairs + i + 1) for i in range(args.pairs)]
     batch = pa.Batch(pairs)
     st = batch.stats()
+    shape = batch.shape()
 
     for _ in range(args.warmup):
         costs, _ = batch.run()
@@ -136,6 +139,7 @@ def main():
             "seq_len": args.n,
             "divergence": args.div,
             "strips_per_gpu": int(st["strips"]),
+            "word_updates_per_gpu": st["word_updates"],
             "cost_checksum": checksum,
         },
         "roofline": {
@@ -145,17 +149,25 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved_gbs / HBM_PEAK_GBS, 8),
             "traffic": None,
-            "kernel": "pa::strip_kernel<false>",
+            "kernel": shape["kernel"],
             "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
             "algorithmic_bytes_per_launch": st["algo_bytes"],
             "note": "integer-VALU-issue bound by design (0.75 B/column + 48 B/word); see valu_roofline",
         },
         "valu_roofline": {
-            "achieved": round(U32_OPS_PER_WORD_UPDATE * st["word_updates"] / avg_kernel_s / 1e12, 4),
-            "peak": round(VALU_PEAK_LANE_OPS / 1e12, 2),
-            "unit": "T u32-lane-ops/s",
-            "frac": round(U32_OPS_PER_WORD_UPDATE * st["word_updates"] / avg_kernel_s / VALU_PEAK_LANE_OPS, 5),
+            "achieved": round(shape["valu_instructions"] / avg_kernel_s / 1e9, 2),
+            "peak": round(VALU_PEAK_WAVE_INSTR / 1e9, 1),
+            "unit": "G wave64 VALU instructions/s",
+            "frac": round(shape["valu_instructions"] / avg_kernel_s / VALU_PEAK_WAVE_INSTR, 4),
+            "mixed_stream_ceiling": VALU_MIXED_CEILING / 1e9,
+            "frac_of_mixed_stream_ceiling": round(shape["valu_instructions"] / avg_kernel_s / VALU_MIXED_CEILING, 4),
+            "instructions_per_2048_cells": round(shape["valu_instructions"] / (st["cells"] / 2048.0), 2),
+            "note": "(11 + 12k) VALU instructions per 64-lane x 32k-row strip step (ISA count, PMC SQ_INSTS_VALU agrees). "
+                    "peak = 1 instruction / 2 clk / SIMD, reached only by unbroken runs of simple VOP2 / 3-VGPR v_bitop3 ops; "
+                    "mixed_stream_ceiling = what tools/issue_probe measures for streams that mix those with carry, v_alignbit, "
+                    "v_bfe, DPP or SGPR-operand ops (1.6 ns per instruction per SIMD), which every Myers step must",
         },
+        "batch_shape": {"k": shape["k"], "sequential": shape["sequential"]},
     }
 
     # ---- the literal single-pair C2 case (latency bound) ----
@@ -206,9 +218,12 @@ def main():
     if pmc.exists():
         try:
             pj = json.loads(pmc.read_text())
-            out["roofline"]["traffic"] = round(pj["hbm_bytes_per_strip"] * st["strips"], 1)
-            out["roofline"]["traffic_note"] = ("FETCH_SIZE+WRITE_SIZE (KiB*1024) per strip wave from profiles/pmc_latest.json x strips; "
-                                                "dominated by the 8-byte sc1 hand-off granules, each moving a 32-64 B sector")
+            same = pj.get("batch_shape") == out["batch_shape"]
+            out["roofline"]["traffic"] = round(pj["hbm_bytes_per_word_update"] * st["word_updates"], 1) if same else None
+            out["roofline"]["traffic_note"] = ("FETCH_SIZE+WRITE_SIZE (KiB*1024) per 64-cell word update of the same batch shape from "
+                                                "profiles/pmc_latest.json (separate rocprofv3 --pmc passes) x word updates of this launch; "
+                                                "dominated by the 8-byte hand-off granules, each moving a 32-64 B sector"
+                                                if same else "profiles/pmc_latest.json was collected for another batch shape")
         except Exception as e:  # a malformed summary must not break the bench line
             out["roofline"]["traffic_note"] = f"pmc summary unreadable: {e}"
 

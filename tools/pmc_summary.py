@@ -1,7 +1,7 @@
-"""Summarise the rocprofv3 passes of tools/pmc_run.sh for pa::strip_kernel into one JSON (per-launch averages).
-FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; on gfx950 FETCH_SIZE under-counts wide coalesced reads by 2x
-(MI355X_MICROARCH.md, HBM section) -- our reads are 8-byte granule polls and 4-byte words, not wide streams, so the raw
-value is kept and the caveat recorded."""
+"""Summarise the rocprofv3 passes of tools/pmc_run.sh for the dominant DP kernel (pa::pair_kernel<k> or pa::strip_kernel<k,..>)
+into one JSON (per-launch averages).  FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3; on gfx950 FETCH_SIZE
+under-counts wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section) -- our reads are 8-byte granules and 4-byte
+words, not wide streams, so the raw value is kept and the caveat recorded."""
 import collections
 import csv
 import glob
@@ -9,26 +9,42 @@ import json
 import sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
-out = {"kernel": "pa::strip_kernel<false>", "counters": {}}
+out = {"counters": {}}
+
+
+def is_dp(name):
+    return "strip_kernel" in name or "pair_kernel" in name
+
+
+for f in glob.glob(f"{root}/trace/*kernel_stats.csv"):
+    best = None
+    for r in csv.DictReader(open(f)):
+        if is_dp(r["Name"]) and (best is None or float(r["TotalDurationNs"]) > float(best["TotalDurationNs"])):
+            best = r
+    if best:
+        out["kernel"] = best["Name"]
+        out["kernel_trace"] = {"calls": int(best["Calls"]), "avg_ns": float(best["AverageNs"]), "min_ns": float(best["MinNs"]),
+                               "max_ns": float(best["MaxNs"]), "percent_of_gpu_time": float(best["Percentage"])}
 for f in sorted(glob.glob(f"{root}/*/*counter_collection.csv")):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "strip_kernel" in r["Kernel_Name"]:
+        if is_dp(r["Kernel_Name"]) and ("kernel" not in out or r["Kernel_Name"] == out["kernel"]):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            out["grid"] = int(r["Grid_Size"])
+            out["grid_threads"] = int(r["Grid_Size"])
     for k, v in agg.items():
         out["counters"][k] = {"avg_per_launch": sum(v) / len(v), "launches": len(v)}
-for f in glob.glob(f"{root}/trace/*kernel_stats.csv"):
-    for r in csv.DictReader(open(f)):
-        if "strip_kernel" in r["Name"]:
-            out["kernel_trace"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"])}
+# the bench line of the same command (word updates of one launch, batch shape)
+for f in glob.glob(f"{root}/*.log"):
+    for line in open(f, errors="ignore"):
+        if line.startswith("{") and '"metric"' in line:
+            j = json.loads(line)
+            out["word_updates_per_launch"] = j["config"].get("word_updates_per_gpu")
+            out["batch_shape"] = j.get("batch_shape")
+            out["bench_kernel_ms_avg"] = j["roofline"]["kernel_ms_avg"]
 c = out["counters"]
 if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     out["hbm_bytes_per_launch"] = (c["FETCH_SIZE"]["avg_per_launch"] + c["WRITE_SIZE"]["avg_per_launch"]) * 1024
-    out["waves_per_launch"] = out.get("grid", 0) // 64
-    out["hbm_bytes_per_strip"] = out["hbm_bytes_per_launch"] / max(out["waves_per_launch"], 1)
-if "SQ_INSTS_VALU" in c and "SQ_WAVE_CYCLES" in c:
-    # SQ_WAVE_CYCLES counts quad-cycles (MI355X_MICROARCH.md); a wave64 integer VALU op occupies its SIMD for 4 cycles
-    out["valu_busy_frac_est"] = c["SQ_INSTS_VALU"]["avg_per_launch"] * 4 / (c["SQ_WAVE_CYCLES"]["avg_per_launch"] * 4 / max(out.get("grid", 64) // 64, 1) * 1024) if False else None
+    if out.get("word_updates_per_launch"):
+        out["hbm_bytes_per_word_update"] = out["hbm_bytes_per_launch"] / out["word_updates_per_launch"]
 json.dump(out, open(f"{root}/summary.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

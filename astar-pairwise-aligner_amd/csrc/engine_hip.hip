@@ -30,6 +30,13 @@ struct HipBackend {
     // pinned staging
     void* h_stage = nullptr;
     size_t h_stage_size = 0;
+    // host-mapped mailbox of the per-block fast path: [done, err, sum, pad.. | v words]
+    uint8_t* mbox = nullptr;      // host address
+    uint8_t* mbox_dev = nullptr;  // the same memory as the GPU sees it
+    size_t mbox_size = 0;
+    uint32_t seq = 0;
+    DeviceBuf d_counter;
+    size_t gran_zeroed = 0;  // granules of d_gran known to be zero (the strips hand every granule back zeroed)
 
     HipBackend(const uint8_t* a, size_t n, const uint8_t* b, size_t m) : a_(a, a + n), b_(b, b + m) {
         if (!ensure_device()) { err = PA_E_HIP; return; }
@@ -56,6 +63,7 @@ struct HipBackend {
         ok = true;
     }
     ~HipBackend() {
+        if (mbox) (void)hipHostFree(mbox);
         if (h_stage) (void)hipHostFree(h_stage);
         if (s) (void)hipStreamDestroy(s);
     }
@@ -88,6 +96,89 @@ struct HipBackend {
         return h_stage;
     }
 
+    static constexpr size_t kMboxV = 64;  // offset of the v words inside the mailbox
+
+    void ensure_mailbox(size_t words) {
+        const size_t need = kMboxV + words * 16;
+        if (need <= mbox_size) return;
+        if (mbox) (void)hipHostFree(mbox);
+        mbox = nullptr;
+        const size_t want = std::max<size_t>(need * 2, 1 << 16);
+        void* hp = nullptr;
+        void* dp = nullptr;
+        if (!hip_ok(hipHostMalloc(&hp, want, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc(mailbox)") ||
+            !hip_ok(hipHostGetDevicePointer(&dp, hp, 0), "hipHostGetDevicePointer"))
+            fail(PA_E_HIP);
+        mbox = (uint8_t*)hp;
+        mbox_dev = (uint8_t*)dp;
+        mbox_size = want;
+        std::memset(mbox, 0, kMboxV);
+        if (!d_counter.ptr && (!d_counter.alloc(64) || !hip_ok(hipMemsetAsync(d_counter.ptr, 0, 64, s), "memset counter"))) fail(PA_E_HIP);
+    }
+
+    void ensure_granules(size_t ngran) {
+        if (ngran <= gran_zeroed) return;
+        const size_t want = std::max<size_t>(ngran * 2, 512);
+        if (!d_gran.alloc(want * 8) || !hip_ok(hipMemsetAsync(d_gran.ptr, 0, want * 8, s), "memset gran")) fail(PA_E_HIP);
+        gran_zeroed = want;
+    }
+
+    // Fast path of one cost-only rectangle: the strips are described by kernel arguments, `v` / sum / err / done live in
+    // the host-mapped mailbox, the host spins on `done`.  One API call (the launch) per block.
+    Cost launch_rect_fast(I i0, I i1, size_t w0, size_t w1, V* v, const uint8_t* hin, uint8_t* hout, bool exact) {
+        const int n = i1 - i0;
+        const size_t w = w1 - w0;
+        const size_t S = (w + kWordsPerStrip - 1) / kWordsPerStrip;
+        const size_t G = (size_t)(n + 31) / 32;
+        ensure_mailbox(w);
+        ensure_granules(S > 1 ? (S - 1) * G : 0);
+        volatile uint32_t* mb = reinterpret_cast<volatile uint32_t*>(mbox);
+        std::memcpy(mbox + kMboxV, v, w * 16);
+        mb[1] = 0;  // err
+        mb[2] = 0;  // sum
+        ++seq;
+        RectArgs r;
+        r.a_codes = d_codes.as<uint32_t>();
+        r.b_prof = d_prof.as<uint32_t>();
+        r.v = reinterpret_cast<uint32_t*>(mbox_dev + kMboxV) - w0 * 4;
+        r.hin_arr = hin;
+        r.hout_arr = hout;
+        r.gran = d_gran.as<uint64_t>();
+        r.gran_stride = G;
+        r.sum_out = reinterpret_cast<int32_t*>(mbox_dev) + 2;
+        r.err = reinterpret_cast<uint32_t*>(mbox_dev) + 1;
+        r.done = reinterpret_cast<uint32_t*>(mbox_dev);
+        r.counter = d_counter.as<uint32_t>();
+        r.n = n;
+        r.col0 = i0;
+        r.w0 = (int)w0;
+        r.w1 = (int)w1;
+        r.exact_end = exact ? 1 : 0;
+        r.seq = seq;
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        hipLaunchKernelGGL((rect_kernel<1>), dim3((unsigned)S), dim3(64), 0, s, r);
+        if (!hip_ok(hipGetLastError(), "rect_kernel launch")) fail(PA_E_HIP);
+        // spin on the completion word; the kernel's own spins are bounded, so this ends
+        uint64_t spins = 0;
+        while (__atomic_load_n(reinterpret_cast<uint32_t*>(mbox), __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 0xFFFFF) == 0 && hipStreamQuery(s) != hipErrorNotReady) {
+                // the stream drained (or failed) without the flag: take the slow, certain route
+                if (!hip_ok(hipStreamSynchronize(s), "sync")) fail(PA_E_HIP);
+                if (__atomic_load_n(reinterpret_cast<uint32_t*>(mbox), __ATOMIC_ACQUIRE) != seq) {
+                    set_error("rect_kernel finished without signalling completion");
+                    fail(PA_E_INTERNAL);
+                }
+            }
+        }
+        if (mb[1] != PA_ERR_NONE) {
+            set_error("device spin timeout (err=%u)", (unsigned)mb[1]);
+            gran_zeroed = 0;  // the hand-off buffer may be dirty
+            fail(PA_E_TIMEOUT);
+        }
+        std::memcpy(v, mbox + kMboxV, w * 16);
+        return (Cost)(int32_t)mb[2];
+    }
+
     // One rectangle launch.  hin/hout are device byte rows indexed by absolute column (or nullptr).
     // Per call: ONE H2D of a pinned staging image [ticket,err,sum,pad | v words | jobs] into `d_call`, an optional
     // granule clear (only when the rectangle spans several strips), the launch, ONE D2H of [misc | v], one sync.
@@ -96,9 +187,11 @@ struct HipBackend {
         const int n = i1 - i0;
         const size_t w = w1 - w0;
         const bool fill = values_host != nullptr;
+        static const bool no_fast = getenv("PA_ENGINE_NO_FAST_PATH") != nullptr;
+        if (!fill && !no_fast && (w + kWordsPerStrip - 1) / kWordsPerStrip <= 1024) return launch_rect_fast(i0, i1, w0, w1, v, hin, hout, exact);
         const size_t ngran = rect_granules(n, (int)w);
         const size_t G = (size_t)(n + 31) / 32;
-        if (d_gran.size < ngran * 8 && !d_gran.alloc(std::max<size_t>(ngran * 8 * 2, 4096))) fail(PA_E_HIP);
+        ensure_granules(ngran);
         if (fill && d_values.size < (size_t)n * w * 16 && !d_values.alloc((size_t)n * w * 16 * 2)) fail(PA_E_HIP);
         const size_t S = (w + kWordsPerStrip - 1) / kWordsPerStrip;
         const size_t off_v = 64, off_jobs = off_v + ((w * 16 + 63) & ~size_t(63));
@@ -134,7 +227,6 @@ struct HipBackend {
         std::memcpy(st + off_v, v, w * 16);
         std::memcpy(st + off_jobs, jobs.data(), jobs.size() * sizeof(StripJob));
         bool good = hip_ok(hipMemcpyAsync(dev, st, total, hipMemcpyHostToDevice, s), "H2D call image") &&
-                    (ngran == 0 || hip_ok(hipMemsetAsync(d_gran.ptr, 0, ngran * 8, s), "memset gran")) &&
                     launch_strips(reinterpret_cast<const StripJob*>(dev + off_jobs), (int)jobs.size(), fill,
                                   reinterpret_cast<uint32_t*>(dev), s, /*zero_ticket=*/false) &&
                     hip_ok(hipMemcpyAsync(st, dev, off_v + w * 16, hipMemcpyDeviceToHost, s), "D2H misc+v");

@@ -636,6 +636,7 @@ struct pa_batch {
     std::vector<StripJob> jobs;
     std::vector<int> last_job;  // per pair (or -1 when w == 0)
     size_t total_gran = 0;
+    bool gran_dirty = true;  // the hand-off granules must be cleared before the next pass
     int k = 1;  // 32-row subwords per lane of this batch's strips
     bool sequential = false;  // one wavefront per pair (pair_kernel) instead of chained strips
     int block_waves = 1;
@@ -843,7 +844,10 @@ extern "C" int pa_batch_run(pa_batch* p, int32_t* cost_out, float* kernel_ms) {
         if (!hip_ok(hipGetLastError(), "profile kernels")) return PA_E_HIP;
     }
     // (2) clear hand-off granules, (3) strips
-    if (p->total_gran && !hip_ok(hipMemsetAsync(p->d_gran.ptr, 0, p->total_gran * 8, s), "memset gran")) return PA_E_HIP;
+    // every strip hands the granules it consumed back zeroed, so the buffer is cleared only before the first pass (and
+    // after a pass that did not finish)
+    if (p->total_gran && p->gran_dirty && !hip_ok(hipMemsetAsync(p->d_gran.ptr, 0, p->total_gran * 8, s), "memset gran")) return PA_E_HIP;
+    p->gran_dirty = true;
     if (!hip_ok(hipMemsetAsync(p->d_sums.ptr, 0, std::max<size_t>(p->pairs * 4, 16), s), "memset sums")) return PA_E_HIP;
     // d_misc (ticket, err, -, bad-base flag) was zeroed above; the events bracket the strip kernel alone
     if (!hip_ok(hipEventRecord(p->ev0, s), "event")) return PA_E_HIP;
@@ -868,6 +872,7 @@ extern "C" int pa_batch_run(pa_batch* p, int32_t* cost_out, float* kernel_ms) {
         set_error("device spin timeout (err=%u)", misc[1]);
         return PA_E_TIMEOUT;
     }
+    p->gran_dirty = false;  // clean finish
     if (kernel_ms) {
         *kernel_ms = 0.f;
         if (!p->jobs.empty() && !hip_ok(hipEventElapsedTime(kernel_ms, p->ev0, p->ev1), "elapsed")) return PA_E_HIP;

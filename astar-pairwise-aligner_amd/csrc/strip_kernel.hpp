@@ -381,6 +381,8 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
             uint32_t glo, ghi;
             alive = resolve_granule(g_gran, gran_next, q, glo, ghi);
             hin2 = ((upper ? ghi : glo) << sh) & 0xC0000000u;
+            // every granule has exactly one consumer: hand it back zeroed, so the buffer needs clearing only once
+            if (lane == 0) __hip_atomic_store((gu64)job.hin_gran + q, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const uint32_t XS = code | hin2;
         // ---- publish the granule completed by the previous chunk (q-1) ----
@@ -456,6 +458,64 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void strip_kernel(const Stri
         run_strip<K, FILL, SCATTER>(job, err);
     }
     PA_DBG(0, 0x1000 + t);
+}
+
+// One rectangle of the A*PA2 block engine per launch, described entirely by kernel arguments (no descriptor upload):
+// block s of the grid is strip s (all strips of one rectangle are resident together, so no ticket is needed).  `v`, the
+// sum, the error word and the completion word live in host-mapped memory: the engine's host thread spins on `done`
+// instead of paying a stream synchronisation per 256-column block.
+struct RectArgs {
+    const uint32_t* a_codes;
+    const uint32_t* b_prof;
+    uint32_t* v;            // biased so that it is indexed by absolute word (host-mapped)
+    const uint8_t* hin_arr;
+    uint8_t* hout_arr;
+    uint64_t* gran;         // (S-1) rows of gran_stride granules, all zero between launches
+    uint64_t gran_stride;
+    int32_t* sum_out;       // host-mapped
+    uint32_t* err;          // host-mapped
+    uint32_t* done;         // host-mapped: receives `seq` when every strip has finished
+    uint32_t* counter;      // device: strips finished so far, left at zero
+    int32_t n, col0, w0, w1, exact_end;
+    uint32_t seq;
+};
+
+template <int K>
+__global__ __launch_bounds__(64) void rect_kernel(RectArgs r) {
+    const int s = (int)blockIdx.x, S = (int)gridDim.x;
+    const int lane = (int)(threadIdx.x & 63);
+    constexpr int wps = 32 * K;
+    StripJob j;
+    j.a_codes = r.a_codes;
+    j.b_prof = r.b_prof;
+    j.v = r.v;
+    j.hin_gran = s > 0 ? r.gran + (size_t)(s - 1) * r.gran_stride : nullptr;
+    j.hin_arr = s == 0 ? r.hin_arr : nullptr;
+    j.hout_gran = s + 1 < S ? r.gran + (size_t)s * r.gran_stride : nullptr;
+    j.hout_arr = s + 1 < S ? nullptr : r.hout_arr;
+    j.values = nullptr;
+    j.sum_out = s + 1 < S ? nullptr : r.sum_out;
+    j.n = r.n;
+    j.word0 = r.w0 + s * wps;
+    const int words = (r.w1 - j.word0) < wps ? (r.w1 - j.word0) : wps;
+    j.nlanes = 2 * words;
+    j.fill_stride = 0;
+    j.fill_word0 = 0;
+    j.exact_tail = s + 1 < S ? 1 : ((r.exact_end || r.hout_arr) ? 1 : 0);
+    j.flags = 0;
+    j.col0 = r.col0;
+    j.tail_rows = -1;
+    j.k = K;
+    run_strip<K, false, false>(j, r.err);
+    // completion: results first (system scope: v and the sum are in host memory), then the count, then the flag
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    uint32_t c = 0;
+    if (lane == 0) c = __hip_atomic_fetch_add(r.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    c = rfl(c);
+    if (c == (uint32_t)(S - 1) && lane == 0) {
+        __hip_atomic_store(r.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(r.done, r.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Sequential-pairs variant: one wavefront runs ALL strips of one rectangle top to bottom (jobs[first[p]] ..

@@ -19,6 +19,7 @@ EXPORTED_SYMBOLS = [
     "pa_last_error", "pa_device_count", "pa_set_device",
     "pa_bp_profile_build", "pa_bp_compute", "pa_bp_fill", "pa_search",
     "pa_batch_create", "pa_batch_run", "pa_batch_stats", "pa_batch_shape", "pa_batch_destroy",
+    "pa_batch_create_trace", "pa_batch_align", "pa_batch_trace_fallbacks", "pa_params_batch_align",
     "pa_align",
 ]
 
@@ -62,6 +63,12 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_batch_stats.argtypes = [vp] + [C.POINTER(C.c_double)] * 4
     L.pa_batch_shape.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.pa_batch_destroy.argtypes = [vp]
+    L.pa_batch_create_trace.argtypes = [vp, vp, vp, vp, sz]
+    L.pa_batch_create_trace.restype = vp
+    L.pa_batch_align.argtypes = [vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.pa_batch_align.restype = C.c_int
+    L.pa_batch_trace_fallbacks.argtypes = [vp]
+    L.pa_batch_trace_fallbacks.restype = C.c_size_t
     for name in ("astarpa2_simple", "astarpa2_full", "astarpa"):
         if hasattr(L, name):
             f = getattr(L, name)
@@ -135,15 +142,16 @@ def search(pattern: bytes, text: bytes, unmatched_cost: float) -> list[int]:
 class Batch:
     """Device-resident batch of independent pairs; run() = full-DP edit distance of every pair."""
 
-    def __init__(self, pairs: list[tuple[bytes, bytes]]):
+    def __init__(self, pairs: list[tuple[bytes, bytes]], trace: bool = False):
         L = load()
         self._keep = pairs
+        self.trace = trace
         n = len(pairs)
         ap = (C.c_void_p * n)(*[C.cast(C.c_char_p(a), C.c_void_p) for a, _ in pairs])
         bp = (C.c_void_p * n)(*[C.cast(C.c_char_p(b), C.c_void_p) for _, b in pairs])
         al = (C.c_size_t * n)(*[len(a) for a, _ in pairs])
         bl = (C.c_size_t * n)(*[len(b) for _, b in pairs])
-        self._h = L.pa_batch_create(ap, al, bp, bl, n)
+        self._h = (L.pa_batch_create_trace if trace else L.pa_batch_create)(ap, al, bp, bl, n)
         if not self._h:
             raise PaError(last_error())
         self.pairs = n
@@ -159,6 +167,28 @@ class Batch:
         if rc != 0:
             raise PaError(f"pa_batch_run rc={rc}: {last_error()}")
         return out, float(ms.value)
+
+    def align(self):
+        """-> (costs int32[pairs], CIGAR strings, forward-kernel ms, traceback-kernel ms); needs trace=True."""
+        L = load()
+        out = np.zeros(self.pairs, np.int32)
+        cig = (C.c_void_p * max(self.pairs, 1))()
+        fms, tms = C.c_float(0), C.c_float(0)
+        rc = L.pa_batch_align(self._h, _p(out), cig, C.byref(fms), C.byref(tms))
+        try:
+            if rc == -1:
+                raise ValueError("sequence contains a character outside ACGT")
+            if rc != 0:
+                raise PaError(f"pa_batch_align rc={rc}: {last_error()}")
+            cigars = [C.string_at(cig[i]).decode() if cig[i] else "" for i in range(self.pairs)]
+        finally:
+            for i in range(self.pairs):
+                if cig[i]:
+                    L.astarpa_free_cigar(C.c_void_p(cig[i]))
+        return out, cigars, float(fms.value), float(tms.value)
+
+    def trace_fallbacks(self) -> int:
+        return int(load().pa_batch_trace_fallbacks(self._h))
 
     def stats(self) -> dict:
         vals = [C.c_double(0) for _ in range(4)]

@@ -1,6 +1,8 @@
 // pa_hip.hip -- host side of libastarpa_c_hip.so: device buffers, strip planning, the operator
 // C ABI (include/pa_bitpacking_hip.h) and the batched full-DP plan.  gfx950 only.
 #include "pa_hip_internal.hpp"
+#include "engine_capi.hpp"
+#include "trace_kernel.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -141,6 +143,10 @@ template __global__ void pair_kernel<1>(const StripJob*, const int32_t*, int, ui
 template __global__ void pair_kernel<2>(const StripJob*, const int32_t*, int, uint32_t*);
 template __global__ void pair_kernel<4>(const StripJob*, const int32_t*, int, uint32_t*);
 template __global__ void pair_kernel<8>(const StripJob*, const int32_t*, int, uint32_t*);
+template __global__ void pair_kernel<1, true>(const StripJob*, const int32_t*, int, uint32_t*);
+template __global__ void pair_kernel<2, true>(const StripJob*, const int32_t*, int, uint32_t*);
+template __global__ void pair_kernel<4, true>(const StripJob*, const int32_t*, int, uint32_t*);
+template __global__ void pair_kernel<8, true>(const StripJob*, const int32_t*, int, uint32_t*);
 
 // ---- device context -----------------------------------------------------------------------------
 
@@ -250,6 +256,8 @@ void plan_rect(std::vector<StripJob>& jobs, const RectPlan& r) {
             j.fill_stride = r.fill_stride;
             j.fill_word0 = r.fill_word0 + word;
         }
+        j.ckpt = r.ckpt;
+        j.ckpt_stride = r.ckpt_stride;
         word += words;
         jobs.push_back(j);
     }
@@ -312,29 +320,47 @@ bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_tic
     return false;
 }
 
-template <int K>
+template <int K, bool CKPT>
 static bool launch_pairs_k(const StripJob* d_jobs, const int32_t* d_first, int npairs, uint32_t* d_err, hipStream_t s, int grid, unsigned lds) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (!hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+        if (!hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_kernel<K, CKPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
                     "hipFuncSetAttribute(max dynamic LDS)"))
             return false;
         attr_set = true;
     }
-    hipLaunchKernelGGL((pair_kernel<K>), dim3(grid), dim3(64 * kStripBlockWaves), lds, s, d_jobs, d_first, npairs, d_err);
+    hipLaunchKernelGGL((pair_kernel<K, CKPT>), dim3(grid), dim3(64 * kStripBlockWaves), lds, s, d_jobs, d_first, npairs, d_err);
     return hip_ok(hipGetLastError(), "pair_kernel launch");
 }
 
-bool launch_pairs(const StripJob* d_jobs, const int32_t* d_first, int npairs, uint32_t* d_ticket_err, hipStream_t s, int k) {
+bool launch_pairs(const StripJob* d_jobs, const int32_t* d_first, int npairs, uint32_t* d_ticket_err, hipStream_t s, int k, bool ckpt) {
     if (npairs == 0) return true;
     const int grid = (npairs + kStripBlockWaves - 1) / kStripBlockWaves;
     const unsigned lds = residency_lds_bytes(grid);
-    if (k == 1) return launch_pairs_k<1>(d_jobs, d_first, npairs, d_ticket_err + 1, s, grid, lds);
-    if (k == 2) return launch_pairs_k<2>(d_jobs, d_first, npairs, d_ticket_err + 1, s, grid, lds);
-    if (k == 4) return launch_pairs_k<4>(d_jobs, d_first, npairs, d_ticket_err + 1, s, grid, lds);
-    if (k == 8) return launch_pairs_k<8>(d_jobs, d_first, npairs, d_ticket_err + 1, s, grid, lds);
+    uint32_t* e = d_ticket_err + 1;
+    if (!ckpt) {
+        if (k == 1) return launch_pairs_k<1, false>(d_jobs, d_first, npairs, e, s, grid, lds);
+        if (k == 2) return launch_pairs_k<2, false>(d_jobs, d_first, npairs, e, s, grid, lds);
+        if (k == 4) return launch_pairs_k<4, false>(d_jobs, d_first, npairs, e, s, grid, lds);
+        if (k == 8) return launch_pairs_k<8, false>(d_jobs, d_first, npairs, e, s, grid, lds);
+    } else {
+        if (k == 1) return launch_pairs_k<1, true>(d_jobs, d_first, npairs, e, s, grid, lds);
+        if (k == 2) return launch_pairs_k<2, true>(d_jobs, d_first, npairs, e, s, grid, lds);
+        if (k == 4) return launch_pairs_k<4, true>(d_jobs, d_first, npairs, e, s, grid, lds);
+        if (k == 8) return launch_pairs_k<8, true>(d_jobs, d_first, npairs, e, s, grid, lds);
+    }
     set_error("unsupported strip height k=%d", k);
     return false;
+}
+
+// Gather the per-pair CIGAR element runs into one contiguous buffer (one block per pair).
+__global__ void pack_cigar_kernel(const uint32_t* __restrict__ src, const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ dst_off,
+                                  const uint32_t* __restrict__ len, uint32_t* __restrict__ dst) {
+    const uint32_t n = len[blockIdx.x];
+    if (n == kTraceFailed) return;
+    const uint32_t* s = src + src_off[blockIdx.x];
+    uint32_t* d = dst + dst_off[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
 }
 
 }  // namespace pa
@@ -641,12 +667,19 @@ struct pa_batch {
     bool sequential = false;  // one wavefront per pair (pair_kernel) instead of chained strips
     int block_waves = 1;
     DeviceBuf d_first;  // sequential: first job of every pair (+ end)
+    // traceback mode (pa_batch_create_trace / pa_batch_align)
+    bool trace = false;
+    size_t trace_fallbacks = 0;  // pairs whose traceback was redone by the host engine
+    std::vector<size_t> ckpt_off, cigar_off;  // per pair, in u32 (ckpt) / elements (cigar)
+    DeviceBuf d_ckpt, d_cigar, d_cigar_len, d_costs, d_scratch_v, d_scratch_vals, d_tjobs, d_cig_src_off, d_cig_dst_off, d_packed;
+    hipEvent_t ev2 = nullptr;
     double cells = 0, word_updates = 0, algo_bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~pa_batch() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        if (ev2) (void)hipEventDestroy(ev2);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -664,7 +697,7 @@ struct BatchShape {
     bool sequential = false;
     int block_waves = 1;
 };
-static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, size_t pairs) {
+static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, size_t pairs, bool sequential_only = false) {
     static const double kLone[4] = {52.9, 76.5, 121.0, 210.0}, kSatChain[3] = {50.8, 65.0, 112.5};
     static const double kShare[4] = {1.0, 0.85, 0.80, 0.78};  // per-wavefront step cost at 1, 2, 3, >= 4 wavefronts per SIMD
     static const int kK[4] = {1, 2, 4, 8};  // k = 8 is built for the sequential kernel only
@@ -675,6 +708,7 @@ static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, s
         if (k == 1 || k == 2 || k == 4 || k == 8) env_k = k;
     }
     if (const char* e = getenv("PA_BATCH_MODE")) env_mode = !strcmp(e, "seq") ? 2 : (!strcmp(e, "chain") ? 1 : 0);
+    if (sequential_only) env_mode = 2;  // the checkpointing forward pass is built for the sequential kernel
     BatchShape best_shape;
     double best = -1;
     for (int t = 0; t < 4; ++t) {
@@ -723,13 +757,14 @@ static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, s
     return best_shape;
 }
 
-extern "C" pa_batch* pa_batch_create(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b,
-                                     const size_t* b_len, size_t pairs) {
+static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len, size_t pairs,
+                              bool trace) {
     if (!ensure_device()) return nullptr;
     auto p = std::make_unique<pa_batch>();
     p->pairs = pairs;
+    p->trace = trace;
     {
-        const BatchShape sh = choose_batch_shape(a_len, b_len, pairs);
+        const BatchShape sh = choose_batch_shape(a_len, b_len, pairs, /*sequential_only=*/trace);
         p->k = sh.k;
         p->sequential = sh.sequential;
         p->block_waves = sh.block_waves;
@@ -759,11 +794,27 @@ extern "C" pa_batch* pa_batch_create(const uint8_t* const* a, const size_t* a_le
         p->algo_bytes += 0.75 * (double)a_len[i] + 48.0 * (double)w;
     }
     p->total_gran = tg;
+    if (trace) {
+        size_t tck = 0, tcg = 0;
+        for (size_t i = 0; i < pairs; ++i) {
+            const size_t w = (b_len[i] + 63) / 64;
+            p->ckpt_off.push_back(tck);
+            p->cigar_off.push_back(tcg);
+            tck += (a_len[i] / 256 + 1) * w * 4;  // u32: one V column per 256 columns of a (slot 0 unused)
+            tcg += a_len[i] + b_len[i] + 2;
+        }
+        if (tcg >= (size_t(1) << 62) || !p->d_ckpt.alloc(tck * 4) || !p->d_cigar.alloc(tcg * 4) || !p->d_packed.alloc(tcg * 4) ||
+            !p->d_cigar_len.alloc(std::max<size_t>(pairs * 4, 16)) || !p->d_costs.alloc(std::max<size_t>(pairs * 4, 16)) ||
+            !p->d_scratch_v.alloc(std::max<size_t>(pairs, 1) * 32 * 16) || !p->d_scratch_vals.alloc(std::max<size_t>(pairs, 1) * 256 * 32 * 16) ||
+            !p->d_tjobs.alloc(std::max<size_t>(pairs, 1) * sizeof(TraceJob)) || !p->d_cig_src_off.alloc(std::max<size_t>(pairs, 1) * 8) ||
+            !p->d_cig_dst_off.alloc(std::max<size_t>(pairs, 1) * 8))
+            return nullptr;
+    }
     if (!p->d_a.alloc(ta) || !p->d_b.alloc(tb) || !p->d_codes.alloc(tc * 4) || !p->d_prof.alloc(tp * 16) ||
         !p->d_v.alloc(tp * 16) || !p->d_gran.alloc(tg * 8) || !p->d_sums.alloc(std::max<size_t>(pairs * 4, 16)) || !p->d_misc.alloc(16))
         return nullptr;
     if (!hip_ok(hipStreamCreate(&p->stream), "hipStreamCreate") || !hip_ok(hipEventCreate(&p->ev0), "event") ||
-        !hip_ok(hipEventCreate(&p->ev1), "event"))
+        !hip_ok(hipEventCreate(&p->ev1), "event") || !hip_ok(hipEventCreate(&p->ev2), "event"))
         return nullptr;
     for (size_t i = 0; i < pairs; ++i) {
         if (a_len[i] && !hip_ok(hipMemcpyAsync(p->d_a.as<uint8_t>() + p->a_off[i], a[i], a_len[i], hipMemcpyHostToDevice, p->stream), "H2D a"))
@@ -794,6 +845,10 @@ extern "C" pa_batch* pa_batch_create(const uint8_t* const* a, const size_t* a_le
         r.tail_rows = (int)b_len[i];
         r.k = p->k;
         r.pingpong = p->sequential;
+        if (trace) {
+            r.ckpt = p->d_ckpt.as<uint32_t>() + p->ckpt_off[i];
+            r.ckpt_stride = w;
+        }
         plan_rect(p->jobs, r);
         p->last_job[i] = (int)p->jobs.size() - 1;
         first[i + 1] = (int32_t)p->jobs.size();
@@ -815,6 +870,34 @@ extern "C" pa_batch* pa_batch_create(const uint8_t* const* a, const size_t* a_le
             return nullptr;
         if (!hip_ok(hipStreamSynchronize(p->stream), "sync")) return nullptr;  // desc is a local
     }
+    if (trace && pairs) {
+        std::vector<TraceJob> tjobs(pairs);
+        std::vector<uint64_t> src_off(pairs);
+        for (size_t i = 0; i < pairs; ++i) {
+            TraceJob& t = tjobs[i];
+            t.a = p->d_a.as<uint8_t>() + p->a_off[i];
+            t.b = p->d_b.as<uint8_t>() + p->b_off[i];
+            t.a_codes = p->d_codes.as<uint32_t>() + p->code_off[i];
+            t.b_prof = p->d_prof.as<uint32_t>() + p->prof_off[i] * 4;
+            t.ckpt = p->d_ckpt.as<uint32_t>() + p->ckpt_off[i];
+            t.final_v = p->d_v.as<uint32_t>() + p->prof_off[i] * 4;
+            t.sum = p->d_sums.as<int32_t>() + i;
+            t.cigar = p->d_cigar.as<uint32_t>() + p->cigar_off[i];
+            t.cigar_len = p->d_cigar_len.as<uint32_t>() + i;
+            t.cost_out = p->d_costs.as<int32_t>() + i;
+            t.scratch_v = p->d_scratch_v.as<uint32_t>() + i * 32 * 4;
+            t.scratch_vals = p->d_scratch_vals.as<uint32_t>() + i * 256 * 32 * 4;
+            t.n = (int32_t)a_len[i];
+            t.m = (int32_t)b_len[i];
+            t.w = (int32_t)((b_len[i] + 63) / 64);
+            t.cigar_cap = (uint32_t)std::min<size_t>(a_len[i] + b_len[i] + 2, 0xFFFFFFF0u);
+            src_off[i] = p->cigar_off[i];
+        }
+        if (!hip_ok(hipMemcpyAsync(p->d_tjobs.ptr, tjobs.data(), pairs * sizeof(TraceJob), hipMemcpyHostToDevice, p->stream), "H2D trace jobs") ||
+            !hip_ok(hipMemcpyAsync(p->d_cig_src_off.ptr, src_off.data(), pairs * 8, hipMemcpyHostToDevice, p->stream), "H2D offsets") ||
+            !hip_ok(hipStreamSynchronize(p->stream), "sync"))
+            return nullptr;
+    }
     if (!p->d_jobs.alloc(p->jobs.size() * sizeof(StripJob))) return nullptr;
     if (!p->jobs.empty() &&
         !hip_ok(hipMemcpyAsync(p->d_jobs.ptr, p->jobs.data(), p->jobs.size() * sizeof(StripJob), hipMemcpyHostToDevice, p->stream), "H2D jobs"))
@@ -823,8 +906,18 @@ extern "C" pa_batch* pa_batch_create(const uint8_t* const* a, const size_t* a_le
     return p.release();
 }
 
-extern "C" int pa_batch_run(pa_batch* p, int32_t* cost_out, float* kernel_ms) {
-    if (!p) return PA_E_ARG;
+extern "C" pa_batch* pa_batch_create(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b,
+                                     const size_t* b_len, size_t pairs) {
+    return batch_create(a, a_len, b, b_len, pairs, false);
+}
+
+extern "C" pa_batch* pa_batch_create_trace(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b,
+                                           const size_t* b_len, size_t pairs) {
+    return batch_create(a, a_len, b, b_len, pairs, true);
+}
+
+// Profiles -> (granule clear) -> DP kernel, all queued on the batch's stream; ev0/ev1 bracket the DP kernel.
+static int batch_forward(pa_batch* p) {
     hipStream_t s = p->stream;
     // (1) profiles (BitProfile::build, once per pair: blocks.rs:112)
     if (!hip_ok(hipMemsetAsync(p->d_misc.ptr, 0, 16, s), "memset")) return PA_E_HIP;
@@ -852,12 +945,20 @@ extern "C" int pa_batch_run(pa_batch* p, int32_t* cost_out, float* kernel_ms) {
     // d_misc (ticket, err, -, bad-base flag) was zeroed above; the events bracket the strip kernel alone
     if (!hip_ok(hipEventRecord(p->ev0, s), "event")) return PA_E_HIP;
     if (p->sequential) {
-        if (!launch_pairs(p->d_jobs.as<StripJob>(), p->d_first.as<int32_t>(), (int)p->pairs, p->d_misc.as<uint32_t>(), s, p->k)) return PA_E_HIP;
+        if (!launch_pairs(p->d_jobs.as<StripJob>(), p->d_first.as<int32_t>(), (int)p->pairs, p->d_misc.as<uint32_t>(), s, p->k, p->trace))
+            return PA_E_HIP;
     } else if (!launch_strips(p->d_jobs.as<StripJob>(), (int)p->jobs.size(), false, p->d_misc.as<uint32_t>(), s, false, false, p->k,
                               p->block_waves)) {
         return PA_E_HIP;
     }
     if (!hip_ok(hipEventRecord(p->ev1, s), "event")) return PA_E_HIP;
+    return 0;
+}
+
+extern "C" int pa_batch_run(pa_batch* p, int32_t* cost_out, float* kernel_ms) {
+    if (!p) return PA_E_ARG;
+    hipStream_t s = p->stream;
+    if (const int rc = batch_forward(p)) return rc;
     // (4) read back: bottom sums and each pair's last v word (for the rows beyond |b| in the last word)
     std::vector<int32_t> sums(p->pairs, 0);
     uint32_t misc[4] = {0, 0, 0, 0};
@@ -887,6 +988,120 @@ extern "C" int pa_batch_run(pa_batch* p, int32_t* cost_out, float* kernel_ms) {
     }
     return 0;
 }
+
+// The parameter set whose traceback pa_batch_align reproduces: nw (Full domain, no doubling) with sparse 256-column
+// blocks and no DT-trace (params.rs:46-68 with front.sparse = true).
+static pa_astarpa2_params traced_batch_params() {
+    engine::AstarPa2Params p = engine::AstarPa2Params::nw();
+    p.front.sparse = true;
+    p.front.dt_trace = false;
+    p.front.incremental_doubling = false;
+    pa_astarpa2_params c;
+    engine::params_to_c(p, &c);
+    return c;
+}
+
+extern "C" void pa_params_batch_align(pa_astarpa2_params* out) {
+    if (out) *out = traced_batch_params();
+}
+
+extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, float* forward_ms, float* trace_ms) {
+    if (!p || !p->trace) {
+        set_error("pa_batch_align needs a batch made by pa_batch_create_trace");
+        return PA_E_ARG;
+    }
+    hipStream_t s = p->stream;
+    const size_t P = p->pairs;
+    if (cigar_out)
+        for (size_t i = 0; i < P; ++i) cigar_out[i] = nullptr;
+    if (const int rc = batch_forward(p)) return rc;
+    // traceback: one wavefront per pair
+    if (P) {
+        const int grid = (int)((P + kStripBlockWaves - 1) / kStripBlockWaves);
+        hipLaunchKernelGGL(trace_kernel, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, p->d_tjobs.as<TraceJob>(), (int)P, p->d_misc.as<uint32_t>() + 1);
+        if (!hip_ok(hipGetLastError(), "trace_kernel launch")) return PA_E_HIP;
+    }
+    if (!hip_ok(hipEventRecord(p->ev2, s), "event")) return PA_E_HIP;
+    std::vector<uint32_t> lens(P, 0);
+    std::vector<int32_t> costs(P, 0);
+    uint32_t misc[4] = {0, 0, 0, 0};
+    if (P && (!hip_ok(hipMemcpyAsync(lens.data(), p->d_cigar_len.ptr, P * 4, hipMemcpyDeviceToHost, s), "D2H lens") ||
+              !hip_ok(hipMemcpyAsync(costs.data(), p->d_costs.ptr, P * 4, hipMemcpyDeviceToHost, s), "D2H costs")))
+        return PA_E_HIP;
+    if (!hip_ok(hipMemcpyAsync(misc, p->d_misc.ptr, 16, hipMemcpyDeviceToHost, s), "D2H") || !hip_ok(hipStreamSynchronize(s), "sync")) return PA_E_HIP;
+    if (misc[3]) {
+        set_error("sequence contains a base outside ACGT");
+        return PA_E_INVALID_BASE;
+    }
+    if (misc[1] != PA_ERR_NONE) {
+        set_error("device spin timeout (err=%u)", misc[1]);
+        return PA_E_TIMEOUT;
+    }
+    p->gran_dirty = false;
+    if (forward_ms) {
+        *forward_ms = 0.f;
+        if (!p->jobs.empty() && !hip_ok(hipEventElapsedTime(forward_ms, p->ev0, p->ev1), "elapsed")) return PA_E_HIP;
+    }
+    if (trace_ms && !hip_ok(hipEventElapsedTime(trace_ms, p->ev1, p->ev2), "elapsed")) return PA_E_HIP;
+    // gather the element runs: one packed buffer, one copy
+    std::vector<uint64_t> dst_off(P, 0);
+    uint64_t total = 0;
+    for (size_t i = 0; i < P; ++i) {
+        dst_off[i] = total;
+        if (lens[i] != kTraceFailed) total += lens[i];
+    }
+    std::vector<uint32_t> packed(total);
+    if (P && total) {
+        if (!hip_ok(hipMemcpyAsync(p->d_cig_dst_off.ptr, dst_off.data(), P * 8, hipMemcpyHostToDevice, s), "H2D offsets")) return PA_E_HIP;
+        hipLaunchKernelGGL(pack_cigar_kernel, dim3((unsigned)P), dim3(256), 0, s, p->d_cigar.as<uint32_t>(), p->d_cig_src_off.as<uint64_t>(),
+                           p->d_cig_dst_off.as<uint64_t>(), p->d_cigar_len.as<uint32_t>(), p->d_packed.as<uint32_t>());
+        if (!hip_ok(hipGetLastError(), "pack_cigar_kernel") ||
+            !hip_ok(hipMemcpyAsync(packed.data(), p->d_packed.ptr, total * 4, hipMemcpyDeviceToHost, s), "D2H cigars") ||
+            !hip_ok(hipStreamSynchronize(s), "sync"))
+            return PA_E_HIP;
+    }
+    const pa_astarpa2_params fallback = traced_batch_params();
+    for (size_t i = 0; i < P; ++i) {
+        cost_out[i] = costs[i];
+        if (!cigar_out) continue;
+        std::string text;
+        if (lens[i] == kTraceFailed) {
+            // taller re-fill than one strip (or a state the reference would panic on): the host engine redoes this pair
+            p->trace_fallbacks += 1;
+            const uint8_t* ha = nullptr;
+            const uint8_t* hb = nullptr;
+            std::vector<uint8_t> ba(p->n[i]), bb(p->m[i]);
+            if ((p->n[i] && !hip_ok(hipMemcpy(ba.data(), p->d_a.as<uint8_t>() + p->a_off[i], p->n[i], hipMemcpyDeviceToHost), "D2H a")) ||
+                (p->m[i] && !hip_ok(hipMemcpy(bb.data(), p->d_b.as<uint8_t>() + p->b_off[i], p->m[i], hipMemcpyDeviceToHost), "D2H b")))
+                return PA_E_HIP;
+            ha = ba.data();
+            hb = bb.data();
+            int32_t c = 0;
+            const int rc = align_hip(ha, p->n[i], hb, p->m[i], fallback, true, false, &c, &text, nullptr);
+            if (rc != 0) return rc;
+            if (c != costs[i]) {
+                set_error("traceback fallback disagrees with the batched cost (pair %zu: %d vs %d)", i, c, costs[i]);
+                return PA_E_INTERNAL;
+            }
+        } else {
+            engine::Cigar cg;
+            const uint32_t* e = packed.data() + dst_off[i];
+            for (uint32_t k = lens[i]; k-- > 0;) {  // stored end -> start
+                const uint32_t op = e[k] & 3u;
+                cg.push_elem(engine::CigarElem{op == kOpMatch ? engine::CigarOp::Match : op == kOpSub ? engine::CigarOp::Sub
+                                                : op == kOpIns ? engine::CigarOp::Ins : engine::CigarOp::Del,
+                                               (engine::I)(e[k] >> 2)});
+            }
+            text = cg.to_string();
+        }
+        cigar_out[i] = (char*)std::malloc(text.size() + 1);
+        if (!cigar_out[i]) return PA_E_ARG;
+        std::memcpy(cigar_out[i], text.c_str(), text.size() + 1);
+    }
+    return 0;
+}
+
+extern "C" size_t pa_batch_trace_fallbacks(const pa_batch* p) { return p ? p->trace_fallbacks : 0; }
 
 extern "C" void pa_batch_stats(const pa_batch* p, double* cells, double* word_updates, double* strips, double* algo_bytes) {
     if (cells) *cells = p->cells;

@@ -4,8 +4,10 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <string>
 #include <vector>
 
+#include "../../include/pa_astarpa2.h"
 #include "../../include/pa_bitpacking_hip.h"
 #include "strip_kernel.hpp"
 
@@ -50,6 +52,8 @@ struct RectPlan {
     bool pingpong = false;  // sequential-pairs mode: two granule rows per rectangle, strip s writes row s&1;
                             // the ragged bottom is planned as short k = 1 strips (strip_plan)
     int k = 1;  // 32-row subwords per lane (1: lowest latency; 2, 4: fewer instructions per cell, cost-only strips)
+    uint32_t* ckpt = nullptr;  // traced batches: V column after every 256th column (StripJob::ckpt)
+    int ckpt_stride = 0;
 };
 
 void plan_rect(std::vector<StripJob>& jobs, const RectPlan& r);
@@ -62,7 +66,9 @@ StripPlan strip_plan(int w, int k, bool sequential);
 size_t rect_granules(int n, int w, int k = 1, bool pingpong = false);
 bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_ticket_err, hipStream_t s, bool zero_ticket = true,
                    bool scatter = false, int k = 1, int block_waves = kStripBlockWaves);
-bool launch_pairs(const StripJob* d_jobs, const int32_t* d_first, int npairs, uint32_t* d_ticket_err, hipStream_t s, int k);
+bool launch_pairs(const StripJob* d_jobs, const int32_t* d_first, int npairs, uint32_t* d_ticket_err, hipStream_t s, int k, bool ckpt = false);
+int align_hip(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params& params, bool trace, bool self_check,
+              int32_t* cost_out, std::string* cigar_out, pa_astarpa2_stats* stats_out);
 bool encode_a_device(const uint8_t* d_a, int n, uint32_t* d_codes, uint32_t* d_bad, hipStream_t s);
 bool build_b_device(const uint8_t* d_b, int m, uint64_t* d_prof, uint32_t* d_bad, hipStream_t s);
 

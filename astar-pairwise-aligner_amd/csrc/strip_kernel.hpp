@@ -77,9 +77,13 @@ struct StripJob {
                               //       (Block::index from the bottom, block.rs:110-120), so the host adds 64*words only
                               // < 0: plain sum of the bottom-row deltas
     int32_t k;                // pair_kernel only: subwords per lane of THIS strip (1 = short tail strip, else the kernel's K)
+    uint32_t* ckpt;           // CKPT kernels: V column after every 256th column, u32 view of ckpt[c][ckpt_stride] (V each),
+                              // c = (column + 1) / 256; the sparse blocks of the traceback (blocks.rs:322-339).  Or nullptr
+    int32_t ckpt_stride;      // words per checkpoint column
+    int32_t pad2_;
 };
 enum : int32_t { kJobVInitOne = 1 };
-static_assert(sizeof(StripJob) == 112, "StripJob layout");
+static_assert(sizeof(StripJob) == 128, "StripJob layout");
 
 enum : uint32_t {
     PA_ERR_NONE = 0,
@@ -185,7 +189,7 @@ __device__ __forceinline__ void myers_step(uint32_t s_x, uint32_t& X, uint32_t (
 
 // One chunk = 32 columns = 32 unrolled steps.  Lane j (< 32) of XS carries the packed pipeline input of column 32q+j.
 // The lagged accumulator of steps 0..15 is acc_lo, of steps 16..31 acc_hi (static, so no register moves).
-template <int K, bool PRED, bool PASS, bool FILL, bool SCATTER>
+template <int K, bool PRED, bool PASS, bool FILL, bool SCATTER, bool CKPT>
 __device__ __forceinline__ void run_chunk(const StripJob& job, int q, uint32_t XS, uint32_t& X, uint32_t (&vp)[K],
                                           uint32_t (&vm)[K], const uint32_t (&nb0)[K], const uint32_t (&nb1)[K],
                                           const uint32_t (&nb2)[K], const uint32_t (&nb3)[K], uint32_t& acc_lo,
@@ -205,6 +209,30 @@ __device__ __forceinline__ void run_chunk(const StripJob& job, int q, uint32_t X
                         gu32 dst = vout + (size_t)col * (size_t)job.fill_stride * 4 + (size_t)(sub >> 1) * 4 + (sub & 1);
                         dst[0] = vp[k];
                         dst[2] = vm[k];
+                    }
+                }
+            }
+        }
+        if (CKPT) {
+            // the one lane (if any) whose column just completed a 256-column block stores its V words
+            const int t = (q * 32 + j + 1) & 255;
+            if (lane == t && active) {
+                gu32 base = (gu32)job.ckpt + ((size_t)((col + 1) >> 8) * (size_t)job.ckpt_stride + (size_t)job.word0) * 4;
+                if (K == 1) {
+                    if (lane < job.nlanes) {
+                        base[(size_t)(lane >> 1) * 4 + (lane & 1)] = vp[0];
+                        base[(size_t)(lane >> 1) * 4 + 2 + (lane & 1)] = vm[0];
+                    }
+                } else {
+                    // a lane owns K/2 whole V words: one 16-byte store each
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    typedef PA_GLOBAL u32x4* gu32x4;
+#pragma unroll
+                    for (int i = 0; i < K / 2; ++i) {
+                        if (lane * K + 2 * i < job.nlanes) {
+                            const u32x4 word = {vp[2 * i], vp[2 * i + 1], vm[2 * i], vm[2 * i + 1]};
+                            *(gu32x4)(base + ((size_t)lane * (K / 2) + i) * 4) = word;
+                        }
                     }
                 }
             }
@@ -243,7 +271,7 @@ __device__ __forceinline__ bool resolve_granule(gcu64 g, uint64_t pre, int q, ui
 
 // Process one strip.  On a spin timeout the error word is set and the strip stops early.
 // K = 32-row subwords per lane: the strip covers 64*K subwords = 32*K reference words.
-template <int K, bool FILL, bool SCATTER>
+template <int K, bool FILL, bool SCATTER, bool CKPT = false>
 __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
     const int lane = (int)(threadIdx.x & 63);
     const int n = job.n;
@@ -393,13 +421,29 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
         hinb_next = load_hin_byte(q + 1);
 
         const bool interior = !FILL && (q >= 2) && (q * 32 + 31 < n);
-        if (interior) {
-            if (exact_tail) run_chunk<K, false, true, false, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80);
-            else run_chunk<K, false, false, false, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80);
+        // a 256-column block can only complete in a chunk whose first column is 0, 32 or 224 (mod 256): lane l reaches column
+        // 255 (mod 256) at step 32q + j = 255 + l.  Only those chunks pay for the checkpoint test.
+        const bool ck_chunk = CKPT && job.ckpt != nullptr && ((q & 7) <= 1 || (q & 7) == 7);
+#define PA_RUN_CHUNK(PRED_, PASS_, FILL_, CK_) \
+    run_chunk<K, PRED_, PASS_, FILL_, SCATTER, CK_>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80)
+        if (CKPT && ck_chunk) {
+            if (interior) {
+                if (exact_tail) PA_RUN_CHUNK(false, true, false, CKPT);
+                else PA_RUN_CHUNK(false, false, false, CKPT);
+            } else {
+                if (exact_tail) PA_RUN_CHUNK(true, true, FILL, CKPT);
+                else PA_RUN_CHUNK(true, false, FILL, CKPT);
+            }
         } else {
-            if (exact_tail) run_chunk<K, true, true, FILL, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80);
-            else run_chunk<K, true, false, FILL, SCATTER>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80);
+            if (interior) {
+                if (exact_tail) PA_RUN_CHUNK(false, true, false, false);
+                else PA_RUN_CHUNK(false, false, false, false);
+            } else {
+                if (exact_tail) PA_RUN_CHUNK(true, true, FILL, false);
+                else PA_RUN_CHUNK(true, false, FILL, false);
+            }
         }
+#undef PA_RUN_CHUNK
     }
     if (alive) publish(C - 1);  // the last granule (completed by chunk Q-1 = C+1)
     PA_DBG(1, 2);
@@ -506,6 +550,9 @@ __global__ __launch_bounds__(64) void rect_kernel(RectArgs r) {
     j.col0 = r.col0;
     j.tail_rows = -1;
     j.k = K;
+    j.ckpt = nullptr;
+    j.ckpt_stride = 0;
+    j.pad2_ = 0;
     run_strip<K, false, false>(j, r.err);
     // completion: results first (system scope: v and the sum are in host memory), then the count, then the flag
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
@@ -522,7 +569,7 @@ __global__ __launch_bounds__(64) void rect_kernel(RectArgs r) {
 // jobs[first[p+1]-1]); the bottom row of strip s goes through the same granule rows (two per rectangle, ping-pong) but
 // is produced and consumed by the same wavefront, so nothing ever polls.  With >= one rectangle per SIMD this removes the
 // strip-to-strip coupling that costs chained strips 40-70 % at 2-7 wavefronts per SIMD (profiles/r01_runs/chain_probe2.log).
-template <int K>
+template <int K, bool CKPT = false>
 __global__ __launch_bounds__(64 * kStripBlockWaves) void pair_kernel(const StripJob* __restrict__ jobs,
                                                                       const int32_t* __restrict__ first, int npairs,
                                                                       uint32_t* err) {
@@ -532,8 +579,8 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void pair_kernel(const Strip
     for (int j = j0; j < j1; ++j) {
         const StripJob job = jobs[j];
         // the ragged bottom of a pair runs as short 32-row-per-lane strips instead of one mostly empty tall one
-        if (K > 1 && job.k == 1) run_strip<1, false, false>(job, err);
-        else run_strip<K, false, false>(job, err);
+        if (K > 1 && job.k == 1) run_strip<1, false, false, CKPT>(job, err);
+        else run_strip<K, false, false, CKPT>(job, err);
         // the next strip reads what this one stored (granules, through the L2): drain and order the stores first
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     }

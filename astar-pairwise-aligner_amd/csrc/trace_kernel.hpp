@@ -1,0 +1,271 @@
+// trace_kernel.hpp -- batched traceback on the GPU: one wavefront per pair walks from (n, m) back to (0, 0).
+//
+// What it replaces: Blocks::trace / fill_with_blocks / parent of the reference for sparse 256-column blocks without
+// DT-trace (astarpa2/src/blocks/trace.rs:21-228, blocks.rs:572-662), i.e. the traceback of
+// AstarPa2Params { domain: Full, doubling: None, block_width: 256, front: { sparse: true, dt_trace: false, .. } }.
+// The forward pass (pair_kernel<K, CKPT=true>) leaves the right-edge column of every 256-column block in `ckpt`
+// (the reference's sparse `Block`s, blocks.rs:322-339).  Per block the wavefront
+//   1. re-fills the sub-rectangle (checkpoint column, to.i] x [to.j - height, to.j] rounded out to words, top row +1,
+//      height = min(to.j, 5/4 width) doubling until the cost at `to` is reproduced (trace.rs:94-122), with the ordinary
+//      strip step (run_strip<1, FILL>) into a per-pair scratch buffer,
+//   2. walks `parent` steps (greedy matches, then insertion / deletion / substitution, trace.rs:145-228) on those
+//      columns until it crosses the checkpoint column.
+// All control flow is wavefront-uniform; the lanes are used for the fill, for prefix sums over a column (Block::index)
+// and for 64-at-a-time match extension.  A pair that needs a taller re-fill than one strip (2048 rows) or hits a state
+// the reference itself would panic on is flagged and redone by the host engine.
+#pragma once
+#include "strip_kernel.hpp"
+
+namespace pa {
+
+struct TraceJob {
+    const uint8_t* a;          // ASCII of a (columns) and b (rows), device
+    const uint8_t* b;
+    const uint32_t* a_codes;   // packed 2-bit codes of a (strip kernel input)
+    const uint32_t* b_prof;    // BitProfile words of b, u32 view
+    const uint32_t* ckpt;      // checkpoint columns: u32 view of ckpt[c][w] (V each), c = column / 256 (c = 0 unused: V::one)
+    const uint32_t* final_v;   // the column at i = n (the forward pass's v), u32 view: the last sparse block
+    const int32_t* sum;        // bottom-row sum of the forward pass (cost = 64 w + sum, tail rows already removed)
+    uint32_t* cigar;           // out: elements (count << 2) | op, from the END of the alignment to its start
+    uint32_t* cigar_len;       // out: number of elements, or kTraceFailed
+    int32_t* cost_out;         // out: the edit distance
+    uint32_t* scratch_v;       // 32 words x 4 u32
+    uint32_t* scratch_vals;    // 256 columns x 32 words x 4 u32
+    int32_t n, m, w;           // |a|, |b|, words of b
+    uint32_t cigar_cap;
+};
+enum : uint32_t { kTraceFailed = 0xFFFFFFFFu };
+enum : uint32_t { kOpMatch = 0, kOpSub = 1, kOpIns = 2, kOpDel = 3 };  // '=', 'X', 'I' (advances b), 'D' (advances a)
+
+__device__ __forceinline__ int32_t wave_sum(int32_t x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return (int32_t)rfl((uint32_t)x);
+}
+
+// Sum of the vertical deltas of the first `rows` rows of a column stored as V words (u32 view, word 0 first); nullptr = V::one.
+__device__ __forceinline__ int32_t column_prefix(gcu32 col, int rows, int lane) {
+    if (col == nullptr) return rows;
+    const int full = rows >> 6, rem = rows & 63;
+    int32_t acc = 0;
+    for (int base = 0; base <= full; base += 64) {
+        const int wi = base + lane;
+        if (wi < full || (wi == full && rem != 0)) {
+            const uint64_t p = (uint64_t)col[wi * 4 + 0] | ((uint64_t)col[wi * 4 + 1] << 32);
+            const uint64_t m = (uint64_t)col[wi * 4 + 2] | ((uint64_t)col[wi * 4 + 3] << 32);
+            const uint64_t mask = wi < full ? ~0ull : ((1ull << rem) - 1ull);
+            acc += __builtin_popcountll(p & mask) - __builtin_popcountll(m & mask);
+        }
+    }
+    return wave_sum(acc);
+}
+
+// Vertical delta of row `r` (relative to the column's first row); nullptr = V::one.
+__device__ __forceinline__ int32_t column_diff(gcu32 col, int r) {
+    if (col == nullptr) return 1;
+    const uint32_t p = rfl(col[(r >> 6) * 4 + ((r >> 5) & 1)]);
+    const uint32_t m = rfl(col[(r >> 6) * 4 + 2 + ((r >> 5) & 1)]);
+    return (int32_t)((p >> (r & 31)) & 1u) - (int32_t)((m >> (r & 31)) & 1u);
+}
+
+__global__ __launch_bounds__(64 * kStripBlockWaves) void trace_kernel(const TraceJob* __restrict__ jobs, int npairs, uint32_t* err) {
+    const int pair = (int)rfl((uint32_t)(blockIdx.x * kStripBlockWaves + (threadIdx.x >> 6)));
+    if (pair >= npairs) return;
+    const int lane = (int)(threadIdx.x & 63);
+    const TraceJob tj = jobs[pair];
+    const gcu8 a = (gcu8)tj.a;
+    const gcu8 b = (gcu8)tj.b;
+    const gu32 cig = (gu32)tj.cigar;
+    const int n = tj.n, m = tj.m, w = tj.w;
+
+    int32_t g = (n == 0) ? m : (m == 0 ? n : 64 * w + (int32_t)rfl((uint32_t)*(const PA_GLOBAL int32_t*)tj.sum));
+    if (lane == 0) *(gi32)tj.cost_out = g;
+
+    uint32_t len = 0, cur_op = 0, cur_cnt = 0;
+    bool failed = false;
+    auto emit = [&](uint32_t op, uint32_t cnt) {
+        if (cur_cnt != 0 && cur_op == op) {
+            cur_cnt += cnt;
+            return;
+        }
+        if (cur_cnt != 0) {
+            if (len < tj.cigar_cap) {
+                if (lane == 0) cig[len] = (cur_cnt << 2) | cur_op;
+            } else {
+                failed = true;
+            }
+            ++len;
+        }
+        cur_op = op;
+        cur_cnt = cnt;
+    };
+
+    int to_i = n, to_j = m;
+    // the re-filled rectangle: columns (f_i0, f_i1], rows [f_jlo, f_jhi), top-left value f_T0 (at (f_i0, f_jlo))
+    int f_i0 = -1, f_i1 = -1, f_jlo = 0, f_jhi = 0, f_words = 0;
+    int32_t f_T0 = 0;
+    const gu32 vals = (gu32)tj.scratch_vals;
+    const gu32 sv = (gu32)tj.scratch_v;
+    gcu32 fcols = (gcu32)vals;  // where the filled columns live
+    auto ckpt_col = [&](int i0) -> gcu32 {  // the stored column at i0 (a multiple of 256); column 0 is V::one
+        return i0 == 0 ? (gcu32) nullptr : (gcu32)tj.ckpt + (size_t)(i0 >> 8) * (size_t)w * 4;
+    };
+    auto filled_col = [&](int i) -> gcu32 { return fcols + (size_t)(i - f_i0 - 1) * (size_t)f_words * 4; };
+
+    while (!failed && (to_i > 0 || to_j > 0)) {
+        if (to_i == 0) {  // first column: V::one all the way up (trace.rs parent on Block::first_col)
+            emit(kOpIns, (uint32_t)to_j);
+            g -= to_j;
+            to_j = 0;
+            break;
+        }
+        if (to_j == 0) {  // top row: every column costs one deletion
+            emit(kOpDel, (uint32_t)to_i);
+            g -= to_i;
+            to_i = 0;
+            break;
+        }
+        // ---- re-fill when the walk has left the filled columns (trace.rs:83-125) ----
+        if (!(f_i0 < to_i && to_i <= f_i1) && to_i == n && ((n - 1) & 255) == 0) {
+            // the last sparse block is a single column next to a checkpoint: the reference walks it as stored, without a
+            // re-fill (trace.rs:86: neither `prev.e < to.i - 1` nor `block.e > to.i`)
+            f_i0 = n - 1;
+            f_i1 = n;
+            f_jlo = 0;
+            f_jhi = 64 * w;
+            f_words = w;
+            f_T0 = n - 1;
+            fcols = (gcu32)tj.final_v;
+        }
+        if (!(f_i0 < to_i && to_i <= f_i1)) {
+            fcols = (gcu32)vals;
+            const int i0 = ((to_i - 1) >> 8) << 8;
+            const int cols = to_i - i0;
+            const gcu32 ck = ckpt_col(i0);
+            int height = to_j < cols * 5 / 4 ? to_j : cols * 5 / 4;
+            for (;;) {
+                const int jlo_raw = to_j - height > 0 ? to_j - height : 0;
+                const int jlo = jlo_raw & ~63, jhi = (to_j + 63) & ~63;
+                const int words = (jhi - jlo) >> 6;
+                if (words > 32) {  // taller than one strip: leave this pair to the host engine
+                    failed = true;
+                    break;
+                }
+                // left column = the checkpoint's words of these rows (init_v_with_overlap, blocks.rs:753-767)
+                if (lane < words) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) sv[lane * 4 + c] = ck ? ck[((jlo >> 6) + lane) * 4 + c] : (c < 2 ? 0xFFFFFFFFu : 0u);
+                }
+                const int32_t T0 = i0 + column_prefix(ck, jlo, lane);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                StripJob j;
+                j.a_codes = tj.a_codes;
+                j.b_prof = tj.b_prof;
+                j.v = (uint32_t*)tj.scratch_v - (size_t)(jlo >> 6) * 4;
+                j.hin_gran = nullptr;
+                j.hin_arr = nullptr;
+                j.hout_gran = nullptr;
+                j.hout_arr = nullptr;
+                j.values = tj.scratch_vals;
+                j.sum_out = nullptr;
+                j.n = cols;
+                j.word0 = jlo >> 6;
+                j.nlanes = 2 * words;
+                j.fill_stride = words;
+                j.fill_word0 = 0;
+                j.exact_tail = 1;
+                j.flags = 0;
+                j.col0 = i0;
+                j.tail_rows = -1;
+                j.k = 1;
+                j.ckpt = nullptr;
+                j.ckpt_stride = 0;
+                j.pad2_ = 0;
+                run_strip<1, true, false>(j, err);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                f_i0 = i0;
+                f_i1 = to_i;
+                f_jlo = jlo;
+                f_jhi = jhi;
+                f_words = words;
+                f_T0 = T0;
+                const int32_t val = T0 + cols + column_prefix(filled_col(to_i), to_j - jlo, lane);
+                if (val == g) break;
+                if (jlo == 0) {  // "No trace found through block"
+                    failed = true;
+                    break;
+                }
+                height *= 2;
+            }
+            if (failed) break;
+        }
+        // ---- parent (trace.rs:145-228) ----
+        {  // greedy matches, 64 characters at a time
+            uint32_t cnt = 0;
+            while (to_i > 0 && to_j > 0) {
+                const int lim = to_i < to_j ? (to_i < 64 ? to_i : 64) : (to_j < 64 ? to_j : 64);
+                bool eq = false;
+                if (lane < lim) eq = a[to_i - 1 - lane] == b[to_j - 1 - lane];
+                const uint64_t mask = __ballot(eq);
+                const int run = mask == ~0ull ? 64 : __builtin_ctzll(~mask);
+                cnt += (uint32_t)run;
+                to_i -= run;
+                to_j -= run;
+                if (run < 64) break;
+            }
+            if (cnt > 0) {
+                emit(kOpMatch, cnt);
+                continue;
+            }
+        }
+        // vertical delta of the current column at row to_j - 1 (Block::get_diff)
+        const int r = to_j - 1;
+        const bool in_rows = r >= f_jlo && r < f_jhi;
+        if (in_rows && column_diff(filled_col(to_i), r - f_jlo) == 1) {
+            g -= 1;
+            to_j -= 1;
+            emit(kOpIns, 1);
+            continue;
+        }
+        // previous column: the checkpoint itself when to_i - 1 == f_i0, else a filled column
+        const bool prev_ck = (to_i - 1 == f_i0);
+        const gcu32 pc = prev_ck ? ckpt_col(f_i0) : filled_col(to_i - 1);
+        const int p_jlo = prev_ck ? 0 : f_jlo;
+        const int32_t p_top = prev_ck ? f_i0 : f_T0 + (to_i - 1 - f_i0);
+        int32_t hd = 1;
+        if (to_j >= p_jlo) hd = g - (p_top + column_prefix(pc, to_j - p_jlo, lane));
+        if (hd == 1) {
+            g -= 1;
+            to_i -= 1;
+            emit(kOpDel, 1);
+            continue;
+        }
+        if (r < p_jlo) {  // the reference's get_diff(..).unwrap() would panic here
+            failed = true;
+            break;
+        }
+        const int32_t dd = column_diff(pc, r - p_jlo) + hd;
+        if (dd == 1) {
+            g -= 1;
+            to_i -= 1;
+            to_j -= 1;
+            emit(kOpSub, 1);
+            continue;
+        }
+        failed = true;  // "PARENT NOT FOUND IN TRACEBACK"
+    }
+    if (!failed) {
+        if (cur_cnt != 0) {
+            if (len < tj.cigar_cap) {
+                if (lane == 0) cig[len] = (cur_cnt << 2) | cur_op;
+            } else {
+                failed = true;
+            }
+            ++len;
+        }
+        if (g != 0) failed = true;  // "trace ends at distance 0"
+    }
+    if (lane == 0) *(gu32)tj.cigar_len = failed ? kTraceFailed : len;
+}
+
+}  // namespace pa

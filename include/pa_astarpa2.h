@@ -59,6 +59,8 @@ typedef struct pa_astarpa2_stats { /* AstarPa2Stats + BlockStats + TraceStats */
 void pa_params_nw(pa_astarpa2_params* p);
 void pa_params_simple(pa_astarpa2_params* p);
 void pa_params_full(pa_astarpa2_params* p);
+/* nw() with front.sparse = 1 and no DT-trace: the parameter set whose alignments pa_batch_align (pa_bitpacking_hip.h) returns. */
+void pa_params_batch_align(pa_astarpa2_params* p);
 
 /* align_with_stats.  trace != 0 => *cigar_out receives a malloc'ed NUL-terminated CIGAR ("=I4=X=" style,
  * free() it or use astarpa_free_cigar).  Returns 0, or a PA_E_* code.  All DP rectangles run on the GPU. */

@@ -84,6 +84,20 @@ void pa_batch_stats(const pa_batch* plan, double* cells, double* word_updates, d
 void pa_batch_shape(const pa_batch* plan, int* k, int* sequential, double* valu_instructions);
 void pa_batch_destroy(pa_batch* plan);
 
+/* ---- batched global alignment WITH traceback ------------------------------------------------------- */
+/* Cost and CIGAR of every pair, both computed on the GPU: the forward pass keeps the right-edge column of every
+ * 256-column block (the reference's sparse blocks, astarpa2/src/blocks.rs:322-339) and one wavefront per pair walks
+ * back through them like Blocks::trace without DT-trace (blocks/trace.rs:21-228: re-fill of a 5/4-width-high
+ * sub-block, doubling; greedy matches, then insertion / deletion / substitution).  The result is what
+ * `pa_align(.., pa_params_batch_align(), trace = 1, ..)` returns for each pair, i.e. AstarPa2Params::nw() with
+ * front.sparse = true.  cigar_out[i] is a malloc'ed "=I4=X="-style string (release with astarpa_free_cigar / free).
+ * A pair whose re-fill would be taller than one strip (2048 rows) is redone by the host engine transparently. */
+pa_batch* pa_batch_create_trace(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b,
+                                const size_t* b_len, size_t pairs);
+int pa_batch_align(pa_batch* plan, int32_t* cost_out, char** cigar_out, float* forward_ms, float* trace_ms);
+/* Pairs (summed over all pa_batch_align calls of this plan) whose traceback was redone by the host engine. */
+size_t pa_batch_trace_fallbacks(const pa_batch* plan);
+
 #ifdef __cplusplus
 }
 #endif

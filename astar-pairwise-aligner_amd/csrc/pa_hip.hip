@@ -353,13 +353,66 @@ bool launch_pairs(const StripJob* d_jobs, const int32_t* d_first, int npairs, ui
     return false;
 }
 
-// Gather the per-pair CIGAR element runs into one contiguous buffer (one block per pair).
-__global__ void pack_cigar_kernel(const uint32_t* __restrict__ src, const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ dst_off,
-                                  const uint32_t* __restrict__ len, uint32_t* __restrict__ dst) {
+// CIGAR text on the GPU.  trace_kernel leaves each pair's elements (count << 2 | op) from the END of the alignment to its
+// start; one wavefront per pair turns them into the reference's string form (count omitted when 1, ops "=XID",
+// pa-types Cigar::to_string as pinned by astarpa-c/example.cpp:16), written IN PLACE over nothing: into text[pair].
+__global__ __launch_bounds__(64) void format_cigar_kernel(const uint32_t* __restrict__ elems, const uint64_t* __restrict__ off,
+                                                          const uint32_t* __restrict__ len, uint8_t* __restrict__ text,
+                                                          uint32_t* __restrict__ text_len) {
     const uint32_t n = len[blockIdx.x];
-    if (n == kTraceFailed) return;
-    const uint32_t* s = src + src_off[blockIdx.x];
-    uint32_t* d = dst + dst_off[blockIdx.x];
+    if (n == kTraceFailed) {
+        if (threadIdx.x == 0) text_len[blockIdx.x] = 0;
+        return;
+    }
+    const uint32_t* e = elems + off[blockIdx.x];
+    uint8_t* out = text + off[blockIdx.x];  // same offsets: a string never has more characters than the pair has ops
+    const int lane = (int)threadIdx.x;
+    uint32_t pos = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t k = base + (uint32_t)lane;  // k-th element of the OUTPUT = element n-1-k of the stored run
+        uint32_t v = 0, cnt = 0, chars = 0;
+        if (k < n) {
+            v = e[n - 1 - k];
+            cnt = v >> 2;
+            chars = 1;
+            if (cnt != 1) {
+                uint32_t c = cnt;
+                do {
+                    ++chars;
+                    c /= 10;
+                } while (c);
+            }
+        }
+        // exclusive prefix sum of `chars` over the wavefront
+        uint32_t incl = chars;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        const uint32_t start = pos + incl - chars;
+        if (k < n) {
+            uint8_t* w = out + start + chars - 1;
+            *w-- = (uint8_t)"=XID"[v & 3u];
+            if (cnt != 1) {
+                uint32_t c = cnt;
+                do {
+                    *w-- = (uint8_t)('0' + c % 10);
+                    c /= 10;
+                } while (c);
+            }
+        }
+        pos += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) text_len[blockIdx.x] = pos;
+}
+
+// Gather the per-pair strings into one contiguous buffer (one block per pair).
+__global__ void pack_text_kernel(const uint8_t* __restrict__ src, const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ dst_off,
+                                 const uint32_t* __restrict__ len, uint8_t* __restrict__ dst) {
+    const uint32_t n = len[blockIdx.x];
+    const uint8_t* s = src + src_off[blockIdx.x];
+    uint8_t* d = dst + dst_off[blockIdx.x];
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
 }
 
@@ -671,7 +724,7 @@ struct pa_batch {
     bool trace = false;
     size_t trace_fallbacks = 0;  // pairs whose traceback was redone by the host engine
     std::vector<size_t> ckpt_off, cigar_off;  // per pair, in u32 (ckpt) / elements (cigar)
-    DeviceBuf d_ckpt, d_cigar, d_cigar_len, d_costs, d_scratch_v, d_scratch_vals, d_tjobs, d_cig_src_off, d_cig_dst_off, d_packed;
+    DeviceBuf d_ckpt, d_cigar, d_cigar_len, d_costs, d_scratch_v, d_scratch_vals, d_tjobs, d_cig_src_off, d_cig_dst_off, d_packed, d_text, d_text_len;
     hipEvent_t ev2 = nullptr;
     double cells = 0, word_updates = 0, algo_bytes = 0;
     hipStream_t stream = nullptr;
@@ -803,7 +856,8 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             tck += (a_len[i] / 256 + 1) * w * 4;  // u32: one V column per 256 columns of a (slot 0 unused)
             tcg += a_len[i] + b_len[i] + 2;
         }
-        if (tcg >= (size_t(1) << 62) || !p->d_ckpt.alloc(tck * 4) || !p->d_cigar.alloc(tcg * 4) || !p->d_packed.alloc(tcg * 4) ||
+        if (tcg >= (size_t(1) << 62) || !p->d_ckpt.alloc(tck * 4) || !p->d_cigar.alloc(tcg * 4) || !p->d_packed.alloc(tcg) || !p->d_text.alloc(tcg) ||
+            !p->d_text_len.alloc(std::max<size_t>(pairs * 4, 16)) ||
             !p->d_cigar_len.alloc(std::max<size_t>(pairs * 4, 16)) || !p->d_costs.alloc(std::max<size_t>(pairs * 4, 16)) ||
             !p->d_scratch_v.alloc(std::max<size_t>(pairs, 1) * 32 * 16) || !p->d_scratch_vals.alloc(std::max<size_t>(pairs, 1) * 256 * 32 * 16) ||
             !p->d_tjobs.alloc(std::max<size_t>(pairs, 1) * sizeof(TraceJob)) || !p->d_cig_src_off.alloc(std::max<size_t>(pairs, 1) * 8) ||
@@ -1043,22 +1097,32 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
         if (!p->jobs.empty() && !hip_ok(hipEventElapsedTime(forward_ms, p->ev0, p->ev1), "elapsed")) return PA_E_HIP;
     }
     if (trace_ms && !hip_ok(hipEventElapsedTime(trace_ms, p->ev1, p->ev2), "elapsed")) return PA_E_HIP;
-    // gather the element runs: one packed buffer, one copy
+    // CIGAR text is produced on the GPU; gather it into one packed buffer and copy once
+    std::vector<uint32_t> tlens(P, 0);
     std::vector<uint64_t> dst_off(P, 0);
-    uint64_t total = 0;
-    for (size_t i = 0; i < P; ++i) {
-        dst_off[i] = total;
-        if (lens[i] != kTraceFailed) total += lens[i];
-    }
-    std::vector<uint32_t> packed(total);
-    if (P && total) {
-        if (!hip_ok(hipMemcpyAsync(p->d_cig_dst_off.ptr, dst_off.data(), P * 8, hipMemcpyHostToDevice, s), "H2D offsets")) return PA_E_HIP;
-        hipLaunchKernelGGL(pack_cigar_kernel, dim3((unsigned)P), dim3(256), 0, s, p->d_cigar.as<uint32_t>(), p->d_cig_src_off.as<uint64_t>(),
-                           p->d_cig_dst_off.as<uint64_t>(), p->d_cigar_len.as<uint32_t>(), p->d_packed.as<uint32_t>());
-        if (!hip_ok(hipGetLastError(), "pack_cigar_kernel") ||
-            !hip_ok(hipMemcpyAsync(packed.data(), p->d_packed.ptr, total * 4, hipMemcpyDeviceToHost, s), "D2H cigars") ||
+    std::vector<uint8_t> packed;
+    if (P) {
+        hipLaunchKernelGGL(format_cigar_kernel, dim3((unsigned)P), dim3(64), 0, s, p->d_cigar.as<uint32_t>(), p->d_cig_src_off.as<uint64_t>(),
+                           p->d_cigar_len.as<uint32_t>(), p->d_text.as<uint8_t>(), p->d_text_len.as<uint32_t>());
+        if (!hip_ok(hipGetLastError(), "format_cigar_kernel") ||
+            !hip_ok(hipMemcpyAsync(tlens.data(), p->d_text_len.ptr, P * 4, hipMemcpyDeviceToHost, s), "D2H text lens") ||
             !hip_ok(hipStreamSynchronize(s), "sync"))
             return PA_E_HIP;
+        uint64_t total = 0;
+        for (size_t i = 0; i < P; ++i) {
+            dst_off[i] = total;
+            total += tlens[i];
+        }
+        packed.resize(total);
+        if (total) {
+            if (!hip_ok(hipMemcpyAsync(p->d_cig_dst_off.ptr, dst_off.data(), P * 8, hipMemcpyHostToDevice, s), "H2D offsets")) return PA_E_HIP;
+            hipLaunchKernelGGL(pack_text_kernel, dim3((unsigned)P), dim3(256), 0, s, p->d_text.as<uint8_t>(), p->d_cig_src_off.as<uint64_t>(),
+                               p->d_cig_dst_off.as<uint64_t>(), p->d_text_len.as<uint32_t>(), p->d_packed.as<uint8_t>());
+            if (!hip_ok(hipGetLastError(), "pack_text_kernel") ||
+                !hip_ok(hipMemcpyAsync(packed.data(), p->d_packed.ptr, total, hipMemcpyDeviceToHost, s), "D2H cigars") ||
+                !hip_ok(hipStreamSynchronize(s), "sync"))
+                return PA_E_HIP;
+        }
     }
     const pa_astarpa2_params fallback = traced_batch_params();
     for (size_t i = 0; i < P; ++i) {
@@ -1084,15 +1148,7 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
                 return PA_E_INTERNAL;
             }
         } else {
-            engine::Cigar cg;
-            const uint32_t* e = packed.data() + dst_off[i];
-            for (uint32_t k = lens[i]; k-- > 0;) {  // stored end -> start
-                const uint32_t op = e[k] & 3u;
-                cg.push_elem(engine::CigarElem{op == kOpMatch ? engine::CigarOp::Match : op == kOpSub ? engine::CigarOp::Sub
-                                                : op == kOpIns ? engine::CigarOp::Ins : engine::CigarOp::Del,
-                                               (engine::I)(e[k] >> 2)});
-            }
-            text = cg.to_string();
+            text.assign(reinterpret_cast<const char*>(packed.data()) + dst_off[i], tlens[i]);
         }
         cigar_out[i] = (char*)std::malloc(text.size() + 1);
         if (!cigar_out[i]) return PA_E_ARG;

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void trace_kernel(const Trac
                     for (int c = 0; c < 4; ++c) sv[lane * 4 + c] = ck ? ck[((jlo >> 6) + lane) * 4 + c] : (c < 2 ? 0xFFFFFFFFu : 0u);
                 }
                 const int32_t T0 = i0 + column_prefix(ck, jlo, lane);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // same wavefront produces and consumes: ordering only, no L2 write-back
                 StripJob j;
                 j.a_codes = tj.a_codes;
                 j.b_prof = tj.b_prof;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void trace_kernel(const Trac
                 j.ckpt_stride = 0;
                 j.pad2_ = 0;
                 run_strip<1, true, false>(j, err);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // same wavefront produces and consumes: ordering only, no L2 write-back
                 f_i0 = i0;
                 f_i1 = to_i;
                 f_jlo = jlo;
@@ -200,18 +200,61 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void trace_kernel(const Trac
             if (failed) break;
         }
         // ---- parent (trace.rs:145-228) ----
+        // Every address a step may need depends only on `to`, so all loads are issued together (one memory round trip per
+        // step instead of up to four dependent ones); the decisions below then follow the reference's order.
+        const int r = to_j - 1;
+        const int lim = to_i < to_j ? (to_i < 64 ? to_i : 64) : (to_j < 64 ? to_j : 64);
+        uint8_t ca = 0, cb = 1;
+        if (lane < lim) {
+            ca = a[to_i - 1 - lane];
+            cb = b[to_j - 1 - lane];
+        }
+        const bool in_rows = r >= f_jlo && r < f_jhi;
+        uint32_t cur_p = 0, cur_m = 0;  // the dwords of the current column that hold row r
+        if (in_rows) {
+            const gcu32 cc = filled_col(to_i);
+            const int rr = r - f_jlo;
+            cur_p = cc[(rr >> 6) * 4 + ((rr >> 5) & 1)];
+            cur_m = cc[(rr >> 6) * 4 + 2 + ((rr >> 5) & 1)];
+        }
+        // previous column: the checkpoint itself when to_i - 1 == f_i0, else a filled column
+        const bool prev_ck = (to_i - 1 == f_i0);
+        const gcu32 pc = prev_ck ? ckpt_col(f_i0) : filled_col(to_i - 1);
+        const int p_jlo = prev_ck ? 0 : f_jlo;
+        const int32_t p_top = prev_ck ? f_i0 : f_T0 + (to_i - 1 - f_i0);
+        const bool p_idx = to_j >= p_jlo;  // Block::index is defined there
+        int32_t p_part = 0;                 // this lane's share of the prefix sum of the previous column up to row to_j
+        uint32_t prev_p = 0, prev_m = 0;    // the dwords of the previous column that hold row r
+        if (!prev_ck) {                     // a filled column has at most 32 words: one word per lane
+            if (p_idx) {
+                const int rows = to_j - p_jlo, full = rows >> 6, rem = rows & 63;
+                if (lane < full || (lane == full && rem != 0)) {
+                    const uint64_t p = (uint64_t)pc[lane * 4 + 0] | ((uint64_t)pc[lane * 4 + 1] << 32);
+                    const uint64_t m = (uint64_t)pc[lane * 4 + 2] | ((uint64_t)pc[lane * 4 + 3] << 32);
+                    const uint64_t mask = lane < full ? ~0ull : ((1ull << rem) - 1ull);
+                    p_part = __builtin_popcountll(p & mask) - __builtin_popcountll(m & mask);
+                }
+            }
+            if (r >= p_jlo) {
+                const int rr = r - p_jlo;
+                prev_p = pc[(rr >> 6) * 4 + ((rr >> 5) & 1)];
+                prev_m = pc[(rr >> 6) * 4 + 2 + ((rr >> 5) & 1)];
+            }
+        }
+        // ---- decisions ----
         {  // greedy matches, 64 characters at a time
             uint32_t cnt = 0;
-            while (to_i > 0 && to_j > 0) {
-                const int lim = to_i < to_j ? (to_i < 64 ? to_i : 64) : (to_j < 64 ? to_j : 64);
-                bool eq = false;
-                if (lane < lim) eq = a[to_i - 1 - lane] == b[to_j - 1 - lane];
-                const uint64_t mask = __ballot(eq);
+            uint64_t mask = __ballot(lane < lim && ca == cb);
+            for (;;) {
                 const int run = mask == ~0ull ? 64 : __builtin_ctzll(~mask);
                 cnt += (uint32_t)run;
                 to_i -= run;
                 to_j -= run;
-                if (run < 64) break;
+                if (run < 64 || to_i == 0 || to_j == 0) break;
+                const int lim2 = to_i < to_j ? (to_i < 64 ? to_i : 64) : (to_j < 64 ? to_j : 64);
+                bool eq = false;
+                if (lane < lim2) eq = a[to_i - 1 - lane] == b[to_j - 1 - lane];
+                mask = __ballot(eq);
             }
             if (cnt > 0) {
                 emit(kOpMatch, cnt);
@@ -219,21 +262,17 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void trace_kernel(const Trac
             }
         }
         // vertical delta of the current column at row to_j - 1 (Block::get_diff)
-        const int r = to_j - 1;
-        const bool in_rows = r >= f_jlo && r < f_jhi;
-        if (in_rows && column_diff(filled_col(to_i), r - f_jlo) == 1) {
-            g -= 1;
-            to_j -= 1;
-            emit(kOpIns, 1);
-            continue;
+        if (in_rows) {
+            const uint32_t p = rfl(cur_p), m = rfl(cur_m);
+            if ((int32_t)((p >> (r & 31)) & 1u) - (int32_t)((m >> (r & 31)) & 1u) == 1) {
+                g -= 1;
+                to_j -= 1;
+                emit(kOpIns, 1);
+                continue;
+            }
         }
-        // previous column: the checkpoint itself when to_i - 1 == f_i0, else a filled column
-        const bool prev_ck = (to_i - 1 == f_i0);
-        const gcu32 pc = prev_ck ? ckpt_col(f_i0) : filled_col(to_i - 1);
-        const int p_jlo = prev_ck ? 0 : f_jlo;
-        const int32_t p_top = prev_ck ? f_i0 : f_T0 + (to_i - 1 - f_i0);
         int32_t hd = 1;
-        if (to_j >= p_jlo) hd = g - (p_top + column_prefix(pc, to_j - p_jlo, lane));
+        if (p_idx) hd = g - (p_top + (prev_ck ? column_prefix(pc, to_j, lane) : wave_sum(p_part)));
         if (hd == 1) {
             g -= 1;
             to_i -= 1;
@@ -244,7 +283,14 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void trace_kernel(const Trac
             failed = true;
             break;
         }
-        const int32_t dd = column_diff(pc, r - p_jlo) + hd;
+        int32_t pd;
+        if (prev_ck) {
+            pd = column_diff(pc, r);
+        } else {
+            const uint32_t p = rfl(prev_p), m = rfl(prev_m);
+            pd = (int32_t)((p >> (r & 31)) & 1u) - (int32_t)((m >> (r & 31)) & 1u);
+        }
+        const int32_t dd = pd + hd;
         if (dd == 1) {
             g -= 1;
             to_i -= 1;

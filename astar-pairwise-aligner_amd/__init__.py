@@ -8,3 +8,11 @@ from . import _build, aligner, capi, generate  # noqa: F401
 from .aligner import (AstarPa2, AstarPa2Params, BlockParams, astarpa2_full, astarpa2_nw,  # noqa: F401
                       astarpa2_simple, c_abi_align)
 from .capi import Batch, PaError, compute, fill, profile_build, require_gpu, search  # noqa: F401
+
+
+def align_batch(pairs):
+    """[(cost, CIGAR)] of many independent pairs, forward pass and traceback both on the GPU (pa_batch_align).
+    Same alignments as `AstarPa2Params.nw()` with sparse blocks (`pa_params_batch_align`)."""
+    from .sharding import default_align
+
+    return default_align(list(pairs))

@@ -43,22 +43,45 @@ def default_compute(pairs):
     return [int(c) for c in costs]
 
 
+def default_align(pairs):
+    """(cost, CIGAR) of `pairs` on this rank's GPU: checkpointing forward pass + device-side traceback (pa_batch_align)."""
+    from . import capi
+
+    if not pairs:
+        return []
+    batch = capi.Batch(list(pairs), trace=True)
+    try:
+        costs, cigars, _, _ = batch.align()
+    finally:
+        batch.close()
+    return [(int(c), g) for c, g in zip(costs, cigars)]
+
+
+def sharded_align(pairs: Sequence[tuple[bytes, bytes]], compute: Callable | None = None, group=None) -> list[tuple[int, str]]:
+    """(cost, CIGAR) of every pair; same sharding and the same single gather as `sharded_costs` (the variable-size
+    CIGARs travel in that one object gather)."""
+    return _sharded(pairs, compute or default_align, group, lambda x: (int(x[0]), str(x[1])), (0, ""))
+
+
 def sharded_costs(pairs: Sequence[tuple[bytes, bytes]], compute: Callable | None = None, group=None) -> list[int]:
     """Edit distance of every pair, computed by the ranks of the default (or given) process group.
     Every rank passes the same `pairs`; every rank returns the full, ordered result."""
+    return _sharded(pairs, compute or default_compute, group, int, 0)
+
+
+def _sharded(pairs, compute, group, conv, empty):
     import torch.distributed as dist
 
-    compute = compute or default_compute
     if not (dist.is_available() and dist.is_initialized()):
-        return list(compute(list(pairs)))
+        return [conv(x) for x in compute(list(pairs))]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     shards = plan_shards([work_estimate(len(a), len(b)) for a, b in pairs], world)
     mine = shards[rank]
     local = list(compute([pairs[i] for i in mine]))
     gathered: list = [None] * world
     dist.all_gather_object(gathered, list(zip(mine, local)), group=group)  # the one exchange step
-    out = [0] * len(pairs)
+    out = [empty] * len(pairs)
     for part in gathered:
         for i, c in part:
-            out[i] = int(c)
+            out[i] = conv(c)
     return out

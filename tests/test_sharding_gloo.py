@@ -37,7 +37,14 @@ def _worker(rank, world, port, q):
 
     out = sharded_costs(pairs, compute=compute)
     want = [oracle.levenshtein(a, b) for a, b in pairs]
-    q.put((rank, out == want, calls))
+    # the traceback variant gathers (cost, CIGAR): per-rank compute = the engine over the CPU oracle kernels
+    from astar_pairwise_aligner_amd.sharding import sharded_align
+
+    prm = oracle.make_params(domain="full", heuristic="none", doubling="none", block_width=256, sparse=True,
+                             incremental_doubling=False, dt_trace=False)
+    al = sharded_align(pairs[:9], compute=lambda sub: [oracle.cpu_align(a, b, prm)[:2] for a, b in sub])
+    ok_al = all(c == w and oracle.cigar_verify(g, a, b) == c for (c, g), w, (a, b) in zip(al, want, pairs))
+    q.put((rank, out == want and ok_al, calls))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -139,6 +139,7 @@ template __global__ void strip_kernel<1, true, false>(const StripJob*, int, uint
 template __global__ void strip_kernel<1, false, true>(const StripJob*, int, uint32_t*, uint32_t*);
 template __global__ void strip_kernel<2, false, false>(const StripJob*, int, uint32_t*, uint32_t*);
 template __global__ void strip_kernel<4, false, false>(const StripJob*, int, uint32_t*, uint32_t*);
+template __global__ void strip_kernel<8, false, false>(const StripJob*, int, uint32_t*, uint32_t*);
 template __global__ void pair_kernel<1>(const StripJob*, const int32_t*, int, uint32_t*);
 template __global__ void pair_kernel<2>(const StripJob*, const int32_t*, int, uint32_t*);
 template __global__ void pair_kernel<4>(const StripJob*, const int32_t*, int, uint32_t*);
@@ -316,6 +317,7 @@ bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_tic
     if (k == 1) return launch_one(strip_kernel<1, false, false>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
     if (k == 2) return launch_one(strip_kernel<2, false, false>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
     if (k == 4) return launch_one(strip_kernel<4, false, false>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
+    if (k == 8) return launch_one(strip_kernel<8, false, false>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
     set_error("unsupported strip height k=%d", k);
     return false;
 }
@@ -751,9 +753,9 @@ struct BatchShape {
     int block_waves = 1;
 };
 static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, size_t pairs, bool sequential_only = false) {
-    static const double kLone[4] = {52.9, 76.5, 121.0, 210.0}, kSatChain[3] = {50.8, 65.0, 112.5};
+    static const double kLone[4] = {52.9, 76.5, 121.0, 210.0}, kSatChain[4] = {50.8, 65.0, 112.5, 170.0};
     static const double kShare[4] = {1.0, 0.85, 0.80, 0.78};  // per-wavefront step cost at 1, 2, 3, >= 4 wavefronts per SIMD
-    static const int kK[4] = {1, 2, 4, 8};  // k = 8 is built for the sequential kernel only
+    static const int kK[4] = {1, 2, 4, 8};
     const double simds = (double)(g_device_props_cus > 0 ? g_device_props_cus : 256) * 4.0;
     int env_k = 0, env_mode = 0;
     if (const char* e = getenv("PA_STRIP_K")) {
@@ -783,7 +785,7 @@ static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, s
             seq_longest = std::max(seq_longest, Sq * (double)a_len[i]);
         }
         if (live == 0) return best_shape;
-        if (env_mode != 2 && k <= 4) {  // chained strips
+        if (env_mode != 2) {  // chained strips
             const double avg = strips / simds;
             const double per_col = avg <= 1.0 ? kLone[t] : (avg + 1.0) * kSatChain[t];
             const double cost = per_col * colsteps / strips;

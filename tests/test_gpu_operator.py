@@ -137,8 +137,6 @@ def test_batch_multi_strip_chain(pa, oracle):
 def test_batch_shapes(pa, oracle, monkeypatch, k, mode):
     """Every strip height (32*k rows per lane) and both schedules (chained strips / one wavefront per pair) give the
     same costs: ragged lengths around the lane, word and strip boundaries, empty sequences, multi-strip pairs."""
-    if mode == "chain" and k == 8:
-        pytest.skip("k = 8 strips are built for the sequential kernel only")
     monkeypatch.setenv("PA_STRIP_K", str(k))
     monkeypatch.setenv("PA_BATCH_MODE", mode)
     pairs = list(PA_TEST_PAIRS)

@@ -17,9 +17,10 @@ U64P = C.POINTER(C.c_uint64)
 EXPORTED_SYMBOLS = [
     "astarpa2_simple", "astarpa2_full", "astarpa", "astarpa_gcsh", "astarpa_free_cigar",
     "pa_last_error", "pa_device_count", "pa_set_device",
-    "pa_bp_profile_build", "pa_bp_compute", "pa_bp_fill", "pa_search",
+    "pa_bp_profile_build", "pa_bp_compute", "pa_bp_fill", "pa_search", "pa_search_trace",
     "pa_batch_create", "pa_batch_run", "pa_batch_stats", "pa_batch_shape", "pa_batch_destroy",
     "pa_batch_create_trace", "pa_batch_align", "pa_batch_trace_fallbacks", "pa_params_batch_align",
+    "pa_pairs_read", "pa_pairs_count", "pa_pairs_get", "pa_pairs_free", "pa_write_results_csv", "pa_align_file",
     "pa_align",
 ]
 
@@ -56,6 +57,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_bp_fill.restype = C.c_int32
     L.pa_search.argtypes = [vp, sz, vp, sz, C.c_float, vp]
     L.pa_search.restype = C.c_int
+    L.pa_search_trace.argtypes = [vp, sz, vp, sz, C.c_float, sz, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz)]
+    L.pa_search_trace.restype = C.c_int
     L.pa_batch_create.argtypes = [vp, vp, vp, vp, sz]
     L.pa_batch_create.restype = vp
     L.pa_batch_run.argtypes = [vp, vp, C.POINTER(C.c_float)]
@@ -69,6 +72,17 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_batch_align.restype = C.c_int
     L.pa_batch_trace_fallbacks.argtypes = [vp]
     L.pa_batch_trace_fallbacks.restype = C.c_size_t
+    L.pa_pairs_read.argtypes = [C.c_char_p]
+    L.pa_pairs_read.restype = vp
+    L.pa_pairs_count.argtypes = [vp]
+    L.pa_pairs_count.restype = sz
+    L.pa_pairs_get.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz)]
+    L.pa_pairs_get.restype = C.c_int
+    L.pa_pairs_free.argtypes = [vp]
+    L.pa_write_results_csv.argtypes = [C.c_char_p, vp, vp, sz]
+    L.pa_write_results_csv.restype = C.c_int
+    L.pa_align_file.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(sz)]
+    L.pa_align_file.restype = C.c_int
     for name in ("astarpa2_simple", "astarpa2_full", "astarpa"):
         if hasattr(L, name):
             f = getattr(L, name)
@@ -137,6 +151,57 @@ def search(pattern: bytes, text: bytes, unmatched_cost: float) -> list[int]:
     if rc != 0:
         raise PaError(f"pa_search rc={rc}: {last_error()}")
     return out.tolist()
+
+
+def search_trace(pattern: bytes, text: bytes, unmatched_cost: float, idx: int):
+    """SearchResult::trace(idx) (search.rs:125-228) -> (CIGAR string, [(text index, pattern index), ...])."""
+    L = load()
+    cig, path, npos = C.c_void_p(None), C.c_void_p(None), C.c_size_t(0)
+    rc = L.pa_search_trace(_buf(pattern), len(pattern), _buf(text), len(text), unmatched_cost, idx, C.byref(cig), C.byref(path),
+                           C.byref(npos))
+    try:
+        if rc == -1:
+            raise ValueError("unknown base")
+        if rc != 0:
+            raise PaError(f"pa_search_trace rc={rc}: {last_error()}")
+        text_cigar = C.string_at(cig.value).decode()
+        arr = np.ctypeslib.as_array(C.cast(path.value, C.POINTER(C.c_int32)), shape=(2 * npos.value,)).copy() if npos.value else np.zeros(0, np.int32)
+    finally:
+        libc = C.CDLL(None)
+        libc.free.argtypes = [C.c_void_p]
+        if cig.value:
+            libc.free(cig)
+        if path.value:
+            libc.free(path)
+    return text_cigar, [(int(arr[2 * k]), int(arr[2 * k + 1])) for k in range(npos.value)]
+
+
+def read_pairs(path: str) -> list[tuple[bytes, bytes]]:
+    """Sequence pairs of a pa-bin input file or directory (.seq / .txt / .fna / .fa / .fasta; pa-bin/src/lib.rs:67-114)."""
+    L = load()
+    h = L.pa_pairs_read(str(path).encode())
+    if not h:
+        raise PaError(last_error())
+    try:
+        out = []
+        for i in range(L.pa_pairs_count(h)):
+            a, b, al, bl = C.c_void_p(None), C.c_void_p(None), C.c_size_t(0), C.c_size_t(0)
+            L.pa_pairs_get(h, i, C.byref(a), C.byref(al), C.byref(b), C.byref(bl))
+            out.append((C.string_at(a.value, al.value) if al.value else b"", C.string_at(b.value, bl.value) if bl.value else b""))
+        return out
+    finally:
+        L.pa_pairs_free(h)
+
+
+def align_file(input_path: str, output_path: str) -> int:
+    """pa-bin's main loop on the GPU: every pair of the input gets one "{cost},{cigar}" line.  Returns the pair count."""
+    n = C.c_size_t(0)
+    rc = load().pa_align_file(str(input_path).encode(), str(output_path).encode(), C.byref(n))
+    if rc == -1:
+        raise ValueError("sequence contains a character outside ACGT")
+    if rc != 0:
+        raise PaError(f"pa_align_file rc={rc}: {last_error()}")
+    return int(n.value)
 
 
 class Batch:

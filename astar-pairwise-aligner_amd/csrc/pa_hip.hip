@@ -137,6 +137,7 @@ __global__ void build_b_batch_kernel(const uint8_t* __restrict__ b_cat, uint64_t
 template __global__ void strip_kernel<1, false, false>(const StripJob*, int, uint32_t*, uint32_t*);
 template __global__ void strip_kernel<1, true, false>(const StripJob*, int, uint32_t*, uint32_t*);
 template __global__ void strip_kernel<1, false, true>(const StripJob*, int, uint32_t*, uint32_t*);
+template __global__ void strip_kernel<1, true, true>(const StripJob*, int, uint32_t*, uint32_t*);
 template __global__ void strip_kernel<2, false, false>(const StripJob*, int, uint32_t*, uint32_t*);
 template __global__ void strip_kernel<4, false, false>(const StripJob*, int, uint32_t*, uint32_t*);
 template __global__ void strip_kernel<8, false, false>(const StripJob*, int, uint32_t*, uint32_t*);
@@ -312,6 +313,7 @@ bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_tic
         set_error("fill / scatter strips are built for k = 1 only");
         return false;
     }
+    if (scatter && fill) return launch_one(strip_kernel<1, true, true>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
     if (scatter) return launch_one(strip_kernel<1, false, true>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
     if (fill) return launch_one(strip_kernel<1, true, false>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
     if (k == 1) return launch_one(strip_kernel<1, false, false>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
@@ -585,17 +587,14 @@ __global__ void encode_text_cc_kernel(const uint8_t* __restrict__ a, int n, uint
     if (invalid) atomicOr(bad, 1u);
 }
 
-extern "C" int pa_search(const uint8_t* pattern, size_t plen, const uint8_t* text, size_t tlen, float unmatched_cost,
-                         int32_t* out) {
-    if (!ensure_device()) return PA_E_HIP;
-    if (!(unmatched_cost >= 0.0f && unmatched_cost <= 1.0f) || plen > (size_t)(1u << 30) || tlen > (size_t)(1u << 30)) {
-        set_error("pa_search: bad argument");
-        return PA_E_ARG;
-    }
-    const size_t w = (plen + 63) / 64, n = tlen;
-    // ScatterProfile of the pattern on the host (profile.rs:39-63): wildcards N/* (any), Y (C|T), R (A|G);
-    // padding rows match everything.
-    std::vector<uint64_t> prof(4 * std::max<size_t>(w, 1), 0);
+// ---- semi-global search (pa-bitpacking/src/search.rs) ------------------------------------------------------------
+namespace {
+
+// ScatterProfile of the pattern (profile.rs:39-63: wildcards N/* (any), Y (C|T), R (A|G); padding rows match everything)
+// and the left column of the search (every ceil(i / unmatched_cost)-th row costs 1, search.rs:57-65).
+int search_profile(const uint8_t* pattern, size_t plen, float unmatched_cost, std::vector<uint64_t>& prof, std::vector<uint64_t>& v0) {
+    const size_t w = (plen + 63) / 64;
+    prof.assign(4 * std::max<size_t>(w, 1), 0);
     for (size_t j = 0; j < plen; ++j) {
         int mask;
         switch (pattern[j]) {
@@ -613,8 +612,7 @@ extern "C" int pa_search(const uint8_t* pattern, size_t plen, const uint8_t* tex
     }
     for (size_t j = plen; j < w * 64; ++j)
         for (int c = 0; c < 4; ++c) prof[4 * (j / 64) + c] |= 1ull << (j % 64);
-    // left column: every ceil(i / unmatched_cost)-th row costs 1 (search.rs:57-65)
-    std::vector<uint64_t> v0(2 * std::max<size_t>(w, 1), 0);
+    v0.assign(2 * std::max<size_t>(w, 1), 0);
     if (unmatched_cost > 0.0f) {
         for (size_t i = 0;; ++i) {
             const size_t idx = (size_t)std::ceil((float)i / unmatched_cost);
@@ -622,88 +620,267 @@ extern "C" int pa_search(const uint8_t* pattern, size_t plen, const uint8_t* tex
             v0[2 * (idx / 64)] |= 1ull << (idx % 64);
         }
     }
-    std::vector<uint64_t> v(v0);
-    std::vector<uint8_t> hrow(std::max<size_t>(n, 1), 0);
-    if (n > 0 && w > 0) {
-        const size_t cw = (n + 15) / 16 + 2, ngran = rect_granules((int)n, (int)w);
-        DeviceBuf d_text, d_codes, d_prof, d_v, d_hin, d_hout, d_gran, d_jobs, d_misc;
-        if (!d_text.alloc(n) || !d_codes.alloc(cw * 4) || !d_prof.alloc(w * 32) || !d_v.alloc(w * 16) || !d_hin.alloc(n) ||
-            !d_hout.alloc(n) || !d_gran.alloc(ngran * 8) || !d_misc.alloc(16))
-            return PA_E_HIP;
-        hipStream_t s = 0;
-        bool ok = hip_ok(hipMemcpyAsync(d_text.ptr, text, n, hipMemcpyHostToDevice, s), "H2D") &&
-                  hip_ok(hipMemsetAsync(d_codes.ptr, 0, cw * 4, s), "memset") && hip_ok(hipMemsetAsync(d_misc.ptr, 0, 16, s), "memset") &&
-                  hip_ok(hipMemsetAsync(d_hin.ptr, 0, n, s), "memset h") &&  // zeros along the top: start anywhere in the text
-                  hip_ok(hipMemsetAsync(d_gran.ptr, 0, std::max<size_t>(ngran * 8, 16), s), "memset gran") &&
-                  hip_ok(hipMemcpyAsync(d_prof.ptr, prof.data(), w * 32, hipMemcpyHostToDevice, s), "H2D") &&
-                  hip_ok(hipMemcpyAsync(d_v.ptr, v.data(), w * 16, hipMemcpyHostToDevice, s), "H2D");
-        if (!ok) return PA_E_HIP;
-        const int nwords = (int)((n + 15) / 16);
-        hipLaunchKernelGGL(encode_text_cc_kernel, dim3((nwords + 255) / 256), dim3(256), 0, s, d_text.as<uint8_t>(), (int)n,
-                           d_codes.as<uint32_t>(), nwords, d_misc.as<uint32_t>() + 3);
-        std::vector<StripJob> jobs;
-        RectPlan r;
-        r.a_codes = d_codes.as<uint32_t>();
-        r.b_prof = d_prof.as<uint32_t>();
-        r.v = d_v.as<uint32_t>();
-        r.n = (int)n;
-        r.w0 = 0;
-        r.w1 = (int)w;
-        r.hin_arr = d_hin.as<uint8_t>();
-        r.hout_arr = d_hout.as<uint8_t>();
-        r.gran = d_gran.as<uint64_t>();
-        r.gran_stride = (n + 31) / 32;
-        r.sum_out = d_misc.as<int32_t>() + 2;
-        r.exact_end = true;  // scatter_profile::compute(.., exact_end = true, ..), search.rs:71
-        plan_rect(jobs, r);
-        if (!d_jobs.alloc(jobs.size() * sizeof(StripJob))) return PA_E_HIP;
-        uint32_t misc[4] = {0, 0, 0, 0};
-        ok = hip_ok(hipMemcpyAsync(d_jobs.ptr, jobs.data(), jobs.size() * sizeof(StripJob), hipMemcpyHostToDevice, s), "H2D jobs") &&
-             launch_strips(d_jobs.as<StripJob>(), (int)jobs.size(), false, d_misc.as<uint32_t>(), s, false, /*scatter=*/true) &&
-             hip_ok(hipMemcpyAsync(misc, d_misc.ptr, 16, hipMemcpyDeviceToHost, s), "D2H") &&
-             hip_ok(hipMemcpyAsync(v.data(), d_v.ptr, w * 16, hipMemcpyDeviceToHost, s), "D2H") &&
-             hip_ok(hipMemcpyAsync(hrow.data(), d_hout.ptr, n, hipMemcpyDeviceToHost, s), "D2H") && hip_ok(hipStreamSynchronize(s), "sync");
-        if (!ok) return PA_E_HIP;
-        if (misc[3]) {
-            set_error("text must be actgACTG only");
-            return PA_E_INVALID_BASE;
-        }
-        if (misc[1] != PA_ERR_NONE) {
-            set_error("device spin timeout (err=%u)", misc[1]);
-            return PA_E_TIMEOUT;
-        }
-    } else if (w > 0) {
-        // empty text: nothing to compute
+    return 0;
+}
+
+// scatter_profile::compute::<2, _, 4, FILL>(text[0..n), pattern profile, h = zeros, v, exact_end = true, values)
+// (search.rs:71,152) on the GPU: v is updated in place, hrow[n] receives the bottom-row deltas (bit0 = +1, bit1 = -1),
+// values (optional) the V of every word after every column (values[col * w + word], two u64 each).
+int search_rect(const uint8_t* text, size_t n, const std::vector<uint64_t>& prof, size_t w, std::vector<uint64_t>& v,
+                std::vector<uint8_t>& hrow, std::vector<uint64_t>* values) {
+    hrow.assign(std::max<size_t>(n, 1), 0);
+    if (values) values->assign(n * w * 2, 0);
+    if (n == 0 || w == 0) return 0;
+    const bool fill = values != nullptr;
+    const size_t cw = (n + 15) / 16 + 2, ngran = rect_granules((int)n, (int)w);
+    DeviceBuf d_text, d_codes, d_prof, d_v, d_hin, d_hout, d_gran, d_jobs, d_misc, d_values;
+    if (!d_text.alloc(n) || !d_codes.alloc(cw * 4) || !d_prof.alloc(w * 32) || !d_v.alloc(w * 16) || !d_hin.alloc(n) ||
+        !d_hout.alloc(n) || !d_gran.alloc(ngran * 8) || !d_misc.alloc(16) || (fill && !d_values.alloc(n * w * 16)))
+        return PA_E_HIP;
+    hipStream_t s = 0;
+    bool ok = hip_ok(hipMemcpyAsync(d_text.ptr, text, n, hipMemcpyHostToDevice, s), "H2D") &&
+              hip_ok(hipMemsetAsync(d_codes.ptr, 0, cw * 4, s), "memset") && hip_ok(hipMemsetAsync(d_misc.ptr, 0, 16, s), "memset") &&
+              hip_ok(hipMemsetAsync(d_hin.ptr, 0, n, s), "memset h") &&  // zeros along the top: start anywhere in the text
+              hip_ok(hipMemsetAsync(d_gran.ptr, 0, std::max<size_t>(ngran * 8, 16), s), "memset gran") &&
+              hip_ok(hipMemcpyAsync(d_prof.ptr, prof.data(), w * 32, hipMemcpyHostToDevice, s), "H2D") &&
+              hip_ok(hipMemcpyAsync(d_v.ptr, v.data(), w * 16, hipMemcpyHostToDevice, s), "H2D");
+    if (!ok) return PA_E_HIP;
+    const int nwords = (int)((n + 15) / 16);
+    hipLaunchKernelGGL(encode_text_cc_kernel, dim3((nwords + 255) / 256), dim3(256), 0, s, d_text.as<uint8_t>(), (int)n,
+                       d_codes.as<uint32_t>(), nwords, d_misc.as<uint32_t>() + 3);
+    std::vector<StripJob> jobs;
+    RectPlan r;
+    r.a_codes = d_codes.as<uint32_t>();
+    r.b_prof = d_prof.as<uint32_t>();
+    r.v = d_v.as<uint32_t>();
+    r.n = (int)n;
+    r.w0 = 0;
+    r.w1 = (int)w;
+    r.hin_arr = d_hin.as<uint8_t>();
+    r.hout_arr = d_hout.as<uint8_t>();
+    r.gran = d_gran.as<uint64_t>();
+    r.gran_stride = (n + 31) / 32;
+    r.sum_out = d_misc.as<int32_t>() + 2;
+    r.exact_end = true;
+    if (fill) {
+        r.values = d_values.as<uint32_t>();
+        r.fill_stride = (int)w;
+        r.fill_word0 = 0;
     }
+    plan_rect(jobs, r);
+    if (!d_jobs.alloc(jobs.size() * sizeof(StripJob))) return PA_E_HIP;
+    uint32_t misc[4] = {0, 0, 0, 0};
+    ok = hip_ok(hipMemcpyAsync(d_jobs.ptr, jobs.data(), jobs.size() * sizeof(StripJob), hipMemcpyHostToDevice, s), "H2D jobs") &&
+         launch_strips(d_jobs.as<StripJob>(), (int)jobs.size(), fill, d_misc.as<uint32_t>(), s, false, /*scatter=*/true) &&
+         hip_ok(hipMemcpyAsync(misc, d_misc.ptr, 16, hipMemcpyDeviceToHost, s), "D2H") &&
+         hip_ok(hipMemcpyAsync(v.data(), d_v.ptr, w * 16, hipMemcpyDeviceToHost, s), "D2H") &&
+         hip_ok(hipMemcpyAsync(hrow.data(), d_hout.ptr, n, hipMemcpyDeviceToHost, s), "D2H") &&
+         (!fill || hip_ok(hipMemcpyAsync(values->data(), d_values.ptr, n * w * 16, hipMemcpyDeviceToHost, s), "D2H values")) &&
+         hip_ok(hipStreamSynchronize(s), "sync");
+    if (!ok) return PA_E_HIP;
+    if (misc[3]) {
+        set_error("text must be actgACTG only");
+        return PA_E_INVALID_BASE;
+    }
+    if (misc[1] != PA_ERR_NONE) {
+        set_error("device spin timeout (err=%u)", misc[1]);
+        return PA_E_TIMEOUT;
+    }
+    return 0;
+}
+
+int32_t v_value(uint64_t p, uint64_t m) { return (int32_t)__builtin_popcountll(p) - (int32_t)__builtin_popcountll(m); }
+int32_t v_suffix(uint64_t p, uint64_t m, int j) {  // V::value_of_suffix, encoding.rs:35-40
+    const uint64_t mask = ~((1ull << (64 - j)) - 1);
+    return (int32_t)__builtin_popcountll(p & mask) - (int32_t)__builtin_popcountll(m & mask);
+}
+int32_t vec_value_to(const uint64_t* v, int64_t j) {  // V::value_to, encoding.rs:57-66
+    int32_t s = 0;
+    for (int64_t k = 0; k < j / 64; ++k) s += v_value(v[2 * k], v[2 * k + 1]);
+    if (j % 64 != 0) {
+        const uint64_t mask = (1ull << (j % 64)) - 1;
+        s += (int32_t)__builtin_popcountll(v[2 * (j / 64)] & mask) - (int32_t)__builtin_popcountll(v[2 * (j / 64) + 1] & mask);
+    }
+    return s;
+}
+int32_t vec_value_from(const uint64_t* v, size_t w, int64_t j) {  // V::value_from, encoding.rs:67-76
+    int32_t s = 0;
+    if (j % 64 != 0) s += v_suffix(v[2 * (j / 64)], v[2 * (j / 64) + 1], (int)(64 - j % 64));
+    for (size_t k = (size_t)((j + 63) / 64); k < w; ++k) s += v_value(v[2 * k], v[2 * k + 1]);
+    return s;
+}
+
+int search_out(const uint8_t* pattern, size_t plen, const uint8_t* text, size_t tlen, float unmatched_cost, std::vector<int32_t>& out,
+               std::vector<uint64_t>& prof, std::vector<uint64_t>& v0) {
+    if (!ensure_device()) return PA_E_HIP;
+    if (!(unmatched_cost >= 0.0f && unmatched_cost <= 1.0f) || plen > (size_t)(1u << 30) || tlen > (size_t)(1u << 30)) {
+        set_error("pa_search: bad argument");
+        return PA_E_ARG;
+    }
+    const size_t w = (plen + 63) / 64, n = tlen;
+    if (const int rc = search_profile(pattern, plen, unmatched_cost, prof, v0)) return rc;
+    std::vector<uint64_t> v(v0);
+    std::vector<uint8_t> hrow;
+    if (const int rc = search_rect(text, n, prof, w, v, hrow, nullptr)) return rc;
     // Assemble the bottom row then the right column in reverse (search.rs:73-100).
-    auto value = [](uint64_t p, uint64_t m) { return (int32_t)__builtin_popcountll(p) - (int32_t)__builtin_popcountll(m); };
-    auto suffix = [](uint64_t p, uint64_t m, int j) {
-        const uint64_t mask = ~((1ull << (64 - j)) - 1);
-        return (int32_t)__builtin_popcountll(p & mask) - (int32_t)__builtin_popcountll(m & mask);
-    };
+    out.clear();
     const size_t padding = w * 64 - plen;
     int32_t bsum = 0;
-    for (size_t j = 0; j < w; ++j) bsum += value(v0[2 * j], v0[2 * j + 1]);
-    size_t k = 0, skipped = 0;
-    out[k++] = bsum;
+    for (size_t j = 0; j < w; ++j) bsum += v_value(v0[2 * j], v0[2 * j + 1]);
+    size_t skipped = 0;
+    out.push_back(bsum);
     for (size_t i = 0; i < n; ++i) {
         bsum += (int32_t)(hrow[i] & 1) - (int32_t)((hrow[i] >> 1) & 1);
         if (skipped < padding) skipped++;
-        else out[k++] = bsum;
+        else out.push_back(bsum);
     }
     for (size_t jj = w; jj-- > 0;) {
         for (int j = 1; j <= 64; ++j) {
-            const int32_t val = bsum - suffix(v[2 * jj], v[2 * jj + 1], j) + suffix(v0[2 * jj], v0[2 * jj + 1], j);
+            const int32_t val = bsum - v_suffix(v[2 * jj], v[2 * jj + 1], j) + v_suffix(v0[2 * jj], v0[2 * jj + 1], j);
             if (skipped < padding) skipped++;
-            else out[k++] = val;
+            else out.push_back(val);
         }
-        bsum -= value(v[2 * jj], v[2 * jj + 1]);
-        bsum += value(v0[2 * jj], v0[2 * jj + 1]);
+        bsum -= v_value(v[2 * jj], v[2 * jj + 1]);
+        bsum += v_value(v0[2 * jj], v0[2 * jj + 1]);
     }
-    if (k != plen + tlen + 1) {
+    if (out.size() != plen + tlen + 1) {
         set_error("pa_search: internal length mismatch");
         return PA_E_INTERNAL;
     }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int pa_search(const uint8_t* pattern, size_t plen, const uint8_t* text, size_t tlen, float unmatched_cost,
+                         int32_t* out) {
+    std::vector<int32_t> o;
+    std::vector<uint64_t> prof, v0;
+    if (const int rc = search_out(pattern, plen, text, tlen, unmatched_cost, o, prof, v0)) return rc;
+    std::memcpy(out, o.data(), o.size() * sizeof(int32_t));
+    return 0;
+}
+
+// SearchResult::trace(idx), search.rs:104-228.
+extern "C" int pa_search_trace(const uint8_t* pattern, size_t plen, const uint8_t* text, size_t tlen, float unmatched_cost, size_t idx,
+                               char** cigar_out, int32_t** path_out, size_t* npos_out) {
+    if (cigar_out) *cigar_out = nullptr;
+    if (path_out) *path_out = nullptr;
+    if (npos_out) *npos_out = 0;
+    std::vector<int32_t> out;
+    std::vector<uint64_t> prof, v0;
+    if (const int rc = search_out(pattern, plen, text, tlen, unmatched_cost, out, prof, v0)) return rc;
+    const size_t w = (plen + 63) / 64;
+    if (idx >= out.size() || w == 0) {
+        set_error("pa_search_trace: idx out of range");
+        return PA_E_ARG;
+    }
+    // idx_to_pos, search.rs:105-115
+    int64_t pi, pj;
+    if (idx <= tlen) {
+        pi = (int64_t)idx;
+        pj = (int64_t)plen;
+    } else {
+        pi = (int64_t)tlen;
+        pj = (int64_t)plen - ((int64_t)idx - (int64_t)tlen);
+    }
+    int32_t target = out[idx];
+    if ((size_t)pi == tlen) target -= vec_value_from(v0.data(), w, pj);
+    // re-fill text[start..end) x pattern, doubling the width until the cost at `pos` is reproduced (search.rs:132-177)
+    size_t width = 2 * plen, start = 0;
+    const size_t end = (size_t)pi;
+    std::vector<uint64_t> values, first;
+    for (;;) {
+        start = end > width ? end - width : 0;
+        first = start == 0 ? v0 : std::vector<uint64_t>();
+        if (start != 0) {
+            first.assign(2 * w, 0);
+            for (size_t k = 0; k < w; ++k) first[2 * k] = ~0ull;
+        }
+        std::vector<uint64_t> v(first);
+        std::vector<uint8_t> hrow;
+        if (const int rc = search_rect(text + start, end - start, prof, w, v, hrow, &values)) return rc;
+        const int32_t cost = vec_value_to(v.data(), pj);
+        if (cost < target) {
+            set_error("pa_search_trace: found a path cheaper than the target cost");
+            return PA_E_INTERNAL;
+        }
+        if (cost == target) break;
+        if (start == 0) {
+            set_error("pa_search_trace: the full text does not reproduce the target cost");
+            return PA_E_INTERNAL;
+        }
+        width *= 2;
+    }
+    auto column = [&](int64_t i) -> const uint64_t* {  // fill[i - start]
+        return (size_t)i == start ? first.data() : values.data() + ((size_t)i - start - 1) * w * 2;
+    };
+    auto cost_at = [&](int64_t i, int64_t j) { return vec_value_to(column(i), j); };
+    auto tcode = [&](int64_t i) {  // CC order A C T G (profile.rs:23)
+        switch (text[i]) {
+            case 'a': case 'A': return 0;
+            case 'c': case 'C': return 1;
+            case 't': case 'T': return 2;
+            default: return 3;
+        }
+    };
+    engine::Cigar cigar;
+    std::vector<int32_t> path{(int32_t)pi, (int32_t)pj};
+    int32_t g = target;
+    while (pi > (int64_t)start && pj > 0) {  // search.rs:185-224
+        engine::I cnt = 0;
+        while (pi > (int64_t)start && pj > 0 && ((prof[4 * ((pj - 1) / 64) + tcode(pi - 1)] >> ((pj - 1) % 64)) & 1)) {
+            ++cnt;
+            --pi;
+            --pj;
+            path.push_back((int32_t)pi);
+            path.push_back((int32_t)pj);
+        }
+        if (cnt > 0) {
+            cigar.push_elem(engine::CigarElem{engine::CigarOp::Match, cnt});
+            continue;
+        }
+        if (cost_at(pi - 1, pj) == g - 1) {
+            --g;
+            --pi;
+            cigar.push_elem(engine::CigarElem{engine::CigarOp::Del, 1});
+        } else if (cost_at(pi, pj - 1) == g - 1) {
+            --g;
+            --pj;
+            cigar.push_elem(engine::CigarElem{engine::CigarOp::Ins, 1});
+        } else if (cost_at(pi - 1, pj - 1) == g - 1) {
+            --g;
+            --pi;
+            --pj;
+            cigar.push_elem(engine::CigarElem{engine::CigarOp::Sub, 1});
+        } else {
+            set_error("pa_search_trace: bad trace, stuck at (%lld, %lld)", (long long)pi, (long long)pj);
+            return PA_E_INTERNAL;
+        }
+        path.push_back((int32_t)pi);
+        path.push_back((int32_t)pj);
+    }
+    if (!(pi == 0 || g == 0)) {
+        set_error("pa_search_trace: trace ended inside the text with cost left");
+        return PA_E_INTERNAL;
+    }
+    cigar.reverse();
+    const std::string text_cigar = cigar.to_string();
+    const size_t np = path.size() / 2;
+    if (cigar_out) {
+        *cigar_out = (char*)std::malloc(text_cigar.size() + 1);
+        if (!*cigar_out) return PA_E_ARG;
+        std::memcpy(*cigar_out, text_cigar.c_str(), text_cigar.size() + 1);
+    }
+    if (path_out) {
+        *path_out = (int32_t*)std::malloc(std::max<size_t>(np, 1) * 2 * sizeof(int32_t));
+        if (!*path_out) return PA_E_ARG;
+        for (size_t k = 0; k < np; ++k) {
+            (*path_out)[2 * k] = path[2 * (np - 1 - k)];
+            (*path_out)[2 * k + 1] = path[2 * (np - 1 - k) + 1];
+        }
+    }
+    if (npos_out) *npos_out = np;
     return 0;
 }
 

@@ -1,0 +1,176 @@
+// pairs_io.hip -- the data formats either side of the batched aligner (host code only).
+//
+// What it restates: pa-bin's input loop and result line (pa-bin/src/lib.rs:67-114, pa-bin/src/main.rs:24-35):
+//   * `.seq`  : consecutive line pairs, the first starts with '>' and the second with '<' (both markers dropped);
+//   * `.txt`  : consecutive line pairs, plain sequences;
+//   * `.fna` / `.fa` / `.fasta` : FASTA records taken two at a time (multi-line sequences concatenated);
+//   * a directory: every file in it (sorted by name here; the reference uses the directory order);
+//   * output: one line `{cost},{cigar}` per pair.
+// Lines lose their trailing "\n" / "\r\n" like Rust's BufRead::lines; an odd trailing line or record is dropped like
+// itertools' tuples().  Nothing here touches the GPU; pa_align_file feeds the pairs to pa_batch_align.
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "pa_hip_internal.hpp"
+
+struct pa_pairs {
+    std::vector<std::string> a, b;
+};
+
+namespace {
+
+bool read_lines(const std::string& path, std::vector<std::string>& lines) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::string line;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        lines.push_back(line);
+    }
+    return true;
+}
+
+std::string extension(const std::string& path) {
+    const size_t slash = path.find_last_of('/');
+    const size_t dot = path.find_last_of('.');
+    if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return "";
+    return path.substr(dot + 1);
+}
+
+int read_file(const std::string& path, pa_pairs& out) {
+    const std::string ext = extension(path);
+    std::vector<std::string> lines;
+    if (ext == "seq" || ext == "txt") {
+        if (!read_lines(path, lines)) {
+            pa::set_error("cannot open %s", path.c_str());
+            return PA_E_ARG;
+        }
+        for (size_t i = 0; i + 1 < lines.size(); i += 2) {
+            std::string a = lines[i], b = lines[i + 1];
+            if (ext == "seq") {
+                if (a.empty() || a[0] != '>' || b.empty() || b[0] != '<') {
+                    pa::set_error("%s: line %zu: .seq pairs are a '>' line followed by a '<' line", path.c_str(), i + 1);
+                    return PA_E_ARG;
+                }
+                a.erase(0, 1);
+                b.erase(0, 1);
+            }
+            out.a.push_back(std::move(a));
+            out.b.push_back(std::move(b));
+        }
+        return 0;
+    }
+    if (ext == "fna" || ext == "fa" || ext == "fasta") {
+        if (!read_lines(path, lines)) {
+            pa::set_error("cannot open %s", path.c_str());
+            return PA_E_ARG;
+        }
+        std::vector<std::string> records;
+        bool open = false;
+        for (const std::string& l : lines) {
+            if (!l.empty() && l[0] == '>') {
+                records.emplace_back();
+                open = true;
+            } else if (open) {
+                records.back() += l;
+            } else if (!l.empty()) {
+                pa::set_error("%s: sequence data before the first FASTA header", path.c_str());
+                return PA_E_ARG;
+            }
+        }
+        for (size_t i = 0; i + 1 < records.size(); i += 2) {
+            out.a.push_back(std::move(records[i]));
+            out.b.push_back(std::move(records[i + 1]));
+        }
+        return 0;
+    }
+    pa::set_error("Unknown file extension \"%s\". Must be in {seq,txt,fna,fa,fasta}.", ext.c_str());
+    return PA_E_ARG;
+}
+
+}  // namespace
+
+extern "C" pa_pairs* pa_pairs_read(const char* path) {
+    if (!path) return nullptr;
+    auto p = std::make_unique<pa_pairs>();
+    struct stat st;
+    if (stat(path, &st) != 0) {
+        pa::set_error("%s is not a file or directory", path);
+        return nullptr;
+    }
+    if (S_ISDIR(st.st_mode)) {
+        std::vector<std::string> files;
+        if (DIR* d = opendir(path)) {
+            while (dirent* e = readdir(d)) {
+                const std::string name = e->d_name;
+                if (name != "." && name != "..") files.push_back(std::string(path) + "/" + name);
+            }
+            closedir(d);
+        }
+        std::sort(files.begin(), files.end());
+        for (const std::string& f : files)
+            if (read_file(f, *p) != 0) return nullptr;
+    } else if (read_file(path, *p) != 0) {
+        return nullptr;
+    }
+    return p.release();
+}
+
+extern "C" size_t pa_pairs_count(const pa_pairs* p) { return p ? p->a.size() : 0; }
+
+extern "C" int pa_pairs_get(const pa_pairs* p, size_t i, const uint8_t** a, size_t* a_len, const uint8_t** b, size_t* b_len) {
+    if (!p || i >= p->a.size()) return PA_E_ARG;
+    if (a) *a = reinterpret_cast<const uint8_t*>(p->a[i].data());
+    if (a_len) *a_len = p->a[i].size();
+    if (b) *b = reinterpret_cast<const uint8_t*>(p->b[i].data());
+    if (b_len) *b_len = p->b[i].size();
+    return 0;
+}
+
+extern "C" void pa_pairs_free(pa_pairs* p) { delete p; }
+
+extern "C" int pa_write_results_csv(const char* path, const int32_t* costs, const char* const* cigars, size_t n) {
+    FILE* f = std::fopen(path, "w");
+    if (!f) {
+        pa::set_error("cannot create %s", path ? path : "(null)");
+        return PA_E_ARG;
+    }
+    for (size_t i = 0; i < n; ++i) std::fprintf(f, "%d,%s\n", costs[i], cigars && cigars[i] ? cigars[i] : "");
+    return std::fclose(f) == 0 ? 0 : PA_E_ARG;
+}
+
+// pa-bin's main loop for a whole input at once: read the pairs, align them all on the GPU (cost + CIGAR), write the CSV.
+extern "C" int pa_align_file(const char* input_path, const char* output_path, size_t* pairs_out) {
+    std::unique_ptr<pa_pairs, void (*)(pa_pairs*)> in(pa_pairs_read(input_path), pa_pairs_free);
+    if (!in) return PA_E_ARG;
+    const size_t n = in->a.size();
+    if (pairs_out) *pairs_out = n;
+    std::vector<const uint8_t*> ap(n), bp(n);
+    std::vector<size_t> al(n), bl(n);
+    for (size_t i = 0; i < n; ++i) {
+        ap[i] = reinterpret_cast<const uint8_t*>(in->a[i].data());
+        bp[i] = reinterpret_cast<const uint8_t*>(in->b[i].data());
+        al[i] = in->a[i].size();
+        bl[i] = in->b[i].size();
+    }
+    std::vector<int32_t> costs(n, 0);
+    std::vector<char*> cigars(n, nullptr);
+    int rc = 0;
+    if (n) {
+        pa_batch* plan = pa_batch_create_trace(ap.data(), al.data(), bp.data(), bl.data(), n);
+        if (!plan) return PA_E_HIP;
+        rc = pa_batch_align(plan, costs.data(), cigars.data(), nullptr, nullptr);
+        pa_batch_destroy(plan);
+    }
+    if (rc == 0 && output_path) rc = pa_write_results_csv(output_path, costs.data(), cigars.data(), n);
+    for (char* c : cigars) std::free(c);
+    return rc;
+}

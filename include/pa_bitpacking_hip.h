@@ -63,6 +63,14 @@ int32_t pa_bp_fill(const uint64_t* a2, size_t n, const uint64_t* b2, size_t w, u
  * out[|pattern| + |text| + 1] = costs along the bottom row, then up the right column.  Runs the ScatterProfile
  * variant of the strip kernel (simd/scatter_profile.rs). */
 int pa_search(const uint8_t* pattern, size_t plen, const uint8_t* text, size_t tlen, float unmatched_cost, int32_t* out);
+/* SearchResult::trace(idx) (search.rs:104-228): the alignment that ends at output index idx of pa_search (bottom row left
+ * to right, then the right column upwards).  The sub-rectangle text[end - width .. end) x pattern is re-filled on the GPU
+ * (FILL variant of the scatter-profile strip kernel, width = 2|pattern| doubling) and walked back on the host in the
+ * reference's order: matches, then 'D' (one text character), 'I' (one pattern character), 'X'.
+ * *cigar_out: malloc'ed "=I4=X=" string; *path_out: malloc'ed (text index, pattern index) pairs from the start of the
+ * alignment to its end, *npos_out of them.  Release both with free(). */
+int pa_search_trace(const uint8_t* pattern, size_t plen, const uint8_t* text, size_t tlen, float unmatched_cost, size_t idx,
+                    char** cigar_out, int32_t** path_out, size_t* npos_out);
 
 /* ---- batched full-DP (cost only) on device-resident pairs ------------------------------------------ */
 /* What `AstarPa2Params::nw().make_aligner(false).cost(a,b)` computes (astarpa2/src/params.rs:46-68,
@@ -97,6 +105,18 @@ pa_batch* pa_batch_create_trace(const uint8_t* const* a, const size_t* a_len, co
 int pa_batch_align(pa_batch* plan, int32_t* cost_out, char** cigar_out, float* forward_ms, float* trace_ms);
 /* Pairs (summed over all pa_batch_align calls of this plan) whose traceback was redone by the host engine. */
 size_t pa_batch_trace_fallbacks(const pa_batch* plan);
+
+/* ---- pa-bin's data formats (pa-bin/src/lib.rs:67-114, pa-bin/src/main.rs:24-35) ------------------------- */
+/* Input: `.seq` (line pairs, '>' then '<' markers), `.txt` (plain line pairs), `.fna`/`.fa`/`.fasta` (records taken two at
+ * a time), or a directory of such files.  Output: one line "{cost},{cigar}" per pair.  Host code only. */
+typedef struct pa_pairs pa_pairs;
+pa_pairs* pa_pairs_read(const char* path); /* NULL on error (pa_last_error) */
+size_t pa_pairs_count(const pa_pairs* pairs);
+int pa_pairs_get(const pa_pairs* pairs, size_t i, const uint8_t** a, size_t* a_len, const uint8_t** b, size_t* b_len);
+void pa_pairs_free(pa_pairs* pairs);
+int pa_write_results_csv(const char* path, const int32_t* costs, const char* const* cigars, size_t n);
+/* pa-bin's main loop for a whole input at once: read, pa_batch_align every pair on the GPU, write the CSV. */
+int pa_align_file(const char* input_path, const char* output_path, size_t* pairs_out);
 
 #ifdef __cplusplus
 }

@@ -62,6 +62,8 @@ def lib() -> C.CDLL:
         L.pa_or_nw_cost.restype = C.c_int32
         L.pa_or_search.argtypes = [vp, sz, vp, sz, C.c_float, vp]
         L.pa_or_search.restype = C.c_int
+        L.pa_or_search_trace.argtypes = [vp, sz, vp, sz, C.c_float, sz, vp, sz, vp, sz, C.POINTER(sz)]
+        L.pa_or_search_trace.restype = C.c_int
         L.pa_or_levenshtein.argtypes = [vp, sz, vp, sz]
         L.pa_or_levenshtein.restype = C.c_int32
         L.pa_or_cigar_verify.argtypes = [C.c_char_p, vp, sz, vp, sz]
@@ -140,6 +142,19 @@ def search(pattern: bytes, text: bytes, unmatched_cost: float) -> list[int]:
 
 def levenshtein(a: bytes, b: bytes) -> int:
     return lib().pa_or_levenshtein(_buf(a), len(a), _buf(b), len(b))
+
+
+def search_trace(pattern: bytes, text: bytes, unmatched_cost: float, idx: int):
+    """SearchResult::trace(idx) (search.rs:125-228) -> (cigar string, [(text index, pattern index), ...])."""
+    cap = len(pattern) + len(text) + 8
+    cig = C.create_string_buffer(2 * cap)
+    path = np.zeros(2 * cap, np.int32)
+    npos = C.c_size_t(0)
+    rc = lib().pa_or_search_trace(_buf(pattern), len(pattern), _buf(text), len(text), unmatched_cost, idx, cig, 2 * cap,
+                                  _p(path), cap, C.byref(npos))
+    if rc != 0:
+        raise ValueError(f"pa_or_search_trace failed rc={rc}")
+    return cig.value.decode(), [(int(path[2 * k]), int(path[2 * k + 1])) for k in range(npos.value)]
 
 
 def cigar_verify(cigar: str, a: bytes, b: bytes) -> int:

@@ -6,6 +6,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 /* ---- encoding.rs:21-38 ------------------------------------------------------------------- */
@@ -238,6 +239,124 @@ int pa_or_search(const uint8_t* pattern, size_t plen, const uint8_t* text, size_
     }
 done:
     free(t); free(p); free(v0); free(v); free(h);
+    return rc;
+}
+
+/* ---- SearchResult::trace, search.rs:104-228 ------------------------------------------------- */
+static int32_t vec_value_to(const pa_v_t* v, int64_t j) { /* V::value_to, encoding.rs:57-66 */
+    int32_t s = 0;
+    for (int64_t k = 0; k < j / 64; ++k) s += pa_or_v_value(v[k]);
+    if (j % 64 != 0) s += pa_or_v_value_of_prefix(v[j / 64], (int)(j % 64));
+    return s;
+}
+static int32_t vec_value_from(const pa_v_t* v, size_t w, int64_t j) { /* V::value_from, encoding.rs:67-76 */
+    int32_t s = 0;
+    if (j % 64 != 0) s += pa_or_v_value_of_suffix(v[j / 64], (int)(64 - j % 64));
+    for (size_t k = (size_t)((j + 63) / 64); k < w; ++k) s += pa_or_v_value(v[k]);
+    return s;
+}
+
+int pa_or_search_trace(const uint8_t* pattern, size_t plen, const uint8_t* text, size_t tlen, float unmatched_cost,
+                       size_t idx, char* cigar_buf, size_t cigar_cap, int32_t* path_buf, size_t path_cap, size_t* npos_out) {
+    size_t w = (plen + 63) / 64;
+    int rc = -1;
+    int32_t* out = (int32_t*)malloc((plen + tlen + 1) * sizeof(int32_t));
+    uint8_t* t = (uint8_t*)malloc(tlen ? tlen : 1);
+    uint64_t (*p)[4] = (uint64_t (*)[4])calloc(w ? w : 1, sizeof(uint64_t[4]));
+    pa_v_t* v0 = (pa_v_t*)calloc(w ? w : 1, sizeof(pa_v_t));
+    pa_v_t* fill = NULL;
+    uint8_t* ops = NULL;   /* one op per step, end -> start */
+    int32_t* poss = NULL;  /* (i, j) per visited position, end -> start */
+    if (idx > plen + tlen || w == 0) goto done;
+    if (pa_or_search(pattern, plen, text, tlen, unmatched_cost, out) != 0) goto done;
+    for (size_t i = 0; i < tlen; ++i) t[i] = (uint8_t)scatter_char(text[i]);
+    for (size_t j = 0; j < plen; ++j) {
+        int mask[4];
+        scatter_mask(pattern[j], mask);
+        for (int k = 0; k < 4; ++k) p[j / 64][k] |= (uint64_t)mask[k] << (j % 64);
+    }
+    for (size_t j = plen; j < w * 64; ++j)
+        for (int k = 0; k < 4; ++k) p[j / 64][k] |= 1ull << (j % 64);
+    if (unmatched_cost > 0.0f)
+        for (size_t i = 0;; ++i) {
+            size_t k = (size_t)ceilf((float)i / unmatched_cost);
+            if (k >= plen) break;
+            v0[k / 64].p |= 1ull << (k % 64);
+        }
+    {
+        /* idx_to_pos, search.rs:105-115 */
+        int64_t pi, pj;
+        if (idx <= tlen) { pi = (int64_t)idx; pj = (int64_t)plen; }
+        else { pi = (int64_t)tlen; pj = (int64_t)plen - ((int64_t)idx - (int64_t)tlen); }
+        int32_t target = out[idx];
+        if ((size_t)pi == tlen) target -= vec_value_from(v0, w, pj);
+        size_t width = 2 * plen, end = (size_t)pi, start;
+        for (;;) { /* search.rs:140-177 */
+            start = end > width ? end - width : 0;
+            size_t cols = end - start;
+            free(fill);
+            fill = (pa_v_t*)malloc((cols + 1) * w * sizeof(pa_v_t));
+            for (size_t k = 0; k < w; ++k) fill[k] = start == 0 ? v0[k] : (pa_v_t){~0ull, 0};
+            for (size_t c = 0; c < cols; ++c) { /* h = zero along the top; one column at a time */
+                pa_h_t h = {0, 0};
+                for (size_t k = 0; k < w; ++k) {
+                    pa_v_t vv = fill[c * w + k];
+                    myers_step(p[k][t[start + c]], &h, &vv);
+                    fill[(c + 1) * w + k] = vv;
+                }
+            }
+            int32_t cost = vec_value_to(fill + cols * w, pj);
+            if (cost < target) goto done; /* "found trace path of cost < target" assert */
+            if (cost == target) break;
+            if (start == 0) goto done;
+            width *= 2;
+        }
+        size_t cap = (size_t)pi - start + (size_t)pj + 2, nops = 0, np = 0;
+        ops = (uint8_t*)malloc(cap);
+        poss = (int32_t*)malloc(2 * cap * sizeof(int32_t));
+#define COSTAT(i_, j_) vec_value_to(fill + ((size_t)(i_) - start) * w, (j_))
+        int32_t g = target;
+        poss[0] = (int32_t)pi; poss[1] = (int32_t)pj; np = 1;
+        while (pi > (int64_t)start && pj > 0) { /* search.rs:185-224 */
+            int cnt = 0;
+            while (pi > (int64_t)start && pj > 0 && ((p[(pj - 1) / 64][t[pi - 1]] >> ((pj - 1) % 64)) & 1)) {
+                ++cnt; --pi; --pj;
+                ops[nops++] = '=';
+                poss[2 * np] = (int32_t)pi; poss[2 * np + 1] = (int32_t)pj; ++np;
+            }
+            if (cnt > 0) continue;
+            if (COSTAT(pi - 1, pj) == g - 1) { --g; --pi; ops[nops++] = 'D'; }
+            else if (COSTAT(pi, pj - 1) == g - 1) { --g; --pj; ops[nops++] = 'I'; }
+            else if (COSTAT(pi - 1, pj - 1) == g - 1) { --g; --pi; --pj; ops[nops++] = 'X'; }
+            else goto done; /* "Bad trace!" */
+            poss[2 * np] = (int32_t)pi; poss[2 * np + 1] = (int32_t)pj; ++np;
+        }
+#undef COSTAT
+        if (!(pi == 0 || g == 0)) goto done;
+        /* reverse into the outputs; CIGAR in "=I4=X=" form */
+        size_t pos = 0;
+        for (size_t k = nops; k > 0;) {
+            size_t run = 1;
+            uint8_t op = ops[k - 1];
+            while (k - run > 0 && ops[k - run - 1] == op) ++run;
+            char tmp[32];
+            int len = run == 1 ? snprintf(tmp, sizeof tmp, "%c", op) : snprintf(tmp, sizeof tmp, "%zu%c", run, op);
+            if (pos + (size_t)len + 1 > cigar_cap) goto done;
+            memcpy(cigar_buf + pos, tmp, (size_t)len);
+            pos += (size_t)len;
+            k -= run;
+        }
+        cigar_buf[pos] = 0;
+        if (np > path_cap) goto done;
+        for (size_t k = 0; k < np; ++k) {
+            path_buf[2 * k] = poss[2 * (np - 1 - k)];
+            path_buf[2 * k + 1] = poss[2 * (np - 1 - k) + 1];
+        }
+        *npos_out = np;
+        rc = 0;
+    }
+done:
+    free(out); free(t); free(p); free(v0); free(fill); free(ops); free(poss);
     return rc;
 }
 

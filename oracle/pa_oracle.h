@@ -86,6 +86,12 @@ int32_t pa_or_nw_cost(const uint8_t* a, size_t n, const uint8_t* b, size_t m, in
 int pa_or_search(const uint8_t* pattern, size_t plen, const uint8_t* text, size_t tlen,
                  float unmatched_cost, int32_t* out);
 
+/* SearchResult::trace(idx), search.rs:104-228: the alignment ending at output index idx (bottom row left to right, then the
+ * right column upwards).  cigar_buf receives the "=I4=X=" string ('I' consumes a pattern row, 'D' a text column), path_buf
+ * the visited (text index, pattern index) positions from start to end.  0, or -1 where the reference would panic. */
+int pa_or_search_trace(const uint8_t* pattern, size_t plen, const uint8_t* text, size_t tlen, float unmatched_cost,
+                       size_t idx, char* cigar_buf, size_t cigar_cap, int32_t* path_buf, size_t path_cap, size_t* npos_out);
+
 /* Plain O(nm) unit-cost Levenshtein (stands in for triple_accel::levenshtein_exp, pa-test/src/lib.rs:76). */
 int32_t pa_or_levenshtein(const uint8_t* a, size_t n, const uint8_t* b, size_t m);
 

@@ -154,3 +154,18 @@ def test_bitprofile_encoding(oracle):
     assert pa["b1"].tolist() == [0, 0, full, full]
     assert pb["b0"].tolist() == [0b10101]
     assert pb["b1"].tolist() == [0b10011]
+
+
+def test_search_trace_doc_example(oracle):
+    """The documented matrix of search.rs:28-45 pins the hit "AC" at text[3..5): tracing output index 5 (cost 0) walks
+    (3,0) -> (4,1) -> (5,2) with two matches; index 4 (cost 1) needs one insertion.  The reference holds no vector for
+    SearchResult::trace itself (pa_python exposes `.out` only): everything else about it is parity unpinned."""
+    assert oracle.search_trace(b"AC", b"CTTACTTA", 0.0, 5) == ("2=", [(3, 0), (4, 1), (5, 2)])
+    out = oracle.search(b"AC", b"CTTACTTA", 0.0)
+    for idx in range(9):  # bottom row: the CIGAR's edit count is the reported cost
+        cigar, path = oracle.search_trace(b"AC", b"CTTACTTA", 0.0, idx)
+        import re
+
+        edits = sum(int(n or 1) for n, op in re.findall(r"(\d*)([=XID])", cigar) if op != "=")
+        assert edits == out[idx]
+        assert path[-1] == (idx, 2)

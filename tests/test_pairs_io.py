@@ -1,0 +1,73 @@
+"""pa-bin's input/output formats (pa-bin/src/lib.rs:67-114, main.rs:24-35) behind the C ABI: parsing is host code and
+runs without a GPU; the end-to-end `align_file` needs one."""
+import pytest
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import astar_pairwise_aligner_amd as pa
+
+    pa.capi.load()
+    return pa
+
+
+def test_seq_format(pa, tmp_path):
+    f = tmp_path / "x.seq"
+    f.write_text(">ACGT\n<ACGA\n>TT\r\n<T\r\n>dangling\n")
+    assert pa.read_pairs(f) == [(b"ACGT", b"ACGA"), (b"TT", b"T")]  # CRLF stripped, odd last line dropped
+
+
+def test_seq_format_requires_markers(pa, tmp_path):
+    f = tmp_path / "bad.seq"
+    f.write_text("ACGT\n<ACGA\n")
+    with pytest.raises(pa.PaError):
+        pa.read_pairs(f)
+
+
+def test_txt_format(pa, tmp_path):
+    f = tmp_path / "x.txt"
+    f.write_text("ACGT\nACGA\n\nGG\n")
+    assert pa.read_pairs(f) == [(b"ACGT", b"ACGA"), (b"", b"GG")]
+
+
+def test_fasta_format(pa, tmp_path):
+    f = tmp_path / "x.fa"
+    f.write_text(">r1 first\nACGT\nAC\n>r2\nACGA\n>r3\nTTT\n>r4\n\nTT\nT\n>odd\nA\n")
+    assert pa.read_pairs(f) == [(b"ACGTAC", b"ACGA"), (b"TTT", b"TTT")]
+    for ext in ("fna", "fasta"):
+        g = tmp_path / f"y.{ext}"
+        g.write_text(">a\nAC\n>b\nAG\n")
+        assert pa.read_pairs(g) == [(b"AC", b"AG")]
+
+
+def test_directory_and_unknown_extension(pa, tmp_path):
+    d = tmp_path / "in"
+    d.mkdir()
+    (d / "b.txt").write_text("C\nG\n")
+    (d / "a.seq").write_text(">A\n<T\n")
+    assert pa.read_pairs(d) == [(b"A", b"T"), (b"C", b"G")]  # files in name order
+    bad = tmp_path / "x.csv"
+    bad.write_text("A\nC\n")
+    with pytest.raises(pa.PaError):
+        pa.read_pairs(bad)
+    with pytest.raises(pa.PaError):
+        pa.read_pairs(tmp_path / "missing.seq")
+
+
+@pytest.mark.gpu
+def test_align_file_writes_cost_cigar_lines(pa, oracle, tmp_path):
+    from tests.util_seq import gen_pair
+
+    pa.require_gpu()
+    pairs = [gen_pair(n, 0.08, seed=n) for n in (50, 300, 1000, 2600)] + [(b"ACTCGCT", b"AACTCGTT")]
+    f = tmp_path / "in.seq"
+    f.write_text("".join(f">{a.decode()}\n<{b.decode()}\n" for a, b in pairs))
+    out = tmp_path / "out.csv"
+    assert pa.align_file(f, out) == len(pairs)
+    lines = out.read_text().splitlines()
+    assert len(lines) == len(pairs)
+    for (a, b), line in zip(pairs, lines):
+        cost, cigar = line.split(",")
+        assert int(cost) == oracle.levenshtein(a, b)
+        assert oracle.cigar_verify(cigar, a, b) == int(cost)
+    assert lines[-1].startswith("2,")  # astarpa-c/example.c:8-29

@@ -902,7 +902,8 @@ struct pa_batch {
     // traceback mode (pa_batch_create_trace / pa_batch_align)
     bool trace = false;
     size_t trace_fallbacks = 0;  // pairs whose traceback was redone by the host engine
-    std::vector<size_t> ckpt_off, cigar_off;  // per pair, in u32 (ckpt) / elements (cigar)
+    std::vector<size_t> ckpt_off, cigar_off, word_off;  // per pair, in u32 (ckpt) / elements (cigar) / words of b before this pair
+    DeviceBuf d_scratch_gran;
     DeviceBuf d_ckpt, d_cigar, d_cigar_len, d_costs, d_scratch_v, d_scratch_vals, d_tjobs, d_cig_src_off, d_cig_dst_off, d_packed, d_text, d_text_len;
     hipEvent_t ev2 = nullptr;
     double cells = 0, word_updates = 0, algo_bytes = 0;
@@ -1027,18 +1028,22 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
     }
     p->total_gran = tg;
     if (trace) {
-        size_t tck = 0, tcg = 0;
+        size_t tck = 0, tcg = 0, tw = 0;
         for (size_t i = 0; i < pairs; ++i) {
             const size_t w = (b_len[i] + 63) / 64;
             p->ckpt_off.push_back(tck);
             p->cigar_off.push_back(tcg);
+            p->word_off.push_back(tw);
+            tw += std::max<size_t>(w, 1);
             tck += (a_len[i] / 256 + 1) * w * 4;  // u32: one V column per 256 columns of a (slot 0 unused)
             tcg += a_len[i] + b_len[i] + 2;
         }
         if (tcg >= (size_t(1) << 62) || !p->d_ckpt.alloc(tck * 4) || !p->d_cigar.alloc(tcg * 4) || !p->d_packed.alloc(tcg) || !p->d_text.alloc(tcg) ||
             !p->d_text_len.alloc(std::max<size_t>(pairs * 4, 16)) ||
             !p->d_cigar_len.alloc(std::max<size_t>(pairs * 4, 16)) || !p->d_costs.alloc(std::max<size_t>(pairs * 4, 16)) ||
-            !p->d_scratch_v.alloc(std::max<size_t>(pairs, 1) * 32 * 16) || !p->d_scratch_vals.alloc(std::max<size_t>(pairs, 1) * 256 * 32 * 16) ||
+            // re-fill scratch: a block's sub-rectangle can be as tall as the pair (256 columns x w words of V)
+            !p->d_scratch_v.alloc(std::max<size_t>(tw, 1) * 16) || !p->d_scratch_vals.alloc(std::max<size_t>(tw, 1) * 256 * 16) ||
+            !p->d_scratch_gran.alloc(std::max<size_t>(pairs, 1) * 16 * 8) ||
             !p->d_tjobs.alloc(std::max<size_t>(pairs, 1) * sizeof(TraceJob)) || !p->d_cig_src_off.alloc(std::max<size_t>(pairs, 1) * 8) ||
             !p->d_cig_dst_off.alloc(std::max<size_t>(pairs, 1) * 8))
             return nullptr;
@@ -1118,15 +1123,17 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             t.cigar = p->d_cigar.as<uint32_t>() + p->cigar_off[i];
             t.cigar_len = p->d_cigar_len.as<uint32_t>() + i;
             t.cost_out = p->d_costs.as<int32_t>() + i;
-            t.scratch_v = p->d_scratch_v.as<uint32_t>() + i * 32 * 4;
-            t.scratch_vals = p->d_scratch_vals.as<uint32_t>() + i * 256 * 32 * 4;
+            t.scratch_v = p->d_scratch_v.as<uint32_t>() + p->word_off[i] * 4;
+            t.scratch_vals = p->d_scratch_vals.as<uint32_t>() + p->word_off[i] * 256 * 4;
+            t.scratch_gran = p->d_scratch_gran.as<uint64_t>() + i * 16;
             t.n = (int32_t)a_len[i];
             t.m = (int32_t)b_len[i];
             t.w = (int32_t)((b_len[i] + 63) / 64);
             t.cigar_cap = (uint32_t)std::min<size_t>(a_len[i] + b_len[i] + 2, 0xFFFFFFF0u);
             src_off[i] = p->cigar_off[i];
         }
-        if (!hip_ok(hipMemcpyAsync(p->d_tjobs.ptr, tjobs.data(), pairs * sizeof(TraceJob), hipMemcpyHostToDevice, p->stream), "H2D trace jobs") ||
+        if (!hip_ok(hipMemsetAsync(p->d_scratch_gran.ptr, 0, pairs * 16 * 8, p->stream), "memset trace granules") ||
+            !hip_ok(hipMemcpyAsync(p->d_tjobs.ptr, tjobs.data(), pairs * sizeof(TraceJob), hipMemcpyHostToDevice, p->stream), "H2D trace jobs") ||
             !hip_ok(hipMemcpyAsync(p->d_cig_src_off.ptr, src_off.data(), pairs * 8, hipMemcpyHostToDevice, p->stream), "H2D offsets") ||
             !hip_ok(hipStreamSynchronize(p->stream), "sync"))
             return nullptr;

@@ -11,8 +11,9 @@
 //   2. walks `parent` steps (greedy matches, then insertion / deletion / substitution, trace.rs:145-228) on those
 //      columns until it crosses the checkpoint column.
 // All control flow is wavefront-uniform; the lanes are used for the fill, for prefix sums over a column (Block::index)
-// and for 64-at-a-time match extension.  A pair that needs a taller re-fill than one strip (2048 rows) or hits a state
-// the reference itself would panic on is flagged and redone by the host engine.
+// and for 64-at-a-time match extension.  A re-fill taller than one strip (2048 rows: a huge indel inside one block) runs
+// as several strips one after the other, like pair_kernel.  A pair that hits a state the reference itself would panic on is
+// flagged and redone by the host engine.
 #pragma once
 #include "strip_kernel.hpp"
 
@@ -29,8 +30,9 @@ struct TraceJob {
     uint32_t* cigar;           // out: elements (count << 2) | op, from the END of the alignment to its start
     uint32_t* cigar_len;       // out: number of elements, or kTraceFailed
     int32_t* cost_out;         // out: the edit distance
-    uint32_t* scratch_v;       // 32 words x 4 u32
-    uint32_t* scratch_vals;    // 256 columns x 32 words x 4 u32
+    uint32_t* scratch_v;       // w words x 4 u32
+    uint32_t* scratch_vals;    // 256 columns x w words x 4 u32 (a re-fill may need the full height)
+    uint64_t* scratch_gran;    // 2 rows x 8 granules, zero between uses (multi-strip re-fills hand their bottom row down)
     int32_t n, m, w;           // |a|, |b|, words of b
     uint32_t cigar_cap;
 };
@@ -147,42 +149,41 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void trace_kernel(const Trac
                 const int jlo_raw = to_j - height > 0 ? to_j - height : 0;
                 const int jlo = jlo_raw & ~63, jhi = (to_j + 63) & ~63;
                 const int words = (jhi - jlo) >> 6;
-                if (words > 32) {  // taller than one strip: leave this pair to the host engine
-                    failed = true;
-                    break;
-                }
                 // left column = the checkpoint's words of these rows (init_v_with_overlap, blocks.rs:753-767)
-                if (lane < words) {
+                for (int wi = lane; wi < words; wi += 64) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) sv[lane * 4 + c] = ck ? ck[((jlo >> 6) + lane) * 4 + c] : (c < 2 ? 0xFFFFFFFFu : 0u);
+                    for (int c = 0; c < 4; ++c) sv[wi * 4 + c] = ck ? ck[((jlo >> 6) + wi) * 4 + c] : (c < 2 ? 0xFFFFFFFFu : 0u);
                 }
                 const int32_t T0 = i0 + column_prefix(ck, jlo, lane);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // same wavefront produces and consumes: ordering only, no L2 write-back
-                StripJob j;
-                j.a_codes = tj.a_codes;
-                j.b_prof = tj.b_prof;
-                j.v = (uint32_t*)tj.scratch_v - (size_t)(jlo >> 6) * 4;
-                j.hin_gran = nullptr;
-                j.hin_arr = nullptr;
-                j.hout_gran = nullptr;
-                j.hout_arr = nullptr;
-                j.values = tj.scratch_vals;
-                j.sum_out = nullptr;
-                j.n = cols;
-                j.word0 = jlo >> 6;
-                j.nlanes = 2 * words;
-                j.fill_stride = words;
-                j.fill_word0 = 0;
-                j.exact_tail = 1;
-                j.flags = 0;
-                j.col0 = i0;
-                j.tail_rows = -1;
-                j.k = 1;
-                j.ckpt = nullptr;
-                j.ckpt_stride = 0;
-                j.pad2_ = 0;
-                run_strip<1, true, false>(j, err);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // same wavefront produces and consumes: ordering only, no L2 write-back
+                const int S = (words + 31) >> 5;  // strips of 32 words, top to bottom
+                for (int st = 0; st < S; ++st) {
+                    StripJob j;
+                    j.a_codes = tj.a_codes;
+                    j.b_prof = tj.b_prof;
+                    j.v = (uint32_t*)tj.scratch_v - (size_t)(jlo >> 6) * 4;
+                    j.hin_gran = st > 0 ? tj.scratch_gran + (size_t)((st - 1) & 1) * 8 : nullptr;
+                    j.hin_arr = nullptr;
+                    j.hout_gran = st + 1 < S ? tj.scratch_gran + (size_t)(st & 1) * 8 : nullptr;
+                    j.hout_arr = nullptr;
+                    j.values = tj.scratch_vals;
+                    j.sum_out = nullptr;
+                    j.n = cols;
+                    j.word0 = (jlo >> 6) + 32 * st;
+                    j.nlanes = 2 * (words - 32 * st < 32 ? words - 32 * st : 32);
+                    j.fill_stride = words;
+                    j.fill_word0 = 32 * st;
+                    j.exact_tail = 1;
+                    j.flags = 0;
+                    j.col0 = i0;
+                    j.tail_rows = -1;
+                    j.k = 1;
+                    j.ckpt = nullptr;
+                    j.ckpt_stride = 0;
+                    j.pad2_ = 0;
+                    run_strip<1, true, false>(j, err);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                }
                 f_i0 = i0;
                 f_i1 = to_i;
                 f_jlo = jlo;
@@ -225,8 +226,9 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void trace_kernel(const Trac
         const bool p_idx = to_j >= p_jlo;  // Block::index is defined there
         int32_t p_part = 0;                 // this lane's share of the prefix sum of the previous column up to row to_j
         uint32_t prev_p = 0, prev_m = 0;    // the dwords of the previous column that hold row r
-        if (!prev_ck) {                     // a filled column has at most 32 words: one word per lane
-            if (p_idx) {
+        const bool p_wide = !prev_ck && f_words > 64;  // a multi-strip re-fill: use the general column sum below
+        if (!prev_ck) {                     // a filled column of up to 64 words: one word per lane
+            if (p_idx && !p_wide) {
                 const int rows = to_j - p_jlo, full = rows >> 6, rem = rows & 63;
                 if (lane < full || (lane == full && rem != 0)) {
                     const uint64_t p = (uint64_t)pc[lane * 4 + 0] | ((uint64_t)pc[lane * 4 + 1] << 32);
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void trace_kernel(const Trac
             }
         }
         int32_t hd = 1;
-        if (p_idx) hd = g - (p_top + (prev_ck ? column_prefix(pc, to_j, lane) : wave_sum(p_part)));
+        if (p_idx) hd = g - (p_top + (prev_ck ? column_prefix(pc, to_j, lane) : (p_wide ? column_prefix(pc, to_j - p_jlo, lane) : wave_sum(p_part))));
         if (hd == 1) {
             g -= 1;
             to_i -= 1;

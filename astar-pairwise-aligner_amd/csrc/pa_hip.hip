@@ -141,6 +141,10 @@ template __global__ void strip_kernel<1, true, true>(const StripJob*, int, uint3
 template __global__ void strip_kernel<2, false, false>(const StripJob*, int, uint32_t*, uint32_t*);
 template __global__ void strip_kernel<4, false, false>(const StripJob*, int, uint32_t*, uint32_t*);
 template __global__ void strip_kernel<8, false, false>(const StripJob*, int, uint32_t*, uint32_t*);
+template __global__ void strip_kernel<1, false, false, true>(const StripJob*, int, uint32_t*, uint32_t*);
+template __global__ void strip_kernel<2, false, false, true>(const StripJob*, int, uint32_t*, uint32_t*);
+template __global__ void strip_kernel<4, false, false, true>(const StripJob*, int, uint32_t*, uint32_t*);
+template __global__ void strip_kernel<8, false, false, true>(const StripJob*, int, uint32_t*, uint32_t*);
 template __global__ void pair_kernel<1>(const StripJob*, const int32_t*, int, uint32_t*);
 template __global__ void pair_kernel<2>(const StripJob*, const int32_t*, int, uint32_t*);
 template __global__ void pair_kernel<4>(const StripJob*, const int32_t*, int, uint32_t*);
@@ -301,7 +305,7 @@ static bool launch_one(Kern kern, int grid, int block_waves, unsigned lds, hipSt
 }
 
 bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_ticket_err, hipStream_t s, bool zero_ticket, bool scatter,
-                   int k, int block_waves) {
+                   int k, int block_waves, bool ckpt) {
     if (njobs == 0) return true;
     // d_ticket_err[0] = ticket, [1] = err
     if (zero_ticket && !hip_ok(hipMemsetAsync(d_ticket_err, 0, 2 * sizeof(uint32_t), s), "memset ticket")) return false;
@@ -309,9 +313,15 @@ bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_tic
     const int grid = (njobs + block_waves - 1) / block_waves;  // one wave per job; jobs beyond residency queue behind their
                                                                // producers (ticket order)
     const unsigned lds = block_waves == kStripBlockWaves ? residency_lds_bytes(grid) : 0;
-    if ((scatter || fill) && k != 1) {
-        set_error("fill / scatter strips are built for k = 1 only");
+    if ((scatter || fill) && (k != 1 || ckpt)) {
+        set_error("fill / scatter strips are built for k = 1 without checkpoints only");
         return false;
+    }
+    if (ckpt) {
+        if (k == 1) return launch_one(strip_kernel<1, false, false, true>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
+        if (k == 2) return launch_one(strip_kernel<2, false, false, true>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
+        if (k == 4) return launch_one(strip_kernel<4, false, false, true>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
+        if (k == 8) return launch_one(strip_kernel<8, false, false, true>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
     }
     if (scatter && fill) return launch_one(strip_kernel<1, true, true>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
     if (scatter) return launch_one(strip_kernel<1, false, true>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
@@ -930,7 +940,7 @@ struct BatchShape {
     bool sequential = false;
     int block_waves = 1;
 };
-static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, size_t pairs, bool sequential_only = false) {
+static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, size_t pairs) {
     static const double kLone[4] = {52.9, 76.5, 121.0, 210.0}, kSatChain[4] = {50.8, 65.0, 112.5, 170.0};
     static const double kShare[4] = {1.0, 0.85, 0.80, 0.78};  // per-wavefront step cost at 1, 2, 3, >= 4 wavefronts per SIMD
     static const int kK[4] = {1, 2, 4, 8};
@@ -941,7 +951,6 @@ static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, s
         if (k == 1 || k == 2 || k == 4 || k == 8) env_k = k;
     }
     if (const char* e = getenv("PA_BATCH_MODE")) env_mode = !strcmp(e, "seq") ? 2 : (!strcmp(e, "chain") ? 1 : 0);
-    if (sequential_only) env_mode = 2;  // the checkpointing forward pass is built for the sequential kernel
     BatchShape best_shape;
     double best = -1;
     for (int t = 0; t < 4; ++t) {
@@ -997,7 +1006,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
     p->pairs = pairs;
     p->trace = trace;
     {
-        const BatchShape sh = choose_batch_shape(a_len, b_len, pairs, /*sequential_only=*/trace);
+        const BatchShape sh = choose_batch_shape(a_len, b_len, pairs);
         p->k = sh.k;
         p->sequential = sh.sequential;
         p->block_waves = sh.block_waves;
@@ -1054,10 +1063,15 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
     if (!hip_ok(hipStreamCreate(&p->stream), "hipStreamCreate") || !hip_ok(hipEventCreate(&p->ev0), "event") ||
         !hip_ok(hipEventCreate(&p->ev1), "event") || !hip_ok(hipEventCreate(&p->ev2), "event"))
         return nullptr;
-    for (size_t i = 0; i < pairs; ++i) {
-        if (a_len[i] && !hip_ok(hipMemcpyAsync(p->d_a.as<uint8_t>() + p->a_off[i], a[i], a_len[i], hipMemcpyHostToDevice, p->stream), "H2D a"))
-            return nullptr;
-        if (b_len[i] && !hip_ok(hipMemcpyAsync(p->d_b.as<uint8_t>() + p->b_off[i], b[i], b_len[i], hipMemcpyHostToDevice, p->stream), "H2D b"))
+    {  // one upload per side: gather the sequences into the device layout on the host first
+        std::vector<uint8_t> ha(ta, 0), hb(tb, 0);
+        for (size_t i = 0; i < pairs; ++i) {
+            if (a_len[i]) std::memcpy(ha.data() + p->a_off[i], a[i], a_len[i]);
+            if (b_len[i]) std::memcpy(hb.data() + p->b_off[i], b[i], b_len[i]);
+        }
+        if ((ta && !hip_ok(hipMemcpyAsync(p->d_a.ptr, ha.data(), ta, hipMemcpyHostToDevice, p->stream), "H2D a")) ||
+            (tb && !hip_ok(hipMemcpyAsync(p->d_b.ptr, hb.data(), tb, hipMemcpyHostToDevice, p->stream), "H2D b")) ||
+            !hip_ok(hipStreamSynchronize(p->stream), "sync"))
             return nullptr;
     }
     // Jobs: pair-major, strips of a pair consecutive (ticket order == dependency order).
@@ -1188,7 +1202,7 @@ static int batch_forward(pa_batch* p) {
         if (!launch_pairs(p->d_jobs.as<StripJob>(), p->d_first.as<int32_t>(), (int)p->pairs, p->d_misc.as<uint32_t>(), s, p->k, p->trace))
             return PA_E_HIP;
     } else if (!launch_strips(p->d_jobs.as<StripJob>(), (int)p->jobs.size(), false, p->d_misc.as<uint32_t>(), s, false, false, p->k,
-                              p->block_waves)) {
+                              p->block_waves, p->trace)) {
         return PA_E_HIP;
     }
     if (!hip_ok(hipEventRecord(p->ev1, s), "event")) return PA_E_HIP;

@@ -65,7 +65,7 @@ struct StripPlan {
 StripPlan strip_plan(int w, int k, bool sequential);
 size_t rect_granules(int n, int w, int k = 1, bool pingpong = false);
 bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_ticket_err, hipStream_t s, bool zero_ticket = true,
-                   bool scatter = false, int k = 1, int block_waves = kStripBlockWaves);
+                   bool scatter = false, int k = 1, int block_waves = kStripBlockWaves, bool ckpt = false);
 bool launch_pairs(const StripJob* d_jobs, const int32_t* d_first, int npairs, uint32_t* d_ticket_err, hipStream_t s, int k, bool ckpt = false);
 int align_hip(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params& params, bool trace, bool self_check,
               int32_t* cost_out, std::string* cigar_out, pa_astarpa2_stats* stats_out);

@@ -490,7 +490,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
 // crowded SIMD, so balance is worth more than anything else at 1-4 wavefronts per SIMD.
 // `ticket` and `err` must be zeroed (and every hin/hout granule buffer cleared) before the launch.
 constexpr int kStripBlockWaves = 4;
-template <int K, bool FILL, bool SCATTER = false>
+template <int K, bool FILL, bool SCATTER = false, bool CKPT = false>
 __global__ __launch_bounds__(64 * kStripBlockWaves) void strip_kernel(const StripJob* __restrict__ jobs, int njobs,
                                                    uint32_t* ticket, uint32_t* err) {
     uint32_t t = 0;
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void strip_kernel(const Stri
     PA_DBG(0, t + 1);
     if (t < (uint32_t)njobs) {
         const StripJob job = jobs[t];
-        run_strip<K, FILL, SCATTER>(job, err);
+        run_strip<K, FILL, SCATTER, CKPT>(job, err);
     }
     PA_DBG(0, 0x1000 + t);
 }

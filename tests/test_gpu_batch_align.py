@@ -51,6 +51,18 @@ def test_small_and_boundaries(pa, oracle):
     check(pa, oracle, pairs)
 
 
+@pytest.mark.parametrize("k", [1, 2, 4, 8])
+@pytest.mark.parametrize("mode", ["chain", "seq"])
+def test_every_forward_shape_checkpoints_the_same_columns(pa, oracle, monkeypatch, k, mode):
+    """The checkpointing forward pass exists for chained strips and for one-wavefront-per-pair, at every strip height."""
+    monkeypatch.setenv("PA_STRIP_K", str(k))
+    monkeypatch.setenv("PA_BATCH_MODE", mode)
+    rows = 2048 * k
+    pairs = [gen_pair(n, 0.07, seed=n + k) for n in (300, 1000, rows + 70, 2 * rows + 300)]
+    pairs.append((rand_seq(600, seed=3), rand_seq(rows + 2500, seed=4)))
+    check(pa, oracle, pairs)
+
+
 def test_indels_and_unequal_lengths(pa, oracle):
     a = rand_seq(3000, seed=5)
     pairs = [

@@ -271,8 +271,11 @@ __device__ __forceinline__ bool resolve_granule(gcu64 g, uint64_t pre, int q, ui
 
 // Process one strip.  On a spin timeout the error word is set and the strip stops early.
 // K = 32-row subwords per lane: the strip covers 64*K subwords = 32*K reference words.
-template <int K, bool FILL, bool SCATTER, bool CKPT = false>
+// LOCAL: the granules are produced and consumed by the SAME wavefront (pair_kernel, trace_kernel): workgroup-scope
+// accesses, so the rows stay in the L2 instead of being written through / fetched around it 8 bytes at a time.
+template <int K, bool FILL, bool SCATTER, bool CKPT = false, bool LOCAL = false>
 __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
+    constexpr int kGranScope = LOCAL ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT;
     const int lane = (int)(threadIdx.x & 63);
     const int n = job.n;
     const int C = (n + 31) >> 5;  // 32-column chunks == granules
@@ -353,7 +356,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
     };
     auto load_gran = [&](int q) -> uint64_t {
         const int qq = q < Cm1 ? q : Cm1;
-        return __hip_atomic_load(gran_src + (has_gran ? qq : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __hip_atomic_load(gran_src + (has_gran ? qq : 0), __ATOMIC_RELAXED, kGranScope);
     };
     // Publish granule g (columns 32g..32g+31 of the bottom row) from lane 63's lagged accumulators.
     auto publish = [&](int g) {
@@ -368,7 +371,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
         if (job.hout_gran) {
             if (lane == 0)
                 __hip_atomic_store((gu64)job.hout_gran + g, (((uint64_t)vhi << 32) | (uint64_t)vlo) + kGranuleBias,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                   __ATOMIC_RELAXED, kGranScope);
         }
         if (job.hout_arr) {
             if (lane < 32 && lane < cols) {
@@ -410,7 +413,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
             alive = resolve_granule(g_gran, gran_next, q, glo, ghi);
             hin2 = ((upper ? ghi : glo) << sh) & 0xC0000000u;
             // every granule has exactly one consumer: hand it back zeroed, so the buffer needs clearing only once
-            if (lane == 0) __hip_atomic_store((gu64)job.hin_gran + q, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store((gu64)job.hin_gran + q, (uint64_t)0, __ATOMIC_RELAXED, kGranScope);
         }
         const uint32_t XS = code | hin2;
         // ---- publish the granule completed by the previous chunk (q-1) ----
@@ -579,10 +582,10 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void pair_kernel(const Strip
     for (int j = j0; j < j1; ++j) {
         const StripJob job = jobs[j];
         // the ragged bottom of a pair runs as short 32-row-per-lane strips instead of one mostly empty tall one
-        if (K > 1 && job.k == 1) run_strip<1, false, false, CKPT>(job, err);
-        else run_strip<K, false, false, CKPT>(job, err);
-        // the next strip reads what this one stored (granules, through the L2): drain and order the stores first
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        if (K > 1 && job.k == 1) run_strip<1, false, false, CKPT, true>(job, err);
+        else run_strip<K, false, false, CKPT, true>(job, err);
+        // the next strip reads what this one stored (granules): drain and order the stores first (same wavefront, same CU)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
 }
 

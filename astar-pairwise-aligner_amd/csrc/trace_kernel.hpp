@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void trace_kernel(const Trac
                     j.ckpt = nullptr;
                     j.ckpt_stride = 0;
                     j.pad2_ = 0;
-                    run_strip<1, true, false>(j, err);
+                    run_strip<1, true, false, false, true>(j, err);
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 }
                 f_i0 = i0;

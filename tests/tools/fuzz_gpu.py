@@ -1,6 +1,6 @@
 """Randomised parity soak: random batch shapes (strip height, chained / sequential), ragged sizes and divergences;
 costs against the oracle, traced batches against the CPU-kernel engine's cost AND CIGAR string.
-Usage: python tools/fuzz_gpu.py SECONDS [SEED]"""
+Usage: python tests/tools/fuzz_gpu.py SECONDS [SEED]"""
 import os
 import sys
 import time

@@ -104,3 +104,30 @@ def test_100kbp_cost_and_valid_cigar(pa, oracle):
     want_cost, want_cigar, _ = oracle.cpu_align(a, b, traced_params(oracle))
     assert (costs[0], cigars[0]) == (want_cost, want_cigar)
     batch.close()
+
+
+def test_edge_batches(pa, oracle):
+    """Empty batch, a batch of empty pairs, an invalid base: same error behaviour as the cost-only batch."""
+    b0 = pa.Batch([], trace=True)
+    costs, cigars, _, _ = b0.align()
+    assert len(costs) == 0 and cigars == []
+    b0.close()
+    b1 = pa.Batch([(b"", b""), (b"", b"ACG"), (b"TT", b"")], trace=True)
+    costs, cigars, _, _ = b1.align()
+    assert costs.tolist() == [0, 3, 2] and cigars == ["", "3I", "2D"]
+    b1.close()
+    with pytest.raises(ValueError):
+        pa.Batch([(b"ACGTN", b"ACGT")], trace=True).align()
+    with pytest.raises(pa.PaError):
+        pa.Batch([(b"ACGT", b"ACGT")]).align()  # not a traced batch
+
+
+def test_batch_align_equals_engine_with_pa_params_batch_align(pa):
+    """`pa_params_batch_align` names the parameter set: the HIP block engine with it returns the same cost and CIGAR."""
+    pairs = [gen_pair(n, 0.06, seed=n) for n in (100, 777, 3000)]
+    got = pa.align_batch(pairs)
+    p = pa.AstarPa2Params.nw()
+    p.front.sparse = True
+    al = p.make_aligner(True)
+    for (a, b), (c, g) in zip(pairs, got):
+        assert al.align(a, b) == (c, g)

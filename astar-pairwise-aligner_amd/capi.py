@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "pa_last_error", "pa_device_count", "pa_set_device",
     "pa_bp_profile_build", "pa_bp_compute", "pa_bp_fill", "pa_search", "pa_search_trace",
     "pa_batch_create", "pa_batch_run", "pa_batch_stats", "pa_batch_shape", "pa_batch_destroy",
-    "pa_batch_create_trace", "pa_batch_align", "pa_batch_trace_fallbacks", "pa_params_batch_align",
+    "pa_batch_create_banded", "pa_batch_create_trace", "pa_batch_align", "pa_batch_trace_fallbacks", "pa_params_batch_align",
     "pa_pairs_read", "pa_pairs_count", "pa_pairs_get", "pa_pairs_free", "pa_write_results_csv", "pa_align_file",
     "pa_align",
 ]
@@ -66,6 +66,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_batch_stats.argtypes = [vp] + [C.POINTER(C.c_double)] * 4
     L.pa_batch_shape.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.pa_batch_destroy.argtypes = [vp]
+    L.pa_batch_create_banded.argtypes = [vp, vp, vp, vp, sz, C.c_float]
+    L.pa_batch_create_banded.restype = vp
     L.pa_batch_create_trace.argtypes = [vp, vp, vp, vp, sz]
     L.pa_batch_create_trace.restype = vp
     L.pa_batch_align.argtypes = [vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -207,7 +209,8 @@ def align_file(input_path: str, output_path: str) -> int:
 class Batch:
     """Device-resident batch of independent pairs; run() = full-DP edit distance of every pair."""
 
-    def __init__(self, pairs: list[tuple[bytes, bytes]], trace: bool = False):
+    def __init__(self, pairs: list[tuple[bytes, bytes]], trace: bool = False, band: float | None = None):
+        """band: expected edit rate (e.g. 0.05) -> diagonal-band DP, re-run wider where it was too narrow (still exact)."""
         L = load()
         self._keep = pairs
         self.trace = trace
@@ -216,7 +219,12 @@ class Batch:
         bp = (C.c_void_p * n)(*[C.cast(C.c_char_p(b), C.c_void_p) for _, b in pairs])
         al = (C.c_size_t * n)(*[len(a) for a, _ in pairs])
         bl = (C.c_size_t * n)(*[len(b) for _, b in pairs])
-        self._h = (L.pa_batch_create_trace if trace else L.pa_batch_create)(ap, al, bp, bl, n)
+        if band is not None and trace:
+            raise ValueError("banded batches are cost-only")
+        if band is not None:
+            self._h = L.pa_batch_create_banded(ap, al, bp, bl, n, C.c_float(band))
+        else:
+            self._h = (L.pa_batch_create_trace if trace else L.pa_batch_create)(ap, al, bp, bl, n)
         if not self._h:
             raise PaError(last_error())
         self.pairs = n

@@ -909,6 +909,11 @@ struct pa_batch {
     bool sequential = false;  // one wavefront per pair (pair_kernel) instead of chained strips
     int block_waves = 1;
     DeviceBuf d_first;  // sequential: first job of every pair (+ end)
+    // banded mode (pa_batch_create_banded): per-pair cost threshold of the diagonal band that was planned
+    bool banded = false;
+    std::vector<int32_t> band_t;
+    size_t band_retries = 0;  // pairs re-run with a wider band (summed over passes)
+    DeviceBuf d_rjobs, d_rfirst;  // retry sub-batches
     // traceback mode (pa_batch_create_trace / pa_batch_align)
     bool trace = false;
     size_t trace_fallbacks = 0;  // pairs whose traceback was redone by the host engine
@@ -999,13 +1004,107 @@ static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, s
     return best_shape;
 }
 
+// ---- banded sequential pairs (Ukkonen band, the reference's GapGap domain: astarpa2/src/domain.rs:97-116) ----------------
+// With a cost threshold t the optimal path of a pair whose distance is <= t stays on the diagonals x = i - j with
+// |x| + |(n - m) - x| <= t, i.e. x in [(d - t) / 2, (d + t) / 2], d = n - m.  A strip of rows [R0, R1) therefore only needs
+// the columns [R0 + xlo, R1 + xhi): everything left of them enters as +1 deltas (V::one on the left edge, H::one on the
+// part of the top row the strip above did not reach), which can only over-estimate.  If the resulting cost is <= t it is
+// exact (the optimal path never left the computed cells); otherwise the pair is re-run with a wider band.
+static void plan_banded_pair(pa_batch* p, size_t i, int32_t t, std::vector<StripJob>& jobs) {
+    const int n = (int)p->n[i], m = (int)p->m[i], w = (m + 63) / 64;
+    if (n == 0 || w == 0) return;
+    const long d = (long)n - (long)m;
+    if ((long)t < std::labs(d)) t = (int32_t)std::labs(d);
+    const long xlo = (d - t) / 2 - 1, xhi = (d + t + 1) / 2 + 1;  // one diagonal of slack on either side
+    const StripPlan sp = strip_plan(w, p->k, true);
+    const int S = sp.strips(), wps = kWordsPerStrip * p->k;
+    const size_t G = (size_t)n / 32 + 2;
+    uint64_t* rows = p->d_gran.as<uint64_t>() + p->gran_off[i];
+    int word = 0, prev_c0 = 0, prev_c1 = 0;
+    for (int s = 0; s < S; ++s) {
+        const bool tall = s < sp.full;
+        const int words = std::min(tall ? wps : kWordsPerStrip, w - word);
+        const long R0 = 64L * word, R1 = 64L * (word + words);
+        long c0 = std::max(0L, R0 + xlo) & ~31L, c1 = std::min<long>(n, (std::max(0L, R1 + xhi) + 31) & ~31L);
+        if (s + 1 == S) c1 = n;
+        if (s == 0) c0 = 0;
+        c0 = std::min<long>(c0, std::max(0, prev_c1 - 32) & ~31);  // never leave a gap to the strip above ...
+        c0 = std::max<long>(c0, prev_c0);                          // ... and never read granules it did not write
+        if (c1 < prev_c1) c1 = prev_c1;
+        if (c1 <= c0) c1 = std::min<long>(n, c0 + 32);
+        StripJob j;
+        std::memset(&j, 0, sizeof j);
+        j.k = tall ? p->k : 1;
+        j.a_codes = p->d_codes.as<uint32_t>() + p->code_off[i];
+        j.b_prof = p->d_prof.as<uint32_t>() + p->prof_off[i] * 4;
+        j.v = p->d_v.as<uint32_t>() + p->prof_off[i] * 4;
+        j.n = (int)(c1 - c0);
+        j.col0 = (int)c0;
+        j.word0 = word;
+        j.nlanes = 2 * words;
+        j.flags = kJobVInitOne;
+        j.tail_rows = m;
+        j.exact_tail = 1;  // the bottom row feeds the strip below
+        if (s > 0) {
+            j.hin_gran = rows + (size_t)((s - 1) & 1) * G + (size_t)(c0 / 32);
+            j.hin_n = std::max(32, prev_c1 - (int)c0);
+        }
+        if (s + 1 < S) j.hout_gran = rows + (size_t)(s & 1) * G + (size_t)(c0 / 32);
+        else j.exact_tail = 0;
+        j.vsum_out = p->d_sums.as<int32_t>() + i;
+        jobs.push_back(j);
+        prev_c0 = (int)c0;
+        prev_c1 = (int)c1;
+        word += words;
+    }
+}
+
+// Strip height of a banded batch: minimise (strips x (strip rows + band width)) x instructions per step.
+static int choose_band_k(const pa_batch* p) {
+    if (const char* e = getenv("PA_STRIP_K")) {
+        const int k = atoi(e);
+        if (k == 1 || k == 2 || k == 4 || k == 8) return k;
+    }
+    static const double kLone[4] = {52.9, 76.5, 121.0, 210.0};
+    static const int kK[4] = {1, 2, 4, 8};
+    int best_k = 1;
+    double best = -1;
+    for (int t = 0; t < 4; ++t) {
+        double cost = 0;
+        for (size_t i = 0; i < p->pairs; ++i) {
+            const double w = (double)((p->m[i] + 63) / 64), rows = 2048.0 * kK[t];
+            const double S = std::ceil(w * 64.0 / rows);
+            cost += S * (std::min(rows, w * 64.0) + (double)p->band_t[i] + 128.0) * kLone[t];
+        }
+        if (best < 0 || cost < best) {
+            best = cost;
+            best_k = kK[t];
+        }
+    }
+    return best_k;
+}
+
 static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len, size_t pairs,
-                              bool trace) {
+                              bool trace, float band_hint = -1.f) {
     if (!ensure_device()) return nullptr;
     auto p = std::make_unique<pa_batch>();
     p->pairs = pairs;
     p->trace = trace;
-    {
+    p->banded = band_hint >= 0.f;
+    if (p->banded) {
+        for (size_t i = 0; i < pairs; ++i) {
+            p->n.push_back(a_len[i]);
+            p->m.push_back(b_len[i]);
+            const double len = (double)std::max(a_len[i], b_len[i]);
+            const long d = std::labs((long)a_len[i] - (long)b_len[i]);
+            p->band_t.push_back((int32_t)std::min<double>(d + std::ceil(band_hint * len) + 32, (double)a_len[i] + (double)b_len[i] + 64));
+        }
+        p->k = choose_band_k(p.get());
+        p->n.clear();
+        p->m.clear();
+        p->sequential = true;
+        p->block_waves = kStripBlockWaves;
+    } else {
         const BatchShape sh = choose_batch_shape(a_len, b_len, pairs);
         p->k = sh.k;
         p->sequential = sh.sequential;
@@ -1029,7 +1128,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
         tb += (b_len[i] + 15) & ~size_t(15);
         tc += (a_len[i] + 15) / 16;
         tp += w;
-        tg += rect_granules((int)a_len[i], (int)w, p->k, p->sequential);
+        tg += p->banded ? 2 * (a_len[i] / 32 + 2) : rect_granules((int)a_len[i], (int)w, p->k, p->sequential);
         p->cells += (double)a_len[i] * (double)b_len[i];
         p->word_updates += (double)a_len[i] * (double)w;
         // algorithmic HBM bytes, cost-only rectangle: 0.75 B/column + 48 B/word
@@ -1082,6 +1181,12 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
         first[i + 1] = first[i];
         const int w = (int)((b_len[i] + 63) / 64);
         if (w == 0 || a_len[i] == 0) continue;
+        if (p->banded) {
+            plan_banded_pair(p.get(), i, p->band_t[i], p->jobs);
+            p->last_job[i] = (int)p->jobs.size() - 1;
+            first[i + 1] = (int32_t)p->jobs.size();
+            continue;
+        }
         RectPlan r;
         r.a_codes = p->d_codes.as<uint32_t>() + p->code_off[i];
         r.b_prof = p->d_prof.as<uint32_t>() + p->prof_off[i] * 4;
@@ -1165,6 +1270,15 @@ extern "C" pa_batch* pa_batch_create(const uint8_t* const* a, const size_t* a_le
     return batch_create(a, a_len, b, b_len, pairs, false);
 }
 
+extern "C" pa_batch* pa_batch_create_banded(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b,
+                                            const size_t* b_len, size_t pairs, float divergence_hint) {
+    if (!(divergence_hint >= 0.f)) {
+        set_error("pa_batch_create_banded: divergence_hint must be >= 0");
+        return nullptr;
+    }
+    return batch_create(a, a_len, b, b_len, pairs, false, divergence_hint);
+}
+
 extern "C" pa_batch* pa_batch_create_trace(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b,
                                            const size_t* b_len, size_t pairs) {
     return batch_create(a, a_len, b, b_len, pairs, true);
@@ -1209,6 +1323,76 @@ static int batch_forward(pa_batch* p) {
     return 0;
 }
 
+// Banded pass: cost = n + (sum over the pair's strips of their right-edge vertical deltas).  A cost above the band's
+// threshold is only an upper bound: those pairs run again with a wider band (at most up to the bound itself, which is then
+// certainly wide enough), and the thresholds that worked are kept for the next pass over the same batch.
+static int banded_finish(pa_batch* p, std::vector<int32_t>& sums, int32_t* cost_out, float* kernel_ms) {
+    hipStream_t s = p->stream;
+    std::vector<size_t> todo;
+    for (size_t i = 0; i < p->pairs; ++i) {
+        const size_t n = p->n[i], m = p->m[i];
+        if (n == 0 || m == 0) {
+            cost_out[i] = (int32_t)(n + m);
+            continue;
+        }
+        cost_out[i] = (int32_t)n + sums[i];
+        if (cost_out[i] > p->band_t[i]) todo.push_back(i);
+    }
+    bool replanned = !todo.empty();
+    while (!todo.empty()) {
+        p->band_retries += todo.size();
+        std::vector<StripJob> jobs;
+        std::vector<int32_t> first(todo.size() + 1, 0);
+        for (size_t k = 0; k < todo.size(); ++k) {
+            const size_t i = todo[k];
+            p->band_t[i] = (int32_t)std::min<long>((long)cost_out[i], std::max<long>(2L * p->band_t[i], 64));
+            first[k] = (int32_t)jobs.size();
+            plan_banded_pair(p, i, p->band_t[i], jobs);
+            first[k + 1] = (int32_t)jobs.size();
+        }
+        if (!p->d_rjobs.alloc(jobs.size() * sizeof(StripJob)) || !p->d_rfirst.alloc(first.size() * 4)) return PA_E_HIP;
+        hipEvent_t e0 = p->ev0, e1 = p->ev2;
+        for (size_t i : todo)
+            if (!hip_ok(hipMemsetAsync(p->d_sums.as<int32_t>() + i, 0, 4, s), "memset sum")) return PA_E_HIP;
+        uint32_t misc[4] = {0, 0, 0, 0};
+        float ms = 0.f;
+        if (!hip_ok(hipMemcpyAsync(p->d_rjobs.ptr, jobs.data(), jobs.size() * sizeof(StripJob), hipMemcpyHostToDevice, s), "H2D jobs") ||
+            !hip_ok(hipMemcpyAsync(p->d_rfirst.ptr, first.data(), first.size() * 4, hipMemcpyHostToDevice, s), "H2D first") ||
+            !hip_ok(hipEventRecord(e0, s), "event") ||
+            !launch_pairs(p->d_rjobs.as<StripJob>(), p->d_rfirst.as<int32_t>(), (int)todo.size(), p->d_misc.as<uint32_t>(), s, p->k, false) ||
+            !hip_ok(hipEventRecord(e1, s), "event") ||
+            !hip_ok(hipMemcpyAsync(sums.data(), p->d_sums.ptr, p->pairs * 4, hipMemcpyDeviceToHost, s), "D2H") ||
+            !hip_ok(hipMemcpyAsync(misc, p->d_misc.ptr, 16, hipMemcpyDeviceToHost, s), "D2H") || !hip_ok(hipStreamSynchronize(s), "sync"))
+            return PA_E_HIP;
+        if (misc[1] != PA_ERR_NONE) {
+            set_error("device spin timeout (err=%u)", misc[1]);
+            return PA_E_TIMEOUT;
+        }
+        if (kernel_ms && hip_ok(hipEventElapsedTime(&ms, e0, e1), "elapsed")) *kernel_ms += ms;
+        std::vector<size_t> next;
+        for (size_t i : todo) {
+            cost_out[i] = (int32_t)p->n[i] + sums[i];
+            if (cost_out[i] > p->band_t[i]) next.push_back(i);
+        }
+        todo.swap(next);
+    }
+    if (replanned) {  // keep what worked: the next pass over this batch starts from these bands
+        p->jobs.clear();
+        std::vector<int32_t> first(p->pairs + 1, 0);
+        for (size_t i = 0; i < p->pairs; ++i) {
+            first[i] = (int32_t)p->jobs.size();
+            plan_banded_pair(p, i, p->band_t[i], p->jobs);
+            first[i + 1] = (int32_t)p->jobs.size();
+        }
+        if (!p->d_jobs.alloc(p->jobs.size() * sizeof(StripJob)) ||
+            !hip_ok(hipMemcpyAsync(p->d_jobs.ptr, p->jobs.data(), p->jobs.size() * sizeof(StripJob), hipMemcpyHostToDevice, s), "H2D jobs") ||
+            !hip_ok(hipMemcpyAsync(p->d_first.ptr, first.data(), first.size() * 4, hipMemcpyHostToDevice, s), "H2D first") ||
+            !hip_ok(hipStreamSynchronize(s), "sync"))
+            return PA_E_HIP;
+    }
+    return 0;
+}
+
 extern "C" int pa_batch_run(pa_batch* p, int32_t* cost_out, float* kernel_ms) {
     if (!p) return PA_E_ARG;
     hipStream_t s = p->stream;
@@ -1232,6 +1416,7 @@ extern "C" int pa_batch_run(pa_batch* p, int32_t* cost_out, float* kernel_ms) {
         *kernel_ms = 0.f;
         if (!p->jobs.empty() && !hip_ok(hipEventElapsedTime(kernel_ms, p->ev0, p->ev1), "elapsed")) return PA_E_HIP;
     }
+    if (p->banded) return banded_finish(p, sums, cost_out, kernel_ms);
     for (size_t i = 0; i < p->pairs; ++i) {
         const size_t n = p->n[i], m = p->m[i], w = (m + 63) / 64;
         if (n == 0) { cost_out[i] = (int32_t)m; continue; }

@@ -80,10 +80,13 @@ struct StripJob {
     uint32_t* ckpt;           // CKPT kernels: V column after every 256th column, u32 view of ckpt[c][ckpt_stride] (V each),
                               // c = (column + 1) / 256; the sparse blocks of the traceback (blocks.rs:322-339).  Or nullptr
     int32_t ckpt_stride;      // words per checkpoint column
-    int32_t pad2_;
+    int32_t hin_n;            // banded strips: only the first hin_n columns (a multiple of 32, or >= n) have granules from
+                              // the strip above; the rest of the top row is +1 (outside the band).  0 = all of them
+    int32_t* vsum_out;        // banded strips: atomically add the sum of this strip's right-edge vertical deltas (rows
+                              // below tail_rows excluded); cost = n + sum over the strips of a pair.  Or nullptr
 };
 enum : int32_t { kJobVInitOne = 1 };
-static_assert(sizeof(StripJob) == 128, "StripJob layout");
+static_assert(sizeof(StripJob) == 136, "StripJob layout");
 
 enum : uint32_t {
     PA_ERR_NONE = 0,
@@ -408,7 +411,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
         const uint32_t code = (32 * q + (lane & 31) < n) ? ((cw >> sh) & 3u) : 0u;
         // top delta of this lane's column as (p << 31) | (m << 30); H::one() when there is no top row (blocks.rs:732)
         uint32_t hin2 = has_hin ? (((hinb_next & 1u) << 31) | ((hinb_next & 2u) << 29)) : 0x80000000u;
-        if (q < C && has_gran) {
+        if (q < C && has_gran && (job.hin_n == 0 || q * 32 < job.hin_n)) {
             uint32_t glo, ghi;
             alive = resolve_granule(g_gran, gran_next, q, glo, ghi);
             hin2 = ((upper ? ghi : glo) << sh) & 0xC0000000u;
@@ -462,6 +465,26 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
             g_v[word * 4 + half] = vp[k];
             g_v[word * 4 + 2 + half] = vm[k];
         }
+    }
+    if (job.vsum_out) {  // banded pairs: value at the strip's bottom-right = value at its top-right + this
+        int32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int sub = lane * K + k;
+            if (sub < job.nlanes) {
+                uint32_t keep = 0xFFFFFFFFu;
+                if (job.tail_rows >= 0) {
+                    const int row0 = 64 * job.word0 + 32 * sub;
+                    int live = job.tail_rows - row0;  // rows of this subword above |b|
+                    live = live < 0 ? 0 : (live > 32 ? 32 : live);
+                    keep = live == 32 ? 0xFFFFFFFFu : ((1u << live) - 1u);
+                }
+                c += __builtin_popcount(vp[k] & keep) - __builtin_popcount(vm[k] & keep);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (lane == 0) atomicAdd((int32_t*)job.vsum_out, c);
     }
     if (job.sum_out) {
         int32_t c = 0;
@@ -555,7 +578,8 @@ __global__ __launch_bounds__(64) void rect_kernel(RectArgs r) {
     j.k = K;
     j.ckpt = nullptr;
     j.ckpt_stride = 0;
-    j.pad2_ = 0;
+    j.hin_n = 0;
+    j.vsum_out = nullptr;
     run_strip<K, false, false>(j, r.err);
     // completion: results first (system scope: v and the sum are in host memory), then the count, then the flag
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");

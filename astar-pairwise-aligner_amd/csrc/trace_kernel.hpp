@@ -180,7 +180,8 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void trace_kernel(const Trac
                     j.k = 1;
                     j.ckpt = nullptr;
                     j.ckpt_stride = 0;
-                    j.pad2_ = 0;
+                    j.hin_n = 0;
+                    j.vsum_out = nullptr;
                     run_strip<1, true, false, false, true>(j, err);
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 }

@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true")
     ap.add_argument("--no-c4", action="store_true", help="skip the batched alignment-with-traceback leg")
+    ap.add_argument("--no-banded", action="store_true", help="skip the banded leg")
     ap.add_argument("--c4-pairs", type=int, default=10_000)
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
@@ -188,6 +189,31 @@ def main():
         out["single_pair"] = {"gcups": round(cells1 / best / 1e9, 2), "ms": round(best * 1e3, 4),
                               "kernel_ms": round(kms, 4), "kernel_gcups": round(cells1 / kms / 1e6, 2)}
         b1.close()
+
+    # ---- banded C2: the same pairs inside the diagonal band of the expected divergence (GapGap domain), exact costs ----
+    if not args.no_banded and world == 1:
+        t = time.perf_counter()
+        bb = pa.Batch(pairs, band=args.div + 0.01)
+        bcosts, _ = bb.run()
+        first = time.perf_counter() - t
+        assert bcosts.tolist() == costs.tolist(), "banded costs differ from the full DP"
+        best, kms = 1e9, 1e9
+        for _ in range(3):
+            t = time.perf_counter()
+            bcosts, ms1 = bb.run()
+            best = min(best, time.perf_counter() - t)
+            kms = min(kms, ms1)
+        out["banded"] = {
+            "workload": f"the same {args.pairs} pairs, cost only, diagonal band for divergence hint {args.div + 0.01:.2f} "
+                        "(re-run wider where too narrow; costs identical to the full DP)",
+            "pairs_per_sec": round(args.pairs / best, 1),
+            "ms": round(best * 1e3, 3),
+            "kernel_ms": round(kms, 3),
+            "gcups_equivalent": round(bb.stats()["cells"] / best / 1e9, 1),
+            "create_plus_first_pass_ms": round(first * 1e3, 1),
+            "kernel": bb.shape()["kernel"],
+        }
+        bb.close()
 
     # ---- C4 (BASELINE configs[3]): 10 000 x 10 kbp, 1-15 % mixed divergence, cost AND CIGAR on the GPU ----
     if not args.no_c4 and world == 1:

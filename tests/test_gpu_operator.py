@@ -157,6 +157,29 @@ def test_batch_shapes(pa, oracle, monkeypatch, k, mode):
     batch.close()
 
 
+@pytest.mark.parametrize("k", [0, 1, 2, 4, 8])
+@pytest.mark.parametrize("hint", [0.0, 0.02, 0.3])
+def test_banded_batch_is_exact_for_any_hint(pa, oracle, monkeypatch, k, hint):
+    """Diagonal-band DP (pa_batch_create_banded): a hint that is too small only costs re-runs with a wider band, a generous
+    one only costs work; the costs are the full-DP costs either way.  Unequal lengths, long indels, unrelated pairs."""
+    if k:
+        monkeypatch.setenv("PA_STRIP_K", str(k))
+    rows = 2048 * max(k, 1)
+    a = rand_seq(5000, seed=31)
+    pairs = [gen_pair(n, e, seed=n + int(1000 * e)) for n in (1, 40, 700, 3000, rows + 500, 3 * rows + 77) for e in (0.0, 0.03, 0.12)]
+    pairs += [(a, a[:2000] + a[2600:]), (a[:2000] + a[2600:], a), (a, a[:100] + rand_seq(900, seed=5) + a[100:]),
+              (rand_seq(900, seed=1), rand_seq(2500, seed=2)), (rand_seq(2500, seed=3), rand_seq(60, seed=4)),
+              (b"", b""), (b"ACGT", b""), (b"", b"ACGTA")]
+    batch = pa.Batch(pairs, band=hint)
+    costs, _ = batch.run()
+    for (x, y), c in zip(pairs, costs):
+        want = oracle.levenshtein(x, y) if len(x) * len(y) < 4_000_000 else oracle.nw_cost(x, y, True)
+        assert c == want, (len(x), len(y), hint, k)
+    costs2, _ = batch.run()  # the widened bands are kept: same answers, no further re-runs needed
+    assert np.array_equal(costs, costs2)
+    batch.close()
+
+
 def test_batch_invalid_base(pa):
     with pytest.raises(ValueError):
         pa.Batch([(b"ACGTN", b"ACGT")]).run()

@@ -42,7 +42,10 @@ while time.time() - t0 < budget:
             cut = int(rng.integers(0, n + 1))
             pairs.append((a, a[:cut] + rand_seq(int(rng.integers(0, 3000)), seed=7) + a[cut:]))
     traced = bool(rng.integers(0, 2))
-    b = pa.Batch(pairs, trace=traced)
+    band = None if traced or rng.integers(0, 2) else float(rng.choice([0.0, 0.01, 0.05, 0.5]))
+    if band is not None:
+        os.environ.pop("PA_BATCH_MODE", None)
+    b = pa.Batch(pairs, trace=traced, band=band)
     if traced:
         costs, cigars, _, _ = b.align()
     else:
@@ -50,7 +53,7 @@ while time.time() - t0 < budget:
         cigars = [None] * npairs
     for (x, y), c, cg in zip(pairs, costs, cigars):
         want = oracle.levenshtein(x, y) if len(x) * len(y) < 3_000_000 else oracle.nw_cost(x, y, True)
-        assert c == want, ("cost", k, mode, traced, len(x), len(y), int(c), want)
+        assert c == want, ("cost", k, mode, traced, band, len(x), len(y), int(c), want)
         if traced and len(x) * len(y) < 40_000_000:
             wc, wcg, _ = oracle.cpu_align(x, y, prm)
             assert (c, cg) == (wc, wcg), ("cigar", k, mode, len(x), len(y))

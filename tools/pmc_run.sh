@@ -4,7 +4,7 @@ set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc
 mkdir -p $OUT
-CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-pair --no-c4 $PA_BENCH_ARGS"
+CMD="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-pair --no-c4 --no-banded $PA_BENCH_ARGS"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o fetch -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o write -- $CMD > $OUT/write.log 2>&1

@@ -1,4 +1,5 @@
 """Quick timing probe of the batched full-DP path (not the contract bench; see bench.py)."""
+import os
 import sys
 import time
 
@@ -13,9 +14,12 @@ if len(sys.argv) > 1:
 for (n, pairs) in cases:
     base = [generate_pair(n, 0.05, seed=s + 1) for s in range(min(pairs, 32))]
     ps = [base[i % len(base)] for i in range(pairs)]
-    b = pa.Batch(ps)
+    band = float(os.environ["PA_BAND"]) if "PA_BAND" in os.environ else None  # banded DP with this divergence hint
+    t_first = time.time()
+    b = pa.Batch(ps, band=band)
     st = b.stats()
     costs, ms = b.run()
+    first_ms = (time.time() - t_first) * 1e3  # create + first pass (band re-runs included)
     best, bestk = 1e9, 1e9
     for _ in range(3):
         t = time.time()
@@ -23,5 +27,6 @@ for (n, pairs) in cases:
         best = min(best, time.time() - t)
         bestk = min(bestk, ms)
     print(f"n={n} pairs={pairs} strips={int(st['strips'])} kernel_ms={bestk:.3f} wall_ms={best*1e3:.3f} "
-          f"GCUPS(kernel)={st['cells']/bestk/1e6:.1f} GCUPS(wall)={st['cells']/best/1e9:.1f} cost0={costs[0]}", flush=True)
+          f"GCUPS(kernel)={st['cells']/bestk/1e6:.1f} GCUPS(wall)={st['cells']/best/1e9:.1f} cost0={costs[0]}"
+          + (f" band={band} shape={b.shape()['kernel']} create+first_pass_ms={first_ms:.1f} pairs/s={pairs/best:.0f}" if band is not None else ""), flush=True)
     b.close()

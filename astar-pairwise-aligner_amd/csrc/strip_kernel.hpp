@@ -396,7 +396,11 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
     // next chunk -> 32 steps.  Nothing conditional is ever younger than a prefetch, so its wait stays cheap.
     bool alive = true;
     PA_DBG(1, 1);
-    const int Q = C + 2;
+    // A strip whose only product is `values` (+ v) can stop as soon as its last REAL lane has finished column n - 1; the
+    // two drain chunks exist for lane 63's bottom row, which nobody reads then.
+    const bool fill_only = FILL && !job.hout_gran && !job.hout_arr && !job.sum_out && !job.vsum_out;
+    const int last_lane = (job.nlanes + K - 1) / K;  // real lanes
+    const int Q = fill_only ? ((n + last_lane + 31) >> 5 < C + 2 ? (n + last_lane + 31) >> 5 : C + 2) : C + 2;
     for (int q = 0; q < Q && alive; ++q) {
         PA_DBG(2, q + 1);
         // ---- decode this chunk's inputs (both prefetched values are consumed here so the only vector-memory wait of
@@ -426,7 +430,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
         gran_next = load_gran(q + 1);
         hinb_next = load_hin_byte(q + 1);
 
-        const bool interior = !FILL && (q >= 2) && (q * 32 + 31 < n);
+        const bool interior = (q >= 2) && (q * 32 + 31 < n);  // every lane is inside [0, n): no predication needed
         // a 256-column block can only complete in a chunk whose first column is 0, 32 or 224 (mod 256): lane l reaches column
         // 255 (mod 256) at step 32q + j = 255 + l.  Only those chunks pay for the checkpoint test.
         const bool ck_chunk = CKPT && job.ckpt != nullptr && ((q & 7) <= 1 || (q & 7) == 7);
@@ -434,16 +438,16 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
     run_chunk<K, PRED_, PASS_, FILL_, SCATTER, CK_>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80)
         if (CKPT && ck_chunk) {
             if (interior) {
-                if (exact_tail) PA_RUN_CHUNK(false, true, false, CKPT);
-                else PA_RUN_CHUNK(false, false, false, CKPT);
+                if (exact_tail) PA_RUN_CHUNK(false, true, FILL, CKPT);
+                else PA_RUN_CHUNK(false, false, FILL, CKPT);
             } else {
                 if (exact_tail) PA_RUN_CHUNK(true, true, FILL, CKPT);
                 else PA_RUN_CHUNK(true, false, FILL, CKPT);
             }
         } else {
             if (interior) {
-                if (exact_tail) PA_RUN_CHUNK(false, true, false, false);
-                else PA_RUN_CHUNK(false, false, false, false);
+                if (exact_tail) PA_RUN_CHUNK(false, true, FILL, false);
+                else PA_RUN_CHUNK(false, false, FILL, false);
             } else {
                 if (exact_tail) PA_RUN_CHUNK(true, true, FILL, false);
                 else PA_RUN_CHUNK(true, false, FILL, false);

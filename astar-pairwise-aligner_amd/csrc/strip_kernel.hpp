@@ -4,21 +4,28 @@
 // compute_block_of_rows (reference pa-bitpacking/src/simd.rs:98-315,326-547; myers.rs:27-91).
 //
 // MI355X-first design (not the CPU's 8-lane AVX2 strip):
-//  * A *strip* is one 64-lane wavefront.  Lane l owns 32 DP rows (one half of a reference 64-bit
-//    word; word = l/2, half = l&1), so a strip covers 2048 rows = 32 reference words.  32-bit lanes
-//    make every Myers op one VALU instruction (no carry pairs) which halves the per-step latency that
-//    bounds a single long pair.
+//  * A *strip* is one 64-lane wavefront.  Lane l owns K subwords of 32 DP rows (K = 1, 2, 4, 8; subword s = l*K + k is
+//    half s&1 of reference word word0 + s/2), so a strip covers 2048*K rows = 32*K reference words.  K = 1 makes every
+//    Myers op one VALU instruction (lowest latency per column: one long pair); larger K amortises the 11 per-lane
+//    "plumbing" instructions over 12 per subword (23 / 35 / 59 / 107 instructions per step) -- the kernel is bound by
+//    VALU issue, so instructions per DP cell are the cost.
 //  * Anti-diagonal skew inside the wave: at step t lane l processes column t-l.  The horizontal
 //    delta (2 bits) and the column's 2-bit base code travel lane->lane+1 in ONE packed register
 //    through a DPP `wave_shr:1` move -- no LDS, no barrier.
-//  * Strips of one rectangle are chained top->bottom.  The bottom row of strip s (2 bits/column) is
-//    handed to strip s+1 through 8-byte granules of 32 columns each in global memory, written with one
-//    agent-scope relaxed atomic store and polled with agent-scope relaxed loads ("the data is the
-//    flag"; MI355X_MICROARCH.md, handoff R2).  A granule needs no tag: every 2-bit delta field is stored
-//    +1 (1..3), so a written granule is never zero and the buffer is zeroed before each launch.
-//    No fences, no L2 writeback.
-//  * Work items are claimed through an atomic ticket, so a consumer's producer always started
-//    earlier => forward progress without assuming dispatch order.  Every spin is bounded.
+//  * The bottom row of strip s (2 bits/column) reaches strip s+1 through 8-byte granules of 32 columns each in global
+//    memory.  A granule needs no tag: every 2-bit delta field is stored +1 (1..3), so a written granule is never
+//    zero; the consumer hands every granule back zeroed, so the buffer is cleared only once.
+//      - strip_kernel: strips of a rectangle run concurrently, one wavefront each, chained through agent-scope relaxed
+//        atomic stores / polled loads ("the data is the flag"; MI355X_MICROARCH.md, handoff R2; no fences, no L2
+//        write-back).  Jobs are claimed through an atomic ticket in producer-before-consumer order => forward
+//        progress without assuming dispatch order.  Every spin is bounded.
+//      - pair_kernel: ONE wavefront runs all strips of a pair top to bottom (two granule rows, ping-pong,
+//        workgroup-scope accesses that stay in the L2).  Nothing polls; this is the shape of big batches.
+//      - rect_kernel: one rectangle of the A*PA2 engine per launch, described by kernel arguments, results and the
+//        completion word in host-mapped memory.
+//  * Variants (templates): FILL stores every column's V (traceback re-fills), SCATTER reads the four-mask profile of the
+//    semi-global search, CKPT stores the V column after every 256th column (sparse blocks of the batched traceback);
+//    banded pairs give every strip its own column window (StripJob::col0 / n / hin_n / vsum_out).
 //  * HBM traffic is tiny by construction (0.25 B/column of `a`, 16 B/word of profile, 32 B/word of v,
 //    0.5 B/column of h per strip boundary): the kernel is integer-VALU-issue bound, not HBM bound.
 #pragma once

@@ -1016,10 +1016,11 @@ static void plan_banded_pair(pa_batch* p, size_t i, int32_t t, std::vector<Strip
     const long d = (long)n - (long)m;
     if ((long)t < std::labs(d)) t = (int32_t)std::labs(d);
     const long xlo = (d - t) / 2 - 1, xhi = (d + t + 1) / 2 + 1;  // one diagonal of slack on either side
-    const StripPlan sp = strip_plan(w, p->k, true);
+    const StripPlan sp = strip_plan(w, p->k, p->sequential);
     const int S = sp.strips(), wps = kWordsPerStrip * p->k;
-    const size_t G = (size_t)n / 32 + 2;
+    const size_t G = (size_t)n / 32 + 2;  // granules of one bottom row, indexed by absolute column / 32
     uint64_t* rows = p->d_gran.as<uint64_t>() + p->gran_off[i];
+    const bool pingpong = p->sequential;  // one wavefront per pair reuses two rows; chained strips get a row per boundary
     int word = 0, prev_c0 = 0, prev_c1 = 0;
     for (int s = 0; s < S; ++s) {
         const bool tall = s < sp.full;
@@ -1046,10 +1047,10 @@ static void plan_banded_pair(pa_batch* p, size_t i, int32_t t, std::vector<Strip
         j.tail_rows = m;
         j.exact_tail = 1;  // the bottom row feeds the strip below
         if (s > 0) {
-            j.hin_gran = rows + (size_t)((s - 1) & 1) * G + (size_t)(c0 / 32);
+            j.hin_gran = rows + (size_t)(pingpong ? ((s - 1) & 1) : (s - 1)) * G + (size_t)(c0 / 32);
             j.hin_n = std::max(32, prev_c1 - (int)c0);
         }
-        if (s + 1 < S) j.hout_gran = rows + (size_t)(s & 1) * G + (size_t)(c0 / 32);
+        if (s + 1 < S) j.hout_gran = rows + (size_t)(pingpong ? (s & 1) : s) * G + (size_t)(c0 / 32);
         else j.exact_tail = 0;
         j.vsum_out = p->d_sums.as<int32_t>() + i;
         jobs.push_back(j);
@@ -1059,29 +1060,48 @@ static void plan_banded_pair(pa_batch* p, size_t i, int32_t t, std::vector<Strip
     }
 }
 
-// Strip height of a banded batch: minimise (strips x (strip rows + band width)) x instructions per step.
-static int choose_band_k(const pa_batch* p) {
-    if (const char* e = getenv("PA_STRIP_K")) {
-        const int k = atoi(e);
-        if (k == 1 || k == 2 || k == 4 || k == 8) return k;
-    }
+// Shape of a banded batch.  With about one pair per SIMD one wavefront runs a whole pair (no coupling); fewer pairs run
+// as chained strips, where a pair's time is set by the columns along the diagonal (n steps of the step latency) and
+// low strips keep that latency low.  Strip height: minimise (strips x (strip rows + band width)) x step cost.
+static void choose_band_shape(pa_batch* p) {
     static const double kLone[4] = {52.9, 76.5, 121.0, 210.0};
     static const int kK[4] = {1, 2, 4, 8};
+    const double simds = (double)(g_device_props_cus > 0 ? g_device_props_cus : 256) * 4.0;
+    size_t live = 0;
+    for (size_t i = 0; i < p->pairs; ++i) live += (p->n[i] > 0 && p->m[i] > 0) ? 1 : 0;
+    p->sequential = (double)live >= simds;
+    if (const char* e = getenv("PA_BATCH_MODE")) {
+        if (!strcmp(e, "seq")) p->sequential = true;
+        if (!strcmp(e, "chain")) p->sequential = false;
+    }
+    int env_k = 0;
+    if (const char* e = getenv("PA_STRIP_K")) {
+        const int k = atoi(e);
+        if (k == 1 || k == 2 || k == 4 || k == 8) env_k = k;
+    }
     int best_k = 1;
     double best = -1;
     for (int t = 0; t < 4; ++t) {
-        double cost = 0;
+        if (env_k && kK[t] != env_k) continue;
+        double work = 0, strips = 0, longest = 0;
         for (size_t i = 0; i < p->pairs; ++i) {
+            if (p->n[i] == 0 || p->m[i] == 0) continue;
             const double w = (double)((p->m[i] + 63) / 64), rows = 2048.0 * kK[t];
             const double S = std::ceil(w * 64.0 / rows);
-            cost += S * (std::min(rows, w * 64.0) + (double)p->band_t[i] + 128.0) * kLone[t];
+            work += S * (std::min(rows, w * 64.0) + (double)p->band_t[i] + 128.0);
+            strips += S;
+            longest = std::max(longest, (double)p->n[i]);
         }
+        // sequential: all the work, shared by the SIMDs; chained: the longest pair's diagonal, or the shared work
+        double cost = work / std::min(std::max((double)live, 1.0), simds) * kLone[t];
+        if (!p->sequential) cost = std::max(longest * kLone[t], work / simds * kLone[t]);
         if (best < 0 || cost < best) {
             best = cost;
             best_k = kK[t];
+            p->block_waves = (p->sequential || strips <= simds) ? kStripBlockWaves : 1;
         }
     }
-    return best_k;
+    p->k = best_k;
 }
 
 static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len, size_t pairs,
@@ -1099,11 +1119,9 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             const long d = std::labs((long)a_len[i] - (long)b_len[i]);
             p->band_t.push_back((int32_t)std::min<double>(d + std::ceil(band_hint * len) + 32, (double)a_len[i] + (double)b_len[i] + 64));
         }
-        p->k = choose_band_k(p.get());
+        choose_band_shape(p.get());
         p->n.clear();
         p->m.clear();
-        p->sequential = true;
-        p->block_waves = kStripBlockWaves;
     } else {
         const BatchShape sh = choose_batch_shape(a_len, b_len, pairs);
         p->k = sh.k;
@@ -1128,7 +1146,8 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
         tb += (b_len[i] + 15) & ~size_t(15);
         tc += (a_len[i] + 15) / 16;
         tp += w;
-        tg += p->banded ? 2 * (a_len[i] / 32 + 2) : rect_granules((int)a_len[i], (int)w, p->k, p->sequential);
+        tg += p->banded ? (size_t)(p->sequential ? 2 : std::max(1, strip_plan((int)w, p->k, false).strips() - 1)) * (a_len[i] / 32 + 2)
+                        : rect_granules((int)a_len[i], (int)w, p->k, p->sequential);
         p->cells += (double)a_len[i] * (double)b_len[i];
         p->word_updates += (double)a_len[i] * (double)w;
         // algorithmic HBM bytes, cost-only rectangle: 0.75 B/column + 48 B/word
@@ -1308,7 +1327,7 @@ static int batch_forward(pa_batch* p) {
     // every strip hands the granules it consumed back zeroed, so the buffer is cleared only before the first pass (and
     // after a pass that did not finish)
     if (p->total_gran && p->gran_dirty && !hip_ok(hipMemsetAsync(p->d_gran.ptr, 0, p->total_gran * 8, s), "memset gran")) return PA_E_HIP;
-    p->gran_dirty = true;
+    p->gran_dirty = true;  // (banded chained strips skip part of every row: it stays dirty, cleared before every pass)
     if (!hip_ok(hipMemsetAsync(p->d_sums.ptr, 0, std::max<size_t>(p->pairs * 4, 16), s), "memset sums")) return PA_E_HIP;
     // d_misc (ticket, err, -, bad-base flag) was zeroed above; the events bracket the strip kernel alone
     if (!hip_ok(hipEventRecord(p->ev0, s), "event")) return PA_E_HIP;
@@ -1358,8 +1377,10 @@ static int banded_finish(pa_batch* p, std::vector<int32_t>& sums, int32_t* cost_
         float ms = 0.f;
         if (!hip_ok(hipMemcpyAsync(p->d_rjobs.ptr, jobs.data(), jobs.size() * sizeof(StripJob), hipMemcpyHostToDevice, s), "H2D jobs") ||
             !hip_ok(hipMemcpyAsync(p->d_rfirst.ptr, first.data(), first.size() * 4, hipMemcpyHostToDevice, s), "H2D first") ||
+            (!p->sequential && p->total_gran && !hip_ok(hipMemsetAsync(p->d_gran.ptr, 0, p->total_gran * 8, s), "memset gran")) ||
             !hip_ok(hipEventRecord(e0, s), "event") ||
-            !launch_pairs(p->d_rjobs.as<StripJob>(), p->d_rfirst.as<int32_t>(), (int)todo.size(), p->d_misc.as<uint32_t>(), s, p->k, false) ||
+            !(p->sequential ? launch_pairs(p->d_rjobs.as<StripJob>(), p->d_rfirst.as<int32_t>(), (int)todo.size(), p->d_misc.as<uint32_t>(), s, p->k, false)
+                            : launch_strips(p->d_rjobs.as<StripJob>(), (int)jobs.size(), false, p->d_misc.as<uint32_t>(), s, true, false, p->k, 1, false)) ||
             !hip_ok(hipEventRecord(e1, s), "event") ||
             !hip_ok(hipMemcpyAsync(sums.data(), p->d_sums.ptr, p->pairs * 4, hipMemcpyDeviceToHost, s), "D2H") ||
             !hip_ok(hipMemcpyAsync(misc, p->d_misc.ptr, 16, hipMemcpyDeviceToHost, s), "D2H") || !hip_ok(hipStreamSynchronize(s), "sync"))
@@ -1386,7 +1407,7 @@ static int banded_finish(pa_batch* p, std::vector<int32_t>& sums, int32_t* cost_
         }
         if (!p->d_jobs.alloc(p->jobs.size() * sizeof(StripJob)) ||
             !hip_ok(hipMemcpyAsync(p->d_jobs.ptr, p->jobs.data(), p->jobs.size() * sizeof(StripJob), hipMemcpyHostToDevice, s), "H2D jobs") ||
-            !hip_ok(hipMemcpyAsync(p->d_first.ptr, first.data(), first.size() * 4, hipMemcpyHostToDevice, s), "H2D first") ||
+            (p->sequential && !hip_ok(hipMemcpyAsync(p->d_first.ptr, first.data(), first.size() * 4, hipMemcpyHostToDevice, s), "H2D first")) ||
             !hip_ok(hipStreamSynchronize(s), "sync"))
             return PA_E_HIP;
     }
@@ -1411,7 +1432,7 @@ extern "C" int pa_batch_run(pa_batch* p, int32_t* cost_out, float* kernel_ms) {
         set_error("device spin timeout (err=%u)", misc[1]);
         return PA_E_TIMEOUT;
     }
-    p->gran_dirty = false;  // clean finish
+    p->gran_dirty = p->banded && !p->sequential;  // clean finish (banded chained strips leave unconsumed granules behind)
     if (kernel_ms) {
         *kernel_ms = 0.f;
         if (!p->jobs.empty() && !hip_ok(hipEventElapsedTime(kernel_ms, p->ev0, p->ev1), "elapsed")) return PA_E_HIP;

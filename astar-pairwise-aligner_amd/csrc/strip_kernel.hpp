@@ -267,10 +267,14 @@ __device__ __forceinline__ bool resolve_granule(gcu64 g, uint64_t pre, int q, ui
         const uint64_t t0 = wall_clock64();
         uint32_t spins = 0;
         do {
-            __builtin_amdgcn_s_sleep(2);
+            // back off while the wait is long (a banded strip may wait milliseconds for the diagonal to reach it): a
+            // polling wavefront shares its SIMD's issue slots with working ones.  Capped at ~3 us so that a chain of
+            // strips does not accumulate start-up delay.
+            const uint32_t naps = spins < 8u ? 1u : (spins < 64u ? 4u : 16u);
+            for (uint32_t k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(8);
             pre = load_granule(g + q);
             l = rfl((uint32_t)pre);
-            if ((++spins & 1023u) == 0 && wall_clock64() - t0 > kSpinTimeoutTicks) break;
+            if ((++spins & 255u) == 0 && wall_clock64() - t0 > kSpinTimeoutTicks) break;
         } while (l == 0u);
     }
     const uint32_t h = rfl((uint32_t)(pre >> 32));

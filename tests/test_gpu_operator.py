@@ -157,13 +157,15 @@ def test_batch_shapes(pa, oracle, monkeypatch, k, mode):
     batch.close()
 
 
+@pytest.mark.parametrize("mode", ["chain", "seq"])
 @pytest.mark.parametrize("k", [0, 1, 2, 4, 8])
 @pytest.mark.parametrize("hint", [0.0, 0.02, 0.3])
-def test_banded_batch_is_exact_for_any_hint(pa, oracle, monkeypatch, k, hint):
+def test_banded_batch_is_exact_for_any_hint(pa, oracle, monkeypatch, k, hint, mode):
     """Diagonal-band DP (pa_batch_create_banded): a hint that is too small only costs re-runs with a wider band, a generous
     one only costs work; the costs are the full-DP costs either way.  Unequal lengths, long indels, unrelated pairs."""
     if k:
         monkeypatch.setenv("PA_STRIP_K", str(k))
+    monkeypatch.setenv("PA_BATCH_MODE", mode)
     rows = 2048 * max(k, 1)
     a = rand_seq(5000, seed=31)
     pairs = [gen_pair(n, e, seed=n + int(1000 * e)) for n in (1, 40, 700, 3000, rows + 500, 3 * rows + 77) for e in (0.0, 0.03, 0.12)]

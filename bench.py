@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=4096, help="independent pairs per GPU per step")
-    ap.add_argument("--n", type=int, default=100_000, help="sequence length (bp)")
+    ap.add_argument("--seq-len", dest="n", type=int, default=100_000, help="sequence length (bp)")
     ap.add_argument("--div", type=float, default=0.05, help="divergence (edit rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-pair", action="store_true")
@@ -69,14 +69,21 @@ def main():
     from astar_pairwise_aligner_amd.generate import generate_pair
 
     pa.require_gpu()
-    torch.cuda.set_device(local_rank)
-    pa.capi.load().pa_set_device(local_rank)
+    # PA_BENCH_DRY_MULTI=1 (tests only): exercise the N>1 code path on a one-GPU box -- every rank uses GPU 0 and the
+    # collectives run over gloo.  The numbers of such a run mean nothing.
+    dry_multi = os.environ.get("PA_BENCH_DRY_MULTI") == "1"
+    device_index = 0 if dry_multi else local_rank
+    torch.cuda.set_device(device_index)
+    pa.capi.load().pa_set_device(device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dry_multi:
+            dist_mod.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
         dist = dist_mod
 
     def barrier():

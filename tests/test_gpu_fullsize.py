@@ -96,3 +96,26 @@ def test_c5_long_pair_properties(pa, oracle):
     a3, b3 = a[:300_000], mutate(a[:300_000], 0.01, seed=6)
     want, _, _ = oracle.cpu_align(a3, b3, oracle.params_simple(), trace=False)
     assert pa.Batch([(a3, b3)]).run()[0][0] == want
+
+
+def test_bench_two_rank_code_path_dry_run(tmp_path):
+    """bench.py's N>1 branch (barrier, max-over-ranks time, checksum reduction, rank-0-only report) on one GPU: both ranks
+    use GPU 0 and gloo carries the collectives (PA_BENCH_DRY_MULTI=1).  Only the plumbing is checked, not the numbers."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, PA_BENCH_DRY_MULTI="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "8",
+           "--seq-len", "20000", "--no-cpu-baseline", "--no-single-pair", "--no-c4", "--no-banded"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["config"]["pairs_per_gpu"] == 8

@@ -90,3 +90,42 @@ def test_gpu_sharded_single_rank():
 
     pairs = [gen_pair(500 + 100 * i, 0.05, seed=i) for i in range(6)]
     assert sharded_costs(pairs) == [oracle.levenshtein(a, b) for a, b in pairs]
+
+
+def _gpu_worker(rank, world, port, q):
+    """Two ranks sharing GPU 0 (a one-GPU box): the default per-rank compute is the HIP batch; gloo carries the gather."""
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    import oracle
+    from astar_pairwise_aligner_amd.sharding import sharded_align, sharded_costs
+    from tests.util_seq import gen_pair
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pairs = [gen_pair(300 + 211 * i, 0.02 * (i % 6 + 1), seed=i) for i in range(11)]
+    costs = sharded_costs(pairs)
+    aligned = sharded_align(pairs)
+    want = [oracle.levenshtein(a, b) for a, b in pairs]
+    ok = costs == want and [c for c, _ in aligned] == want and all(oracle.cigar_verify(g, a, b) == c for (c, g), (a, b) in zip(aligned, pairs))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_gpu_sharded_two_ranks_one_device():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

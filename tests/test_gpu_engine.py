@@ -101,3 +101,28 @@ def test_cost_only_mode(pa, oracle):
 def test_invalid_base_raises(pa):
     with pytest.raises(ValueError):
         pa.astarpa2_simple(b"ACGTN", b"ACGT")
+
+
+def test_c_program_links_and_runs(tmp_path):
+    """A plain C program built with gcc against include/astarpa.h and libastarpa_c_hip.so: the drop-in for astarpa-c."""
+    import os
+    import re
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    libdir = root / "astar-pairwise-aligner_amd"
+    gcc = shutil.which("gcc") or shutil.which("cc")
+    if gcc is None or not (libdir / "libastarpa_c_hip.so").exists():
+        pytest.skip("no C compiler or library")
+    exe = tmp_path / "link_check"
+    subprocess.run([gcc, str(root / "tests" / "c_abi" / "link_check.c"), "-I", str(root / "include"), "-L", str(libdir),
+                    "-lastarpa_c_hip", "-Wl,-rpath," + str(libdir), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, LD_LIBRARY_PATH=str(libdir) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))).stdout
+    lines = out.strip().splitlines()
+    assert [l.split()[0] for l in lines] == ["astarpa2_simple", "astarpa2_full", "astarpa", "astarpa_gcsh"]
+    for l in lines:
+        name, cost, cigar, n = l.split()
+        assert cost == "2" and int(n) == len(cigar) and re.fullmatch(r"(\d*[=XID])+", cigar)

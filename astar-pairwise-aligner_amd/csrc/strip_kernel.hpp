@@ -255,12 +255,14 @@ __device__ __forceinline__ void run_chunk(const StripJob& job, int q, uint32_t X
 // non-zero: a written granule is distinguishable from the zeroed buffer without a tag.
 constexpr uint64_t kGranuleBias = 0x5555555555555555ull;
 
+template <bool LOCAL>
 __device__ __forceinline__ uint64_t load_granule(gcu64 g) {
-    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(g, __ATOMIC_RELAXED, LOCAL ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Resolve the (possibly prefetched) granule of chunk q; polls when the producer is not there yet.
 // Returns false (after a bounded wall-clock time) if the producer never delivered.
+template <bool LOCAL>
 __device__ __forceinline__ bool resolve_granule(gcu64 g, uint64_t pre, int q, uint32_t& lo, uint32_t& hi) {
     uint32_t l = rfl((uint32_t)pre);
     if (l == 0u) {  // slow path: the producer is not there yet
@@ -272,7 +274,7 @@ __device__ __forceinline__ bool resolve_granule(gcu64 g, uint64_t pre, int q, ui
             // strips does not accumulate start-up delay.
             const uint32_t naps = spins < 8u ? 1u : (spins < 64u ? 4u : 16u);
             for (uint32_t k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(8);
-            pre = load_granule(g + q);
+            pre = load_granule<LOCAL>(g + q);
             l = rfl((uint32_t)pre);
             if ((++spins & 255u) == 0 && wall_clock64() - t0 > kSpinTimeoutTicks) break;
         } while (l == 0u);
@@ -428,7 +430,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
         uint32_t hin2 = has_hin ? (((hinb_next & 1u) << 31) | ((hinb_next & 2u) << 29)) : 0x80000000u;
         if (q < C && has_gran && (job.hin_n == 0 || q * 32 < job.hin_n)) {
             uint32_t glo, ghi;
-            alive = resolve_granule(g_gran, gran_next, q, glo, ghi);
+            alive = resolve_granule<LOCAL>(g_gran, gran_next, q, glo, ghi);
             hin2 = ((upper ? ghi : glo) << sh) & 0xC0000000u;
             // every granule has exactly one consumer: hand it back zeroed, so the buffer needs clearing only once
             if (lane == 0) __hip_atomic_store((gu64)job.hin_gran + q, (uint64_t)0, __ATOMIC_RELAXED, kGranScope);

@@ -242,12 +242,17 @@ class Batch:
         return out, float(ms.value)
 
     def align(self):
-        """-> (costs int32[pairs], CIGAR strings, forward-kernel ms, traceback-kernel ms); needs trace=True."""
+        """-> (costs int32[pairs], CIGAR strings, forward-kernel ms, traceback-kernel ms); needs trace=True.
+        `self.last_c_abi_ms` = wall time of the pa_batch_align call itself (before Python turns the C strings into str)."""
+        import time
+
         L = load()
         out = np.zeros(self.pairs, np.int32)
         cig = (C.c_void_p * max(self.pairs, 1))()
         fms, tms = C.c_float(0), C.c_float(0)
+        t0 = time.perf_counter()
         rc = L.pa_batch_align(self._h, _p(out), cig, C.byref(fms), C.byref(tms))
+        self.last_c_abi_ms = (time.perf_counter() - t0) * 1e3
         try:
             if rc == -1:
                 raise ValueError("sequence contains a character outside ACGT")

@@ -5,6 +5,7 @@
 #include "trace_kernel.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -921,6 +922,8 @@ struct pa_batch {
     DeviceBuf d_scratch_gran;
     DeviceBuf d_ckpt, d_cigar, d_cigar_len, d_costs, d_scratch_v, d_scratch_vals, d_tjobs, d_cig_src_off, d_cig_dst_off, d_packed, d_text, d_text_len;
     hipEvent_t ev2 = nullptr;
+    uint8_t* h_text = nullptr;  // pinned host buffer for the packed CIGAR text
+    size_t h_text_size = 0;
     double cells = 0, word_updates = 0, algo_bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -928,6 +931,7 @@ struct pa_batch {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (ev2) (void)hipEventDestroy(ev2);
+        if (h_text) (void)hipHostFree(h_text);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -1472,6 +1476,16 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
     }
     hipStream_t s = p->stream;
     const size_t P = p->pairs;
+    static const bool prof = getenv("PA_ALIGN_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    double t_mark = t_begin;
+    auto mark = [&](const char* what) {
+        if (!prof) return;
+        const double t = now();
+        std::fprintf(stderr, "[pa_batch_align] %-28s %8.3f ms\n", what, t - t_mark);
+        t_mark = t;
+    };
     if (cigar_out)
         for (size_t i = 0; i < P; ++i) cigar_out[i] = nullptr;
     if (const int rc = batch_forward(p)) return rc;
@@ -1489,6 +1503,7 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
               !hip_ok(hipMemcpyAsync(costs.data(), p->d_costs.ptr, P * 4, hipMemcpyDeviceToHost, s), "D2H costs")))
         return PA_E_HIP;
     if (!hip_ok(hipMemcpyAsync(misc, p->d_misc.ptr, 16, hipMemcpyDeviceToHost, s), "D2H") || !hip_ok(hipStreamSynchronize(s), "sync")) return PA_E_HIP;
+    mark("forward + trace (+sync)");
     if (misc[3]) {
         set_error("sequence contains a base outside ACGT");
         return PA_E_INVALID_BASE;
@@ -1506,7 +1521,7 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
     // CIGAR text is produced on the GPU; gather it into one packed buffer and copy once
     std::vector<uint32_t> tlens(P, 0);
     std::vector<uint64_t> dst_off(P, 0);
-    std::vector<uint8_t> packed;
+    const uint8_t* packed = nullptr;
     if (P) {
         hipLaunchKernelGGL(format_cigar_kernel, dim3((unsigned)P), dim3(64), 0, s, p->d_cigar.as<uint32_t>(), p->d_cig_src_off.as<uint64_t>(),
                            p->d_cigar_len.as<uint32_t>(), p->d_text.as<uint8_t>(), p->d_text_len.as<uint32_t>());
@@ -1514,52 +1529,64 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
             !hip_ok(hipMemcpyAsync(tlens.data(), p->d_text_len.ptr, P * 4, hipMemcpyDeviceToHost, s), "D2H text lens") ||
             !hip_ok(hipStreamSynchronize(s), "sync"))
             return PA_E_HIP;
+        mark("format kernel + lens D2H");
         uint64_t total = 0;
         for (size_t i = 0; i < P; ++i) {
             dst_off[i] = total;
             total += tlens[i];
         }
-        packed.resize(total);
+        if (total > p->h_text_size) {  // pinned, so the one big D2H runs at link speed
+            if (p->h_text) (void)hipHostFree(p->h_text);
+            p->h_text = nullptr;
+            p->h_text_size = 0;
+            void* hp = nullptr;
+            if (!hip_ok(hipHostMalloc(&hp, total + total / 4 + 4096, hipHostMallocDefault), "hipHostMalloc(cigar text)")) return PA_E_HIP;
+            p->h_text = (uint8_t*)hp;
+            p->h_text_size = total + total / 4 + 4096;
+        }
+        packed = p->h_text;
         if (total) {
             if (!hip_ok(hipMemcpyAsync(p->d_cig_dst_off.ptr, dst_off.data(), P * 8, hipMemcpyHostToDevice, s), "H2D offsets")) return PA_E_HIP;
             hipLaunchKernelGGL(pack_text_kernel, dim3((unsigned)P), dim3(256), 0, s, p->d_text.as<uint8_t>(), p->d_cig_src_off.as<uint64_t>(),
                                p->d_cig_dst_off.as<uint64_t>(), p->d_text_len.as<uint32_t>(), p->d_packed.as<uint8_t>());
             if (!hip_ok(hipGetLastError(), "pack_text_kernel") ||
-                !hip_ok(hipMemcpyAsync(packed.data(), p->d_packed.ptr, total, hipMemcpyDeviceToHost, s), "D2H cigars") ||
+                !hip_ok(hipMemcpyAsync(p->h_text, p->d_packed.ptr, total, hipMemcpyDeviceToHost, s), "D2H cigars") ||
                 !hip_ok(hipStreamSynchronize(s), "sync"))
                 return PA_E_HIP;
         }
     }
+    mark("pack kernel + text D2H");
     const pa_astarpa2_params fallback = traced_batch_params();
     for (size_t i = 0; i < P; ++i) {
         cost_out[i] = costs[i];
         if (!cigar_out) continue;
+        if (lens[i] != kTraceFailed) {  // the common case: one allocation, one copy out of the packed buffer
+            char* out = (char*)std::malloc((size_t)tlens[i] + 1);
+            if (!out) return PA_E_ARG;
+            if (tlens[i]) std::memcpy(out, packed + dst_off[i], tlens[i]);
+            out[tlens[i]] = 0;
+            cigar_out[i] = out;
+            continue;
+        }
+        // a state the reference would panic on: the host engine redoes this pair
         std::string text;
-        if (lens[i] == kTraceFailed) {
-            // taller re-fill than one strip (or a state the reference would panic on): the host engine redoes this pair
-            p->trace_fallbacks += 1;
-            const uint8_t* ha = nullptr;
-            const uint8_t* hb = nullptr;
-            std::vector<uint8_t> ba(p->n[i]), bb(p->m[i]);
-            if ((p->n[i] && !hip_ok(hipMemcpy(ba.data(), p->d_a.as<uint8_t>() + p->a_off[i], p->n[i], hipMemcpyDeviceToHost), "D2H a")) ||
-                (p->m[i] && !hip_ok(hipMemcpy(bb.data(), p->d_b.as<uint8_t>() + p->b_off[i], p->m[i], hipMemcpyDeviceToHost), "D2H b")))
-                return PA_E_HIP;
-            ha = ba.data();
-            hb = bb.data();
-            int32_t c = 0;
-            const int rc = align_hip(ha, p->n[i], hb, p->m[i], fallback, true, false, &c, &text, nullptr);
-            if (rc != 0) return rc;
-            if (c != costs[i]) {
-                set_error("traceback fallback disagrees with the batched cost (pair %zu: %d vs %d)", i, c, costs[i]);
-                return PA_E_INTERNAL;
-            }
-        } else {
-            text.assign(reinterpret_cast<const char*>(packed.data()) + dst_off[i], tlens[i]);
+        p->trace_fallbacks += 1;
+        std::vector<uint8_t> ba(p->n[i]), bb(p->m[i]);
+        if ((p->n[i] && !hip_ok(hipMemcpy(ba.data(), p->d_a.as<uint8_t>() + p->a_off[i], p->n[i], hipMemcpyDeviceToHost), "D2H a")) ||
+            (p->m[i] && !hip_ok(hipMemcpy(bb.data(), p->d_b.as<uint8_t>() + p->b_off[i], p->m[i], hipMemcpyDeviceToHost), "D2H b")))
+            return PA_E_HIP;
+        int32_t c = 0;
+        const int rc = align_hip(ba.data(), p->n[i], bb.data(), p->m[i], fallback, true, false, &c, &text, nullptr);
+        if (rc != 0) return rc;
+        if (c != costs[i]) {
+            set_error("traceback fallback disagrees with the batched cost (pair %zu: %d vs %d)", i, c, costs[i]);
+            return PA_E_INTERNAL;
         }
         cigar_out[i] = (char*)std::malloc(text.size() + 1);
         if (!cigar_out[i]) return PA_E_ARG;
         std::memcpy(cigar_out[i], text.c_str(), text.size() + 1);
     }
+    mark("strings to the caller");
     return 0;
 }
 

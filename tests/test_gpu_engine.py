@@ -126,3 +126,36 @@ def test_c_program_links_and_runs(tmp_path):
     for l in lines:
         name, cost, cigar, n = l.split()
         assert cost == "2" and int(n) == len(cigar) and re.fullmatch(r"(\d*[=XID])+", cigar)
+
+
+def test_c_abi_is_reentrant_across_threads(pa, oracle):
+    """astarpa-c is stateless and re-entrant: several host threads align different pairs at the same time."""
+    import threading
+
+    from tests.util_seq import gen_pair
+
+    pairs = [gen_pair(3000 + 257 * t, 0.03 + 0.02 * t, seed=90 + t) for t in range(6)]
+    want = [oracle.levenshtein(a, b) for a, b in pairs]
+    results = [None] * len(pairs)
+    errors = []
+
+    def work(t):
+        try:
+            out = []
+            for _ in range(3):
+                out.append(pa.c_abi_align("astarpa2_simple" if t % 2 else "astarpa2_full", *pairs[t]))
+            results[t] = out
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(len(pairs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors, errors
+    for t, out in enumerate(results):
+        assert out is not None
+        for cost, cigar in out:
+            assert cost == want[t] and oracle.cigar_verify(cigar, *pairs[t]) == cost
+        assert len({c for _, c in out}) == 1  # deterministic

@@ -27,6 +27,7 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -371,6 +372,13 @@ struct Block {
 
 enum class HMode { None, Input, Update, Output };  // blocks.rs:665-671
 
+// A backend MAY offer `compute_chain(i0, i1, segs, nseg, params)`: the ranges of one incrementally doubled block in one go
+// (same results as calling `compute` for each in order; returns the last sum).  The CPU backend does not.
+template <class B, class = void>
+struct has_compute_chain : std::false_type {};
+template <class B>
+struct has_compute_chain<B, std::void_t<typename B::ChainSeg>> : std::true_type {};
+
 // Backend concept (implemented by HipBackend in engine_hip.hip and by the test-only CpuBackend):
 //   I n() const; I m() const;                       sequence lengths
 //   const uint8_t* a() const; const uint8_t* b() const;   raw ASCII (trace uses them, trace.rs:443-500)
@@ -457,6 +465,18 @@ class Blocks {
             stats.num_incremental_blocks += 1;
         }
         return be.compute(ir.s, ir.e, vr.s, vr.e, v, mode, params);
+    }
+
+    // The same accounting as one compute_block per segment (blocks.rs:704-712), then one backend call for all of them.
+    template <class Seg>
+    Cost compute_chain(IRange ir, const Seg* segs, int nseg) {
+        for (int k = 0; k < nseg; ++k) {
+            if (ir.len() > 1) {
+                stats.computed_lanes += segs[k].w1 - segs[k].w0;
+                stats.num_incremental_blocks += 1;
+            }
+        }
+        return be.compute_chain(ir.s, ir.e, segs, nseg, params);
     }
 
     static void init_v_with_overlap(const Block& prev, Block& next) {  // blocks.rs:753-767
@@ -591,9 +611,18 @@ class Blocks {
             const VRange v1 = v_range_of(JRange{old_j_h, new_j_h});
             const VRange v2 = v_range_of(JRange{new_j_h, j_range.e});
             PA_ASSERT(v2.s <= v2.e, "v_range_2");
-            compute_block(ir, v0, next_block.v.data() + (v0.s - offset), HMode::None);
-            if (!v1.empty()) compute_block(ir, v1, next_block.v.data() + (v1.s - offset), HMode::Update);
-            next_block.bot_val += compute_block(ir, v2, next_block.v.data() + (v2.s - offset), HMode::Input);
+            if constexpr (has_compute_chain<Backend>::value) {
+                typename Backend::ChainSeg segs[3];
+                int ns = 0;
+                segs[ns++] = {v0.s, v0.e, next_block.v.data() + (v0.s - offset), HMode::None};
+                if (!v1.empty()) segs[ns++] = {v1.s, v1.e, next_block.v.data() + (v1.s - offset), HMode::Update};
+                segs[ns++] = {v2.s, v2.e, next_block.v.data() + (v2.s - offset), HMode::Input};
+                next_block.bot_val += compute_chain(ir, segs, ns);
+            } else {
+                compute_block(ir, v0, next_block.v.data() + (v0.s - offset), HMode::None);
+                if (!v1.empty()) compute_block(ir, v1, next_block.v.data() + (v1.s - offset), HMode::Update);
+                next_block.bot_val += compute_block(ir, v2, next_block.v.data() + (v2.s - offset), HMode::Input);
+            }
         } else {
             init_v_with_overlap(prev_block, next_block);
             const VRange v01 = v_range_of(JRange{j_range.s, new_j_h});
@@ -601,8 +630,14 @@ class Blocks {
             const VRange v2 = v_range_of(JRange{new_j_h, j_range.e});
             PA_ASSERT(v2.s <= v2.e, "v_range_2");
             // NOTE: an empty output range must still run to set the stored row (blocks.rs:443-455)
-            compute_block(ir, v01, next_block.v.data() + (v01.s - offset), HMode::Output);
-            next_block.bot_val += compute_block(ir, v2, next_block.v.data() + (v2.s - offset), HMode::Input);
+            if constexpr (has_compute_chain<Backend>::value) {
+                typename Backend::ChainSeg segs[2] = {{v01.s, v01.e, next_block.v.data() + (v01.s - offset), HMode::Output},
+                                                      {v2.s, v2.e, next_block.v.data() + (v2.s - offset), HMode::Input}};
+                next_block.bot_val += compute_chain(ir, segs, 2);
+            } else {
+                compute_block(ir, v01, next_block.v.data() + (v01.s - offset), HMode::Output);
+                next_block.bot_val += compute_block(ir, v2, next_block.v.data() + (v2.s - offset), HMode::Input);
+            }
         }
 
         if (self_check) {  // blocks.rs:471-543

@@ -179,6 +179,89 @@ struct HipBackend {
         return (Cost)(int32_t)mb[2];
     }
 
+    // The ranges of one block of the incremental doubling (blocks.rs:370-469) in ONE launch.  Equivalent to calling
+    // compute() for every segment in order; the bottom-row sum of the last segment is returned.
+    struct ChainSeg {
+        size_t w0, w1;
+        V* v;
+        HMode mode;
+    };
+    Cost compute_chain(I i0, I i1, const ChainSeg* segs, int nseg, const BlockParams& bp) {
+        const I n = i1 - i0;
+        static const bool no_fast = getenv("PA_ENGINE_NO_FAST_PATH") != nullptr || getenv("PA_ENGINE_NO_CHAIN") != nullptr;
+        bool fuse = !no_fast && n > 0 && nseg >= 2 && nseg <= 3 && has_h;
+        size_t strips = 0, lo = SIZE_MAX, hi = 0;
+        for (int k = 0; k < nseg && fuse; ++k) {
+            if (segs[k].w0 >= segs[k].w1) fuse = false;  // empty ranges have side effects of their own (see compute())
+            if (k > 0 && segs[k].w0 < segs[k - 1].w1) fuse = false;
+            strips += (segs[k].w1 - segs[k].w0 + kWordsPerStrip - 1) / kWordsPerStrip;
+            lo = std::min(lo, segs[k].w0);
+            hi = std::max(hi, segs[k].w1);
+        }
+        if (fuse && strips > 1024) fuse = false;
+        if (!fuse) {
+            Cost last = 0;
+            for (int k = 0; k < nseg; ++k) last = compute(i0, i1, segs[k].w0, segs[k].w1, segs[k].v, segs[k].mode, bp);
+            return last;
+        }
+        const size_t G = (size_t)(n + 31) / 32;
+        ensure_mailbox(hi - lo);
+        ensure_granules(strips * G);
+        volatile uint32_t* mb = reinterpret_cast<volatile uint32_t*>(mbox);
+        for (int k = 0; k < nseg; ++k) std::memcpy(mbox + kMboxV + (segs[k].w0 - lo) * 16, segs[k].v, (segs[k].w1 - segs[k].w0) * 16);
+        mb[1] = 0;
+        mb[2] = 0;
+        ++seq;
+        ChainArgs r;
+        r.a_codes = d_codes.as<uint32_t>();
+        r.b_prof = d_prof.as<uint32_t>();
+        r.v = reinterpret_cast<uint32_t*>(mbox_dev + kMboxV) - lo * 4;
+        r.h_arr = d_h.as<uint8_t>();
+        r.gran = d_gran.as<uint64_t>();
+        r.gran_stride = G;
+        r.sum_out = reinterpret_cast<int32_t*>(mbox_dev) + 2;
+        r.err = reinterpret_cast<uint32_t*>(mbox_dev) + 1;
+        r.done = reinterpret_cast<uint32_t*>(mbox_dev);
+        r.counter = d_counter.as<uint32_t>();
+        r.n = n;
+        r.col0 = i0;
+        r.nseg = nseg;
+        r.seq = seq;
+        bool prev_stores = false;
+        for (int k = 0; k < 3; ++k) {
+            r.w0[k] = r.w1[k] = r.top[k] = r.store[k] = 0;
+            if (k >= nseg) continue;
+            r.w0[k] = (int32_t)segs[k].w0;
+            r.w1[k] = (int32_t)segs[k].w1;
+            const HMode m = segs[k].mode;
+            r.store[k] = (m == HMode::Update || m == HMode::Output) ? 1 : 0;
+            if (m == HMode::None || m == HMode::Output) r.top[k] = kTopOne;
+            else if (prev_stores && k > 0 && segs[k - 1].w1 == segs[k].w0) r.top[k] = kTopChain;  // the row the segment above stores
+            else r.top[k] = kTopStored;
+            prev_stores = r.store[k] != 0;
+        }
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        hipLaunchKernelGGL((rect_chain_kernel<1>), dim3((unsigned)strips), dim3(64), 0, s, r);
+        if (!hip_ok(hipGetLastError(), "rect_chain_kernel launch")) fail(PA_E_HIP);
+        uint64_t spins = 0;
+        while (__atomic_load_n(reinterpret_cast<uint32_t*>(mbox), __ATOMIC_ACQUIRE) != seq) {
+            if ((++spins & 0xFFFFF) == 0 && hipStreamQuery(s) != hipErrorNotReady) {
+                if (!hip_ok(hipStreamSynchronize(s), "sync")) fail(PA_E_HIP);
+                if (__atomic_load_n(reinterpret_cast<uint32_t*>(mbox), __ATOMIC_ACQUIRE) != seq) {
+                    set_error("rect_chain_kernel finished without signalling completion");
+                    fail(PA_E_INTERNAL);
+                }
+            }
+        }
+        if (mb[1] != PA_ERR_NONE) {
+            set_error("device spin timeout (err=%u)", (unsigned)mb[1]);
+            gran_zeroed = 0;
+            fail(PA_E_TIMEOUT);
+        }
+        for (int k = 0; k < nseg; ++k) std::memcpy(segs[k].v, mbox + kMboxV + (segs[k].w0 - lo) * 16, (segs[k].w1 - segs[k].w0) * 16);
+        return (Cost)(int32_t)mb[2];
+    }
+
     // One rectangle launch.  hin/hout are device byte rows indexed by absolute column (or nullptr).
     // Per call: ONE H2D of a pinned staging image [ticket,err,sum,pad | v words | jobs] into `d_call`, an optional
     // granule clear (only when the rectangle spans several strips), the launch, ONE D2H of [misc | v], one sync.

@@ -609,6 +609,77 @@ __global__ __launch_bounds__(64) void rect_kernel(RectArgs r) {
     }
 }
 
+// Up to three vertically stacked rectangles of one 256-column block in ONE launch: the ranges of the engine's incremental
+// doubling (blocks.rs:370-469: None / Update / Input, or Output / Input).  Segments are independent except that a
+// segment with top == kTopChain takes the bottom row of the segment before it, which is the row that segment also stores
+// into the persistent h row -- exactly what a separate launch would have read back from there.
+enum : int32_t { kTopOne = 0, kTopStored = 1, kTopChain = 2 };
+struct ChainArgs {
+    const uint32_t* a_codes;
+    const uint32_t* b_prof;
+    uint32_t* v;            // host-mapped, biased so that it is indexed by absolute word
+    uint8_t* h_arr;         // the persistent h row (device), one byte per absolute column
+    uint64_t* gran;         // one row of gran_stride granules per strip of the launch, all zero between launches
+    uint64_t gran_stride;
+    int32_t* sum_out;       // host-mapped: bottom-row sum of the LAST segment
+    uint32_t* err;
+    uint32_t* done;
+    uint32_t* counter;
+    int32_t n, col0, nseg;
+    uint32_t seq;
+    int32_t w0[3], w1[3], top[3], store[3];
+};
+
+template <int K>
+__global__ __launch_bounds__(64) void rect_chain_kernel(ChainArgs r) {
+    const int b = (int)blockIdx.x, total = (int)gridDim.x;
+    const int lane = (int)(threadIdx.x & 63);
+    constexpr int wps = 32 * K;
+    int g = 0, s = b;
+    for (; g < r.nseg; ++g) {
+        const int S = (r.w1[g] - r.w0[g] + wps - 1) / wps;
+        if (s < S) break;
+        s -= S;
+    }
+    const int S = (r.w1[g] - r.w0[g] + wps - 1) / wps;
+    const bool last = s + 1 == S;
+    const bool feeds_next = last && g + 1 < r.nseg && r.top[g + 1] == kTopChain;
+    StripJob j;
+    j.a_codes = r.a_codes;
+    j.b_prof = r.b_prof;
+    j.v = r.v;
+    j.hin_gran = (s > 0 || r.top[g] == kTopChain) ? r.gran + (size_t)(b - 1) * r.gran_stride : nullptr;
+    j.hin_arr = (s == 0 && r.top[g] == kTopStored) ? r.h_arr : nullptr;
+    j.hout_gran = (!last || feeds_next) ? r.gran + (size_t)b * r.gran_stride : nullptr;
+    j.hout_arr = (last && r.store[g]) ? r.h_arr : nullptr;
+    j.values = nullptr;
+    j.sum_out = (last && g + 1 == r.nseg) ? r.sum_out : nullptr;
+    j.n = r.n;
+    j.word0 = r.w0[g] + s * wps;
+    const int words = (r.w1[g] - j.word0) < wps ? (r.w1[g] - j.word0) : wps;
+    j.nlanes = 2 * words;
+    j.fill_stride = 0;
+    j.fill_word0 = 0;
+    j.exact_tail = (!last || feeds_next || r.store[g]) ? 1 : 0;
+    j.flags = 0;
+    j.col0 = r.col0;
+    j.tail_rows = -1;
+    j.k = K;
+    j.ckpt = nullptr;
+    j.ckpt_stride = 0;
+    j.hin_n = 0;
+    j.vsum_out = nullptr;
+    run_strip<K, false, false>(j, r.err);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    uint32_t c = 0;
+    if (lane == 0) c = __hip_atomic_fetch_add(r.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    c = rfl(c);
+    if (c == (uint32_t)(total - 1) && lane == 0) {
+        __hip_atomic_store(r.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(r.done, r.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // Sequential-pairs variant: one wavefront runs ALL strips of one rectangle top to bottom (jobs[first[p]] ..
 // jobs[first[p+1]-1]); the bottom row of strip s goes through the same granule rows (two per rectangle, ping-pong) but
 // is produced and consumed by the same wavefront, so nothing ever polls.  With >= one rectangle per SIMD this removes the

@@ -392,6 +392,23 @@ struct HipBackend {
     }
 };
 
+// The engine's bookkeeping without any kernel work (used where the numbers come from a fused GPU pass).
+struct StatsOnlyBackend {
+    const uint8_t* a_;
+    size_t n_;
+    const uint8_t* b_;
+    size_t m_;
+    I n() const { return (I)n_; }
+    I m() const { return (I)m_; }
+    const uint8_t* a() const { return a_; }
+    const uint8_t* b() const { return b_; }
+    void enable_h_row() {}
+    Cost compute(I, I, size_t, size_t, V*, HMode, const BlockParams&) { return 0; }
+    void fill(I, I, size_t, size_t, V*, V*, int8_t*, const BlockParams&) {}
+    std::vector<int8_t> debug_read_h(I, I) { return {}; }
+    void debug_write_h(I, I, const std::vector<int8_t>&) {}
+};
+
 // Shared by pa_align and the astarpa-c symbols.  Returns 0 or a PA_E_* code.
 int align_hip(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params& params,
               bool trace, bool self_check, int32_t* cost_out, std::string* cigar_out, pa_astarpa2_stats* stats_out) {
@@ -403,9 +420,37 @@ int align_hip(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, co
         set_error("sequence too long for i32 coordinates");
         return PA_E_ARG;
     }
+    const engine::AstarPa2Params p = engine::params_from_c(params);
+    if (!trace && !self_check && a_len > 0 && b_len > 0 && p.domain == engine::DomainKind::Full && p.doubling == engine::DoublingKind::None) {
+        // AstarPa2Params::nw().make_aligner(false): the whole matrix, cost only (blocks.rs:252-277: one block updated in
+        // place, 256 columns per operator call).  The values do not depend on the schedule, so the cost comes from ONE
+        // launch of chained strips (pa_batch of one pair) instead of |a|/256 launches; the statistics come from the host
+        // engine walked over a backend that computes nothing (they depend on the lengths only).
+        const uint8_t* aa[1] = {a};
+        const uint8_t* bb[1] = {b};
+        const size_t al[1] = {a_len}, bl[1] = {b_len};
+        pa_batch* bt = pa_batch_create(aa, al, bb, bl, 1);
+        if (!bt) return PA_E_HIP;
+        int32_t c = 0;
+        const int rc = pa_batch_run(bt, &c, nullptr);
+        pa_batch_destroy(bt);
+        if (rc != 0) return rc;
+        if (stats_out) {
+            StatsOnlyBackend sb{a, a_len, b, b_len};
+            try {
+                const engine::AlignResult r = engine::cost_or_align(p, sb, false, false);
+                engine::stats_to_c(r.stats, stats_out);
+            } catch (const engine::EnginePanic& e) {
+                set_error("astarpa2 engine panic: %s", e.what());
+                return PA_E_INTERNAL;
+            }
+        }
+        if (cost_out) *cost_out = c;
+        if (cigar_out) cigar_out->clear();
+        return 0;
+    }
     HipBackend be(a, a_len, b, b_len);
     if (!be.ok) return be.err ? be.err : PA_E_HIP;
-    const engine::AstarPa2Params p = engine::params_from_c(params);
     engine::AlignResult r;
     try {
         r = engine::cost_or_align(p, be, trace, self_check);

@@ -96,6 +96,9 @@ def test_cost_only_mode(pa, oracle):
     for oc in (oracle.params_nw(), oracle.params_simple()):
         want, _, _ = oracle.cpu_align(a, b, oc, trace=False)
         assert gpu_params(pa, oc).make_aligner(False).align(a, b) == (want, None)
+    # nw cost-only runs as ONE launch of chained strips; cost and every band statistic still equal the block-by-block engine
+    for a, b in (gen_pair(4000, 0.1, 5), gen_pair(257, 0.3, 6), gen_pair(70_000, 0.04, 7), (b"ACGT", b"A")):
+        both(pa, oracle, a, b, oracle.params_nw(), trace=False)
 
 
 def test_invalid_base_raises(pa):

@@ -1185,16 +1185,45 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
     if (!hip_ok(hipStreamCreate(&p->stream), "hipStreamCreate") || !hip_ok(hipEventCreate(&p->ev0), "event") ||
         !hip_ok(hipEventCreate(&p->ev1), "event") || !hip_ok(hipEventCreate(&p->ev2), "event"))
         return nullptr;
-    {  // one upload per side: gather the sequences into the device layout on the host first
-        std::vector<uint8_t> ha(ta, 0), hb(tb, 0);
-        for (size_t i = 0; i < pairs; ++i) {
-            if (a_len[i]) std::memcpy(ha.data() + p->a_off[i], a[i], a_len[i]);
-            if (b_len[i]) std::memcpy(hb.data() + p->b_off[i], b[i], b_len[i]);
+    // Upload: the sequences are gathered into the device layout through two pinned staging buffers, so that the copy of one
+    // chunk overlaps the gathering of the next and runs at link speed (a pageable H2D of 800 MB costs 5x as much).
+    {
+        const size_t kChunk = size_t(32) << 20;
+        uint8_t* stage[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};
+        bool ok = true;
+        for (int k = 0; k < 2 && ok; ++k) {
+            void* hp = nullptr;
+            ok = hip_ok(hipHostMalloc(&hp, kChunk, hipHostMallocDefault), "hipHostMalloc(upload staging)") && hip_ok(hipEventCreate(&done[k]), "event");
+            stage[k] = (uint8_t*)hp;
         }
-        if ((ta && !hip_ok(hipMemcpyAsync(p->d_a.ptr, ha.data(), ta, hipMemcpyHostToDevice, p->stream), "H2D a")) ||
-            (tb && !hip_ok(hipMemcpyAsync(p->d_b.ptr, hb.data(), tb, hipMemcpyHostToDevice, p->stream), "H2D b")) ||
-            !hip_ok(hipStreamSynchronize(p->stream), "sync"))
-            return nullptr;
+        bool used[2] = {false, false};  // a staging buffer is reused only after its previous copy has finished
+        int buf = 0;
+        auto upload = [&](uint8_t* dev, const std::vector<size_t>& off, const uint8_t* const* src, const size_t* len, size_t total) {
+            // walk the device image [0, total) in chunks; every chunk is assembled from the pairs that intersect it
+            size_t pair = 0;
+            for (size_t base = 0; base < total && ok; base += kChunk, buf ^= 1) {
+                const size_t end = std::min(total, base + kChunk);
+                if (used[buf]) ok = hip_ok(hipEventSynchronize(done[buf]), "event sync");
+                std::memset(stage[buf], 0, end - base);
+                while (pair < pairs && off[pair] + len[pair] <= base) ++pair;
+                for (size_t q = pair; q < pairs && off[q] < end; ++q) {
+                    const size_t lo = std::max(off[q], base), hi = std::min(off[q] + len[q], end);
+                    if (lo < hi) std::memcpy(stage[buf] + (lo - base), src[q] + (lo - off[q]), hi - lo);
+                }
+                ok = ok && hip_ok(hipMemcpyAsync(dev + base, stage[buf], end - base, hipMemcpyHostToDevice, p->stream), "H2D sequences") &&
+                     hip_ok(hipEventRecord(done[buf], p->stream), "event");
+                used[buf] = true;
+            }
+        };
+        if (ok) upload(p->d_a.as<uint8_t>(), p->a_off, a, a_len, ta);
+        if (ok) upload(p->d_b.as<uint8_t>(), p->b_off, b, b_len, tb);
+        ok = ok && hip_ok(hipStreamSynchronize(p->stream), "sync");
+        for (int k = 0; k < 2; ++k) {
+            if (stage[k]) (void)hipHostFree(stage[k]);
+            if (done[k]) (void)hipEventDestroy(done[k]);
+        }
+        if (!ok) return nullptr;
     }
     // Jobs: pair-major, strips of a pair consecutive (ticket order == dependency order).
     p->last_job.assign(pairs, -1);

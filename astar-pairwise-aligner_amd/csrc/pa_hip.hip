@@ -1165,14 +1165,14 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             p->ckpt_off.push_back(tck);
             p->cigar_off.push_back(tcg);
             p->word_off.push_back(tw);
-            tw += std::max<size_t>(w, 1);
+            tw += std::min<size_t>(std::max<size_t>(w, 1), (size_t)kTraceScratchWords);
             tck += (a_len[i] / 256 + 1) * w * 4;  // u32: one V column per 256 columns of a (slot 0 unused)
             tcg += a_len[i] + b_len[i] + 2;
         }
         if (tcg >= (size_t(1) << 62) || !p->d_ckpt.alloc(tck * 4) || !p->d_cigar.alloc(tcg * 4) || !p->d_packed.alloc(tcg) || !p->d_text.alloc(tcg) ||
             !p->d_text_len.alloc(std::max<size_t>(pairs * 4, 16)) ||
             !p->d_cigar_len.alloc(std::max<size_t>(pairs * 4, 16)) || !p->d_costs.alloc(std::max<size_t>(pairs * 4, 16)) ||
-            // re-fill scratch: a block's sub-rectangle can be as tall as the pair (256 columns x w words of V)
+            // re-fill scratch: 256 columns x min(w, kTraceScratchWords) words of V per pair
             !p->d_scratch_v.alloc(std::max<size_t>(tw, 1) * 16) || !p->d_scratch_vals.alloc(std::max<size_t>(tw, 1) * 256 * 16) ||
             !p->d_scratch_gran.alloc(std::max<size_t>(pairs, 1) * 16 * 8) ||
             !p->d_tjobs.alloc(std::max<size_t>(pairs, 1) * sizeof(TraceJob)) || !p->d_cig_src_off.alloc(std::max<size_t>(pairs, 1) * 8) ||
@@ -1189,13 +1189,22 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
     // chunk overlaps the gathering of the next and runs at link speed (a pageable H2D of 800 MB costs 5x as much).
     {
         const size_t kChunk = size_t(32) << 20;
+        // the two pinned buffers are kept for the life of the process (pinning 64 MB costs more than uploading 200 MB);
+        // one creation at a time uses them
+        static std::mutex stage_mutex;
+        static uint8_t* stage_cache[2] = {nullptr, nullptr};
+        std::lock_guard<std::mutex> stage_lock(stage_mutex);
         uint8_t* stage[2] = {nullptr, nullptr};
         hipEvent_t done[2] = {nullptr, nullptr};
         bool ok = true;
         for (int k = 0; k < 2 && ok; ++k) {
-            void* hp = nullptr;
-            ok = hip_ok(hipHostMalloc(&hp, kChunk, hipHostMallocDefault), "hipHostMalloc(upload staging)") && hip_ok(hipEventCreate(&done[k]), "event");
-            stage[k] = (uint8_t*)hp;
+            if (!stage_cache[k]) {
+                void* hp = nullptr;
+                ok = hip_ok(hipHostMalloc(&hp, kChunk, hipHostMallocDefault), "hipHostMalloc(upload staging)");
+                stage_cache[k] = (uint8_t*)hp;
+            }
+            ok = ok && hip_ok(hipEventCreate(&done[k]), "event");
+            stage[k] = stage_cache[k];
         }
         bool used[2] = {false, false};  // a staging buffer is reused only after its previous copy has finished
         int buf = 0;
@@ -1205,12 +1214,16 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             for (size_t base = 0; base < total && ok; base += kChunk, buf ^= 1) {
                 const size_t end = std::min(total, base + kChunk);
                 if (used[buf]) ok = hip_ok(hipEventSynchronize(done[buf]), "event sync");
-                std::memset(stage[buf], 0, end - base);
                 while (pair < pairs && off[pair] + len[pair] <= base) ++pair;
+                size_t cur = base;  // only the padding between two sequences needs zeroing
                 for (size_t q = pair; q < pairs && off[q] < end; ++q) {
                     const size_t lo = std::max(off[q], base), hi = std::min(off[q] + len[q], end);
-                    if (lo < hi) std::memcpy(stage[buf] + (lo - base), src[q] + (lo - off[q]), hi - lo);
+                    if (lo >= hi) continue;
+                    if (lo > cur) std::memset(stage[buf] + (cur - base), 0, lo - cur);
+                    std::memcpy(stage[buf] + (lo - base), src[q] + (lo - off[q]), hi - lo);
+                    cur = hi;
                 }
+                if (end > cur) std::memset(stage[buf] + (cur - base), 0, end - cur);
                 ok = ok && hip_ok(hipMemcpyAsync(dev + base, stage[buf], end - base, hipMemcpyHostToDevice, p->stream), "H2D sequences") &&
                      hip_ok(hipEventRecord(done[buf], p->stream), "event");
                 used[buf] = true;
@@ -1219,10 +1232,8 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
         if (ok) upload(p->d_a.as<uint8_t>(), p->a_off, a, a_len, ta);
         if (ok) upload(p->d_b.as<uint8_t>(), p->b_off, b, b_len, tb);
         ok = ok && hip_ok(hipStreamSynchronize(p->stream), "sync");
-        for (int k = 0; k < 2; ++k) {
-            if (stage[k]) (void)hipHostFree(stage[k]);
+        for (int k = 0; k < 2; ++k)
             if (done[k]) (void)hipEventDestroy(done[k]);
-        }
         if (!ok) return nullptr;
     }
     // Jobs: pair-major, strips of a pair consecutive (ticket order == dependency order).
@@ -1297,6 +1308,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             t.scratch_v = p->d_scratch_v.as<uint32_t>() + p->word_off[i] * 4;
             t.scratch_vals = p->d_scratch_vals.as<uint32_t>() + p->word_off[i] * 256 * 4;
             t.scratch_gran = p->d_scratch_gran.as<uint64_t>() + i * 16;
+            t.scratch_words = (int32_t)std::min<size_t>(std::max<size_t>((b_len[i] + 63) / 64, 1), (size_t)kTraceScratchWords);
             t.n = (int32_t)a_len[i];
             t.m = (int32_t)b_len[i];
             t.w = (int32_t)((b_len[i] + 63) / 64);

@@ -12,8 +12,8 @@
 //      columns until it crosses the checkpoint column.
 // All control flow is wavefront-uniform; the lanes are used for the fill, for prefix sums over a column (Block::index)
 // and for 64-at-a-time match extension.  A re-fill taller than one strip (2048 rows: a huge indel inside one block) runs
-// as several strips one after the other, like pair_kernel.  A pair that hits a state the reference itself would panic on is
-// flagged and redone by the host engine.
+// as several strips one after the other, like pair_kernel, up to kTraceScratchWords words.  A pair that needs more, or that
+// hits a state the reference itself would panic on, is flagged and redone by the host engine.
 #pragma once
 #include "strip_kernel.hpp"
 
@@ -30,13 +30,17 @@ struct TraceJob {
     uint32_t* cigar;           // out: elements (count << 2) | op, from the END of the alignment to its start
     uint32_t* cigar_len;       // out: number of elements, or kTraceFailed
     int32_t* cost_out;         // out: the edit distance
-    uint32_t* scratch_v;       // w words x 4 u32
-    uint32_t* scratch_vals;    // 256 columns x w words x 4 u32 (a re-fill may need the full height)
+    uint32_t* scratch_v;       // scratch_words words x 4 u32
+    uint32_t* scratch_vals;    // 256 columns x scratch_words words x 4 u32
+    int32_t scratch_words;     // tallest re-fill this pair's scratch can hold (min(w, kTraceScratchWords) words)
     uint64_t* scratch_gran;    // 2 rows x 8 granules, zero between uses (multi-strip re-fills hand their bottom row down)
     int32_t n, m, w;           // |a|, |b|, words of b
     uint32_t cigar_cap;
 };
 enum : uint32_t { kTraceFailed = 0xFFFFFFFFu };
+// Re-fills of up to 128 words (8192 rows, four strips) stay on the GPU; a pair with a taller one (an indel of more than
+// ~8000 rows inside one 256-column block) is flagged for the host engine instead of sizing every pair's scratch for it.
+constexpr int kTraceScratchWords = 128;
 enum : uint32_t { kOpMatch = 0, kOpSub = 1, kOpIns = 2, kOpDel = 3 };  // '=', 'X', 'I' (advances b), 'D' (advances a)
 
 __device__ __forceinline__ int32_t wave_sum(int32_t x) {
@@ -149,6 +153,10 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void trace_kernel(const Trac
                 const int jlo_raw = to_j - height > 0 ? to_j - height : 0;
                 const int jlo = jlo_raw & ~63, jhi = (to_j + 63) & ~63;
                 const int words = (jhi - jlo) >> 6;
+                if (words > tj.scratch_words) {  // taller than this pair's scratch: leave it to the host engine
+                    failed = true;
+                    break;
+                }
                 // left column = the checkpoint's words of these rows (init_v_with_overlap, blocks.rs:753-767)
                 for (int wi = lane; wi < words; wi += 64) {
 #pragma unroll

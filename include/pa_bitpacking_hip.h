@@ -106,7 +106,8 @@ void pa_batch_destroy(pa_batch* plan);
  * sub-block, doubling; greedy matches, then insertion / deletion / substitution).  The result is what
  * `pa_align(.., pa_params_batch_align(), trace = 1, ..)` returns for each pair, i.e. AstarPa2Params::nw() with
  * front.sparse = true.  cigar_out[i] is a malloc'ed "=I4=X="-style string (release with astarpa_free_cigar / free).
- * A pair that reaches a state the reference itself would panic on is redone by the host engine transparently. */
+ * A pair whose traceback needs a re-fill taller than 8192 rows (an indel of that size inside one 256-column block), or that
+ * reaches a state the reference itself would panic on, is redone by the host engine transparently. */
 pa_batch* pa_batch_create_trace(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b,
                                 const size_t* b_len, size_t pairs);
 int pa_batch_align(pa_batch* plan, int32_t* cost_out, char** cigar_out, float* forward_ms, float* trace_ms);

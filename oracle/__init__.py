@@ -276,3 +276,36 @@ def gcsh_probe(a: bytes, b: bytes, k: int, p: int, queries):
     mo = np.zeros((cap, 2), np.int32)
     cnt = L.pa_cpu_gcsh_probe(_buf(a), len(a), _buf(b), len(b), k, p, _p(qi), _p(qj), len(queries), _p(out), _p(mo), cap)
     return out.tolist(), [tuple(x) for x in mo[:cnt].tolist()]
+
+
+_slib = None
+
+
+def sweep_emu_lib() -> C.CDLL:
+    global _slib
+    if _slib is None:
+        build()
+        L = C.CDLL(str(_DIR / "_build" / "libpa_sweep_emu.so"))
+        L.pa_sweep_emu_align.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(AstarPa2ParamsC), C.c_int, C.c_int,
+                                         C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(AstarPa2StatsC), C.c_void_p]
+        L.pa_sweep_emu_align.restype = C.c_int
+        L.pa_sweep_jr_end.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p] + [C.c_int32] * 6
+        L.pa_sweep_jr_end.restype = C.c_int32
+        _slib = L
+    return _slib
+
+
+def sweep_emu_align(a: bytes, b: bytes, params: AstarPa2ParamsC, trace: bool = True, nwaves: int = 4):
+    """The product's device-side sweep (sweep_wave.hpp) run on emulated wavefronts (host threads).
+    -> (rc, cost, cigar, stats, info); rc 0 = ran, 1 = parameters not supported, 2 = the sweep asked for the host fallback."""
+    cost = C.c_int32(0)
+    cig = C.c_void_p(None)
+    stats = AstarPa2StatsC()
+    info = np.zeros(8, np.int32)
+    rc = sweep_emu_lib().pa_sweep_emu_align(_buf(a), len(a), _buf(b), len(b), C.byref(params), int(trace), nwaves,
+                                            C.byref(cost), C.byref(cig), C.byref(stats), _p(info))
+    s = None
+    if cig.value:
+        s = C.string_at(cig.value).decode()
+        engine_lib().pa_cpu_free(cig)
+    return rc, cost.value, s, stats.as_dict(), info.tolist()

@@ -1,0 +1,246 @@
+/*
+ * oracle/sweep_emu.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Runs the product's device-side A*PA2 sweep (astar-pairwise-aligner_amd/csrc/sweep_wave.hpp + sweep_host.hpp) WITHOUT a
+ * GPU: the wave program is instantiated over the array-emulated wavefront of host_wave.hpp and every wavefront is a host
+ * thread, so the band logic, the block-boundary bookkeeping and the hand-off protocol between strips are exercised by the
+ * CPU test-suite.  Expected values come from the host-driven engine over the oracle kernels (engine_cpu.cpp).
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../astar-pairwise-aligner_amd/csrc/sweep_host.hpp"
+#include "cpu_backend.hpp"
+#include "host_wave.hpp"
+
+using namespace pa::engine;
+using namespace pa::sweep;
+using pa_host_wave::HostWave;
+using pa_oracle_cpu::CpuBackend;
+
+namespace {
+
+struct HostLauncher {
+    const uint8_t *a, *b;
+    int32_t n = 0, m = 0, nblk = 0;
+    const int32_t* sh_h = nullptr;
+    bool trace = false;
+    int nwaves = 4;
+    uint32_t pass_id = 0;
+    uint64_t spin_limit = 1ull << 24;
+    std::vector<uint32_t> codes, prof;
+    std::vector<BlockRec> d_old;
+    std::vector<BRec> brec;
+    std::vector<TRec> trec;
+    std::vector<uint64_t> strip_start, pring, gran, col;
+    uint64_t bprog = 0;
+    Status status;
+    uint32_t ticket = 0;
+    PassGeometry geo;
+    Status last_status;
+
+    void begin_pair(int32_t n_, int32_t m_, int32_t nblk_, const int32_t* sh, bool tr) {
+        n = n_;
+        m = m_;
+        nblk = nblk_;
+        sh_h = sh;
+        trace = tr;
+        codes.assign((size_t)(n + 15) / 16 + 16, 0);
+        for (int32_t i = 0; i < n; ++i) {
+            const uint8_t ch = a[i];
+            const uint32_t r = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
+            codes[(size_t)i / 16] |= r << (2 * (i % 16));
+        }
+        const size_t wt = (size_t)(m + 63) / 64;
+        std::vector<pa_bits_t> pa_(n ? n : 1), pb_(wt ? wt : 1);
+        pa_or_bitprofile_build(a, (size_t)n, b, (size_t)m, pa_.data(), pb_.data());
+        prof.assign(wt * 4 + 4, 0);
+        std::memcpy(prof.data(), pb_.data(), wt * 16);
+        BlockRec none;
+        none.js = none.je = none.ojs = none.oje = none.fs = none.fe = kNone;
+        none.top_val = none.bot_val = 0;
+        d_old.assign((size_t)nblk + 2, none);
+        brec.assign((size_t)nblk + 2, BRec{});
+        trec.assign((size_t)nblk + 2, TRec{});
+    }
+    BlockRec read_old(int32_t k) { return d_old[(size_t)k]; }
+    void write_old(int32_t k, const BlockRec& r) { d_old[(size_t)k] = r; }
+
+    Status run_pass(int32_t f_max, int32_t sparse_h, const PassInit& init) {
+        pass_id += 1;
+        geo = pass_geometry(n, m, f_max);
+        strip_start.resize((size_t)geo.nstrips, 0);
+        pring.resize((size_t)geo.nstrips * geo.pr_stride, 0);
+        gran.assign((size_t)geo.nstrips * geo.gran_stride, 0);
+        const size_t slots = trace ? (size_t)nblk + 1 : (size_t)geo.col_ring;
+        col.assign(slots * (size_t)geo.col_stride * 2, 0);
+        std::memset(&status, 0, sizeof(status));
+        ticket = 0;
+        const uint32_t t1 = blk_tag(pass_id, 1);
+        BRec& b1 = brec[1];
+        b1.js = tw_make(t1, init.js1);
+        b1.je = tw_make(t1, init.je1);
+        b1.ojs = tw_make(t1, init.ojs1);
+        b1.oje = tw_make(t1, init.oje1);
+        b1.flags = tw_make(t1, init.flags1);
+        b1.smax = tw_make(t1, init.last_strip);
+        b1.specmax = tw_make(t1, 0);
+        TRec& tr1 = trec[1];
+        tr1.js = tw_make(t1, init.js1);
+        tr1.top_val = tw_make(t1, init.top1);
+        tr1.fs_prev = tw_make(t1, init.fs0);
+        tr1.lim = tw_make(t1, 0);
+        tr1.found = tw_make(t1, 0);
+        tr1.state = tw_make(t1, kTDesc);
+        for (int32_t r = 0; r <= init.last_strip && r < geo.nstrips; ++r) strip_start[(size_t)r] = tw_make(pass_id, 1);
+        bprog = tw_make(t1, init.oje1);
+
+        Ctx c;
+        c.a_codes = codes.data();
+        c.b_prof = prof.data();
+        c.n = n;
+        c.m = m;
+        c.nblk = nblk;
+        c.wtot = geo.wtot;
+        c.f_max = f_max;
+        c.pass = pass_id;
+        c.heur = sh_h ? kHeurSH : heur_kind;
+        c.sparse_h = sparse_h;
+        c.sh_h = sh_h;
+        c.store_cols = trace ? 1 : 0;
+        c.d_old = d_old.data();
+        c.brec = brec.data();
+        c.trec = trec.data();
+        c.bprog = &bprog;
+        c.strip_start = strip_start.data();
+        c.pring = pring.data();
+        c.pr_stride = geo.pr_stride;
+        c.gran = gran.data();
+        c.gran_stride = geo.gran_stride;
+        c.win = geo.win;
+        c.col = col.data();
+        c.col_stride = geo.col_stride;
+        c.col_ring = geo.col_ring;
+        c.status = &status;
+        c.ticket = &ticket;
+        c.nstrips = geo.nstrips;
+        c.nwaves = nwaves < geo.nstrips ? nwaves : geo.nstrips;
+        c.spin_limit = spin_limit;
+        std::vector<std::thread> th;
+        for (int w = 0; w < c.nwaves; ++w) th.emplace_back([&c]() { wave_main<HostWave>(c); });
+        for (auto& t : th) t.join();
+        last_status = status;
+        return status;
+    }
+    int32_t heur_kind = kHeurGap;
+
+    void commit(int32_t k_end, int32_t k_fixed) {
+        if (std::getenv("PA_SWEEP_DEBUG")) {
+            std::fprintf(stderr, "pass %u state=%u value=%d k_end=%d k_fixed=%d\n", pass_id, status.state, status.value, k_end, k_fixed);
+            for (int32_t k = 1; k <= k_end && k <= nblk; ++k) {
+                const BRec& s = brec[(size_t)k];
+                std::fprintf(stderr, "  i=(%d,%d] j_range=[%d,%d] fixed=[%d,%d] top=%d bot=%d\n", (k - 1) * kBlockW, k * kBlockW < n ? k * kBlockW : n,
+                             tw_val(s.ojs), tw_val(s.oje), k <= k_fixed ? tw_val(s.fs) : -9, k <= k_fixed ? tw_val(s.fe) : -9,
+                             k <= k_fixed ? tw_val(s.top_val) : -9, k <= k_fixed ? tw_val(s.bot_val) : -9);
+            }
+        }
+        for (int32_t k = 1; k <= k_end && k <= nblk; ++k) {
+            BlockRec& d = d_old[(size_t)k];
+            const BRec& s = brec[(size_t)k];
+            d.js = tw_val(s.js);
+            d.je = tw_val(s.je);
+            d.ojs = tw_val(s.ojs);
+            d.oje = tw_val(s.oje);
+            if (k <= k_fixed) {
+                d.fs = tw_val(s.fs);
+                d.fe = tw_val(s.fe);
+                d.top_val = tw_val(s.top_val);
+                d.bot_val = tw_val(s.bot_val);
+            }
+        }
+    }
+    void read_blocks(std::vector<Block>& blocks) {
+        for (int32_t k = 1; k <= nblk; ++k) {
+            Block& bl = blocks[(size_t)k];
+            const BRec& s = brec[(size_t)k];
+            const int32_t js = tw_val(s.js), je = tw_val(s.je);
+            bl.i_range = IRange{(k - 1) * kBlockW, k * kBlockW < n ? k * kBlockW : n};
+            bl.original_j_range = JRange{tw_val(s.ojs), tw_val(s.oje)};
+            bl.j_range = JRange{js, je};
+            bl.fixed_j_range = JRange{tw_val(s.fs), tw_val(s.fe)};
+            bl.offset = js;
+            bl.top_val = tw_val(s.top_val);
+            bl.bot_val = tw_val(s.bot_val);
+            bl.j_h.reset();
+            bl.v.resize((size_t)(je - js) / 64);
+            Ctx c;
+            c.win = geo.win;
+            c.store_cols = 1;
+            c.col_ring = geo.col_ring;
+            c.n = n;
+            const uint64_t* colk = col.data() + ((int64_t)k * geo.col_stride - col_base_word(c, k)) * 2;
+            for (size_t w = 0; w < bl.v.size(); ++w) {
+                bl.v[w].p = colk[2 * ((size_t)js / 64 + w)];
+                bl.v[w].m = colk[2 * ((size_t)js / 64 + w) + 1];
+            }
+        }
+    }
+};
+
+}  // namespace
+
+// Same contract as pa_cpu_align (engine_cpu.cpp); info[0] = 1 if the sweep ran, 0 if the parameters are not supported,
+// negative = the sweep asked for the fallback (abort reason), info[1..] = last pass's status words.
+extern "C" int pa_sweep_emu_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params* params,
+                                  int trace, int nwaves, int32_t* cost_out, char** cigar_out, pa_astarpa2_stats* stats_out,
+                                  int32_t* info) {
+    if (!params || !params_valid(*params)) return -4;
+    const AstarPa2Params p = params_from_c(*params);
+    if (info) info[0] = 0;
+    if (!sweep_supported(p, a_len, b_len)) return 1;
+    CpuBackend be(a, a_len, b, b_len);
+    if (!be.ok) return -1;
+    HostLauncher dev;
+    dev.a = a;
+    dev.b = b;
+    dev.nwaves = nwaves > 0 ? nwaves : 4;
+    dev.heur_kind = p.heuristic == HeuristicKind::Gap ? kHeurGap : p.heuristic == HeuristicKind::SH ? kHeurSH : kHeurNone;
+    AlignResult r;
+    try {
+        SweepAligner<CpuBackend, HostLauncher> al(p, be, dev, trace != 0);
+        r = al.align();
+    } catch (const SweepFallback& e) {
+        if (info) {
+            info[0] = -1000 - e.reason;
+            info[1] = (int32_t)dev.last_status.state;
+            info[2] = dev.last_status.value;
+            info[3] = dev.last_status.k_end;
+        }
+        return 2;
+    } catch (const EnginePanic& e) {
+        std::fprintf(stderr, "sweep emu: engine panic: %s\n", e.what());
+        return -5;
+    }
+    if (info) info[0] = 1;
+    if (cost_out) *cost_out = r.cost;
+    if (cigar_out) {
+        *cigar_out = nullptr;
+        if (r.has_cigar) {
+            const std::string s = r.cigar.to_string();
+            *cigar_out = (char*)std::malloc(s.size() + 1);
+            std::memcpy(*cigar_out, s.c_str(), s.size() + 1);
+        }
+    }
+    if (stats_out) stats_to_c(r.stats, stats_out);
+    return 0;
+}
+
+// Test hooks for sweep_logic.hpp: the fast-forwarded j_range end against the literal loops of engine.hpp.
+extern "C" int32_t pa_sweep_jr_end(int32_t kind, int32_t n, int32_t m, const int32_t* sh_h, int32_t is, int32_t ie, int32_t fixed_end,
+                                   int32_t gu, int32_t f_max, int32_t sparse_h) {
+    HeurParams hp{kind, n, m, sh_h};
+    return jr_end_astar(hp, is, ie, fixed_end, gu, f_max, sparse_h);
+}

@@ -10,6 +10,8 @@
 
 #include "engine_capi.hpp"
 #include "pa_hip_internal.hpp"
+#include "sweep_host.hpp"
+#include "sweep_kernel.hpp"
 
 namespace pa {
 
@@ -38,13 +40,27 @@ struct HipBackend {
     DeviceBuf d_counter;
     size_t gran_zeroed = 0;  // granules of d_gran known to be zero (the strips hand every granule back zeroed)
 
-    HipBackend(const uint8_t* a, size_t n, const uint8_t* b, size_t m) : a_(a, a + n), b_(b, b + m) {
+    int device = -1;  // the device the pooled buffers live on
+
+    HipBackend() = default;
+    HipBackend(const uint8_t* a, size_t n, const uint8_t* b, size_t m) { bind(a, n, b, m); }
+
+    // (Re)bind the backend to a pair.  Buffers, the stream and the mailbox are kept from call to call (a thread-local pool,
+    // see pooled_backend()): a relinked astarpa-c user calls astarpa2_simple in a loop, and six hipMallocs + a stream per
+    // call cost more than a short alignment.
+    void bind(const uint8_t* a, size_t n, const uint8_t* b, size_t m) {
+        ok = false;
+        err = 0;
+        has_h = false;
+        a_.assign(a, a + n);
+        b_.assign(b, b + m);
         if (!ensure_device()) { err = PA_E_HIP; return; }
+        (void)hipGetDevice(&device);
         w_total = (m + 63) / 64;
-        const size_t cw = (n + 15) / 16 + 2;
-        if (!d_a.alloc(n) || !d_b.alloc(m) || !d_codes.alloc(cw * 4) || !d_prof.alloc(w_total * 16) ||
-            !d_misc.alloc(16) || !d_htmp.alloc(n + 64)) { err = PA_E_HIP; return; }
-        if (!hip_ok(hipStreamCreate(&s), "hipStreamCreate")) { err = PA_E_HIP; return; }
+        const size_t cw = (n + 15) / 16 + 16;  // the sweep kernel reads up to 8 words past the last column's
+        if (!d_a.reserve(n) || !d_b.reserve(m) || !d_codes.reserve(cw * 4) || !d_prof.reserve(w_total * 16 + 16) ||
+            !d_misc.reserve(16) || !d_htmp.reserve(n + 64)) { err = PA_E_HIP; return; }
+        if (!s && !hip_ok(hipStreamCreate(&s), "hipStreamCreate")) { err = PA_E_HIP; return; }
         bool good = hip_ok(hipMemsetAsync(d_codes.ptr, 0, cw * 4, s), "memset") &&
                     hip_ok(hipMemsetAsync(d_misc.ptr, 0, 16, s), "memset") &&
                     (n == 0 || hip_ok(hipMemcpyAsync(d_a.ptr, a, n, hipMemcpyHostToDevice, s), "H2D a")) &&
@@ -80,7 +96,7 @@ struct HipBackend {
 
     void enable_h_row() {  // blocks.rs:119-123: vec![(0,0); a.len()]
         if (has_h) return;
-        if (!d_h.alloc(a_.size() + 64) || !hip_ok(hipMemsetAsync(d_h.ptr, 0, a_.size() + 64, s), "memset h")) fail(PA_E_HIP);
+        if (!d_h.reserve(a_.size() + 64) || !hip_ok(hipMemsetAsync(d_h.ptr, 0, a_.size() + 64, s), "memset h")) fail(PA_E_HIP);
         has_h = true;
     }
 
@@ -392,6 +408,272 @@ struct HipBackend {
     }
 };
 
+// One backend per host thread and device, reused from call to call.
+static HipBackend& pooled_backend() {
+    static thread_local std::unique_ptr<HipBackend> tl;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!tl || (tl->device >= 0 && tl->device != dev)) tl = std::make_unique<HipBackend>();
+    return *tl;
+}
+
+// ---- the device-side sweep: one launch per align_for_bounded_dist pass (sweep_wave.hpp) ---------------------------------
+// Launcher of sweep::SweepAligner over HIP.  Its buffers are pooled per host thread like the backend's.
+struct SweepPool {
+    DeviceBuf d_old, d_brec, d_trec, d_misc, d_start, d_pring, d_gran, d_col, d_sh, d_recs, d_offs, d_pack;
+    void* h_pin = nullptr;
+    size_t h_pin_size = 0;
+    uint32_t pass_id = 0;
+    int device = -1;
+    ~SweepPool() {
+        if (h_pin) (void)hipHostFree(h_pin);
+    }
+    void* pinned(size_t bytes) {
+        if (bytes > h_pin_size) {
+            if (h_pin) (void)hipHostFree(h_pin);
+            h_pin = nullptr;
+            h_pin_size = 0;
+            const size_t want = std::max<size_t>(bytes * 2, 1 << 16);
+            if (!hip_ok(hipHostMalloc(&h_pin, want, hipHostMallocDefault), "hipHostMalloc")) return nullptr;
+            h_pin_size = want;
+        }
+        return h_pin;
+    }
+};
+static SweepPool& sweep_pool() {
+    static thread_local std::unique_ptr<SweepPool> tl;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!tl || tl->device != dev) {
+        tl = std::make_unique<SweepPool>();
+        tl->device = dev;
+    }
+    return *tl;
+}
+
+struct HipSweepLauncher {
+    HipBackend& be;
+    SweepPool& pool;
+    int32_t n = 0, m = 0, nblk = 0;
+    bool trace = false;
+    bool has_sh = false;
+    int32_t heur_kind = sweep::kHeurGap;
+    sweep::PassGeometry geo{};
+    sweep::BlockRec old1{};
+    float kernel_ms = 0.0f;  // device time of the sweep kernels of this pair
+
+    HipSweepLauncher(HipBackend& backend, SweepPool& p) : be(backend), pool(p) {}
+
+    void hip_fail(const char* what) { throw sweep::SweepFallback(what, -2); }
+    static bool timing_on() {
+        static const bool on = std::getenv("PA_SWEEP_TIMING") != nullptr;
+        return on;
+    }
+
+    // bytes of a zero-initialised tagged buffer: cleared only when it is new (tags of older passes never match)
+    void reserve_tagged(DeviceBuf& b, size_t bytes) {
+        bool grew = false;
+        if (!b.reserve(bytes, &grew)) hip_fail("hipMalloc");
+        if (grew && !hip_ok(hipMemsetAsync(b.ptr, 0, b.size, be.s), "memset")) hip_fail("memset");
+    }
+
+    void begin_pair(int32_t n_, int32_t m_, int32_t nblk_, const int32_t* sh, bool tr) {
+        n = n_;
+        m = m_;
+        nblk = nblk_;
+        trace = tr;
+        has_sh = sh != nullptr;
+        old1.js = sweep::kNone;
+        const size_t recs = (size_t)nblk + 2;
+        if (!pool.d_old.reserve(recs * sizeof(sweep::BlockRec)) ||
+            !hip_ok(hipMemsetD32Async((hipDeviceptr_t)pool.d_old.ptr, (int)sweep::kNone, recs * sizeof(sweep::BlockRec) / 4, be.s), "memset d_old"))
+            hip_fail("d_old");
+        reserve_tagged(pool.d_brec, recs * sizeof(sweep::BRec));
+        reserve_tagged(pool.d_trec, recs * sizeof(sweep::TRec));
+        reserve_tagged(pool.d_misc, 1024);
+        if (has_sh) {
+            if (!pool.d_sh.reserve(((size_t)n + 1) * 4) ||
+                !hip_ok(hipMemcpyAsync(pool.d_sh.ptr, sh, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, be.s), "H2D sh"))
+                hip_fail("sh table");
+        }
+    }
+
+    sweep::BlockRec read_old(int32_t k) {
+        if (k == 1) return old1;
+        sweep::BlockRec r;
+        if (!hip_ok(hipMemcpyAsync(&r, pool.d_old.as<sweep::BlockRec>() + k, sizeof(r), hipMemcpyDeviceToHost, be.s), "D2H rec") ||
+            !hip_ok(hipStreamSynchronize(be.s), "sync"))
+            hip_fail("read_old");
+        return r;
+    }
+    void write_old(int32_t, const sweep::BlockRec&) {}  // the first column's record is only read by the host
+
+    uint64_t* misc_bprog() { return pool.d_misc.as<uint64_t>(); }
+    uint32_t* misc_ticket() { return pool.d_misc.as<uint32_t>() + 4; }
+    sweep::Status* misc_status() { return reinterpret_cast<sweep::Status*>(pool.d_misc.as<uint8_t>() + 64); }
+
+    sweep::Status run_pass(int32_t f_max, int32_t sparse_h, const sweep::PassInit& init) {
+        using namespace sweep;
+        if (pool.pass_id >= 4000) {  // tags wrap: start over with clean tagged buffers
+            for (DeviceBuf* b : {&pool.d_brec, &pool.d_trec, &pool.d_start, &pool.d_pring})
+                if (b->ptr && !hip_ok(hipMemsetAsync(b->ptr, 0, b->size, be.s), "memset")) hip_fail("memset");
+            pool.pass_id = 0;
+        }
+        pool.pass_id += 1;
+        geo = pass_geometry(n, m, f_max);
+        const size_t slots = trace ? (size_t)nblk + 1 : (size_t)geo.col_ring;
+        const size_t gran_bytes = (size_t)geo.nstrips * (size_t)geo.gran_stride * 8;
+        const size_t col_bytes = slots * (size_t)geo.col_stride * 16;
+        const size_t pr_bytes = (size_t)geo.nstrips * (size_t)geo.pr_stride * 8;
+        if (gran_bytes + col_bytes + pr_bytes > (size_t)96 << 30) throw SweepFallback("sweep buffers too large", -3);
+        reserve_tagged(pool.d_start, (size_t)geo.nstrips * 8);
+        reserve_tagged(pool.d_pring, pr_bytes);
+        if (!pool.d_gran.reserve(gran_bytes) || !pool.d_col.reserve(col_bytes)) hip_fail("hipMalloc");
+        if (!hip_ok(hipMemsetAsync(pool.d_gran.ptr, 0, gran_bytes, be.s), "memset granules")) hip_fail("memset");
+
+        InitArgs ia;
+        ia.brec = pool.d_brec.as<BRec>();
+        ia.trec = pool.d_trec.as<TRec>();
+        ia.bprog = misc_bprog();
+        ia.strip_start = pool.d_start.as<uint64_t>();
+        ia.status = misc_status();
+        ia.ticket = misc_ticket();
+        ia.pass = pool.pass_id;
+        ia.js1 = init.js1;
+        ia.je1 = init.je1;
+        ia.ojs1 = init.ojs1;
+        ia.oje1 = init.oje1;
+        ia.flags1 = init.flags1;
+        ia.top1 = init.top1;
+        ia.fs0 = init.fs0;
+        ia.last_strip = init.last_strip;
+        ia.nstrips = geo.nstrips;
+        hipLaunchKernelGGL(sweep_init_kernel, dim3(1), dim3(64), 0, be.s, ia);
+
+        Ctx c;
+        c.a_codes = be.d_codes.as<uint32_t>();
+        c.b_prof = be.d_prof.as<uint32_t>();
+        c.n = n;
+        c.m = m;
+        c.nblk = nblk;
+        c.wtot = geo.wtot;
+        c.f_max = f_max;
+        c.pass = pool.pass_id;
+        c.heur = heur_kind;
+        c.sparse_h = sparse_h;
+        c.sh_h = has_sh ? pool.d_sh.as<int32_t>() : nullptr;
+        c.store_cols = trace ? 1 : 0;
+        c.d_old = pool.d_old.as<BlockRec>();
+        c.brec = pool.d_brec.as<BRec>();
+        c.trec = pool.d_trec.as<TRec>();
+        c.bprog = misc_bprog();
+        c.strip_start = pool.d_start.as<uint64_t>();
+        c.pring = pool.d_pring.as<uint64_t>();
+        c.pr_stride = geo.pr_stride;
+        c.gran = pool.d_gran.as<uint64_t>();
+        c.gran_stride = geo.gran_stride;
+        c.win = geo.win;
+        c.col = pool.d_col.as<uint64_t>();
+        c.col_stride = geo.col_stride;
+        c.col_ring = geo.col_ring;
+        c.status = misc_status();
+        c.ticket = misc_ticket();
+        c.nstrips = geo.nstrips;
+        // wavefronts: one per strip the band can cover at a time (+ slack), one workgroup each; at most one per SIMD
+        int64_t waves = (2ll * geo.win) / kStripRows + 6;
+        if (waves > geo.nstrips) waves = geo.nstrips;
+        if (waves > 1024) waves = 1024;
+        c.nwaves = (int32_t)waves;
+        c.spin_limit = 1u << 19;  // ~2 s of backed-off polls
+        c.timing = nullptr;
+        if (timing_on()) {
+            c.timing = pool.d_misc.as<uint64_t>() + 64;  // bytes 512..575 of d_misc
+            (void)hipMemsetAsync(c.timing, 0, 64, be.s);
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool timing = timing_on();
+        if (timing) {
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0, be.s);
+        }
+        hipLaunchKernelGGL(sweep_kernel, dim3((unsigned)c.nwaves), dim3(64), 0, be.s, c);
+        if (timing) (void)hipEventRecord(e1, be.s);
+        hipLaunchKernelGGL(sweep_commit_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, be.s, pool.d_brec.as<BRec>(), pool.d_old.as<BlockRec>(),
+                           misc_status(), nblk);
+        Status* hs = static_cast<Status*>(pool.pinned(sizeof(Status)));
+        if (!hs) hip_fail("pinned");
+        if (!hip_ok(hipGetLastError(), "sweep launch") ||
+            !hip_ok(hipMemcpyAsync(hs, misc_status(), sizeof(Status), hipMemcpyDeviceToHost, be.s), "D2H status") ||
+            !hip_ok(hipStreamSynchronize(be.s), "sync"))
+            hip_fail("sweep pass");
+        if (timing) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            kernel_ms += ms;
+            uint64_t tm[8] = {0};
+            (void)hipMemcpy(tm, c.timing, 64, hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "sweep pass %u: f_max=%d waves=%d state=%u value=%d k_end=%d kernel %.3f ms | strip-us: begin %.0f slow %.0f cross %.0f end %.0f bottom %.0f plain %.0f gran %.0f\n",
+                         pool.pass_id, f_max, c.nwaves, hs->state, hs->value, hs->k_end, ms, tm[0] * 0.01, tm[1] * 0.01, tm[6] * 0.01, tm[2] * 0.01, tm[3] * 0.01, tm[4] * 0.01,
+                         tm[5] * 0.01);
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+        }
+        const Status st = *hs;
+        if ((st.state == kStDone || st.state == kStNoPath) && st.k_end >= 1) {  // block 1's committed record, as the host needs it next pass
+            old1.js = init.js1;
+            old1.je = init.je1;
+            old1.ojs = init.ojs1;
+            old1.oje = init.oje1;
+        }
+        return st;
+    }
+    void commit(int32_t, int32_t) {}  // done on the device right behind the pass (sweep_commit_kernel)
+
+    // The blocks of the pass that just succeeded, for Blocks::trace.
+    void read_blocks(std::vector<engine::Block>& blocks) {
+        using namespace sweep;
+        const size_t recs = (size_t)nblk + 1;
+        if (!pool.d_recs.reserve(recs * sizeof(BlockOut)) || !pool.d_offs.reserve(recs * 8)) hip_fail("hipMalloc");
+        hipLaunchKernelGGL(sweep_records_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, be.s, pool.d_brec.as<BRec>(),
+                           pool.d_recs.as<BlockOut>(), nblk);
+        std::vector<BlockOut> hr(recs);
+        if (!hip_ok(hipMemcpyAsync(hr.data(), pool.d_recs.ptr, recs * sizeof(BlockOut), hipMemcpyDeviceToHost, be.s), "D2H records") ||
+            !hip_ok(hipStreamSynchronize(be.s), "sync"))
+            hip_fail("records");
+        std::vector<int64_t> offs(recs, 0);
+        int64_t total = 0;
+        for (int32_t k = 1; k <= nblk; ++k) {
+            offs[(size_t)k] = total;
+            total += (hr[(size_t)k].je - hr[(size_t)k].js) / 64;
+        }
+        if (!pool.d_pack.reserve((size_t)total * 16 + 16)) hip_fail("hipMalloc");
+        uint64_t* hp = static_cast<uint64_t*>(pool.pinned((size_t)total * 16 + 16));
+        if (!hp) hip_fail("pinned");
+        if (!hip_ok(hipMemcpyAsync(pool.d_offs.ptr, offs.data(), recs * 8, hipMemcpyHostToDevice, be.s), "H2D offsets")) hip_fail("offsets");
+        hipLaunchKernelGGL(sweep_gather_kernel, dim3((unsigned)nblk), dim3(256), 0, be.s, pool.d_col.as<uint64_t>(), geo.col_stride, geo.win,
+                           pool.d_recs.as<BlockOut>(), pool.d_offs.as<int64_t>(), pool.d_pack.as<uint64_t>(), nblk);
+        if (!hip_ok(hipMemcpyAsync(hp, pool.d_pack.ptr, (size_t)total * 16, hipMemcpyDeviceToHost, be.s), "D2H columns") ||
+            !hip_ok(hipStreamSynchronize(be.s), "sync"))
+            hip_fail("columns");
+        for (int32_t k = 1; k <= nblk; ++k) {
+            engine::Block& bl = blocks[(size_t)k];
+            const BlockOut& o = hr[(size_t)k];
+            bl.i_range = engine::IRange{(k - 1) * kBlockW, k * kBlockW < n ? k * kBlockW : n};
+            bl.original_j_range = engine::JRange{o.ojs, o.oje};
+            bl.j_range = engine::JRange{o.js, o.je};
+            bl.fixed_j_range = engine::JRange{o.fs, o.fe};
+            bl.offset = o.js;
+            bl.top_val = o.top_val;
+            bl.bot_val = o.bot_val;
+            bl.j_h.reset();
+            const size_t w = (size_t)(o.je - o.js) / 64;
+            bl.v.resize(w);
+            std::memcpy(bl.v.data(), hp + offs[(size_t)k] * 2, w * 16);
+        }
+    }
+};
+
 // The engine's bookkeeping without any kernel work (used where the numbers come from a fused GPU pass).
 struct StatsOnlyBackend {
     const uint8_t* a_;
@@ -449,9 +731,35 @@ int align_hip(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, co
         if (cigar_out) cigar_out->clear();
         return 0;
     }
-    HipBackend be(a, a_len, b, b_len);
+    HipBackend& be = pooled_backend();
+    be.bind(a, a_len, b, b_len);
     if (!be.ok) return be.err ? be.err : PA_E_HIP;
     engine::AlignResult r;
+    // Domain::Astar with a closed-form / per-column heuristic and the sparse, non-incremental block engine (the `simple`
+    // preset and its relatives): every align_for_bounded_dist pass is ONE persistent launch with the band logic in the kernel
+    // (sweep_wave.hpp).  A pass the kernel hands back (SweepFallback) is redone by the host-driven engine below.
+    static const bool no_sweep = std::getenv("PA_ENGINE_NO_SWEEP") != nullptr;
+    if (!no_sweep && !self_check && sweep::sweep_supported(p, a_len, b_len)) {
+        try {
+            HipSweepLauncher launcher(be, sweep_pool());
+            launcher.heur_kind = p.heuristic == engine::HeuristicKind::Gap ? sweep::kHeurGap
+                                 : p.heuristic == engine::HeuristicKind::SH ? sweep::kHeurSH : sweep::kHeurNone;
+            sweep::SweepAligner<HipBackend, HipSweepLauncher> al(p, be, launcher, trace);
+            r = al.align();
+            if (cost_out) *cost_out = r.cost;
+            if (cigar_out) *cigar_out = r.has_cigar ? r.cigar.to_string() : std::string();
+            if (stats_out) engine::stats_to_c(r.stats, stats_out);
+            return 0;
+        } catch (const sweep::SweepFallback& e) {
+            if (std::getenv("PA_SWEEP_TIMING")) std::fprintf(stderr, "sweep fallback: %s (%d)\n", e.what(), e.reason);
+            be.bind(a, a_len, b, b_len);  // fresh backend state for the host-driven engine
+            if (!be.ok) return be.err ? be.err : PA_E_HIP;
+        } catch (const engine::EnginePanic& e) {
+            if (be.err) return be.err;
+            set_error("astarpa2 engine panic: %s", e.what());
+            return PA_E_INTERNAL;
+        }
+    }
     try {
         r = engine::cost_or_align(p, be, trace, self_check);
     } catch (const engine::EnginePanic& e) {

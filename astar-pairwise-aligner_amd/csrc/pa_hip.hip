@@ -186,6 +186,14 @@ bool DeviceBuf::alloc(size_t bytes) {
     size = bytes;
     return true;
 }
+bool DeviceBuf::reserve(size_t bytes, bool* grew) {
+    if (grew) *grew = false;
+    if (ptr && size >= bytes) return true;
+    const size_t want = bytes + bytes / 4 + 256;  // geometric growth: a pool of buffers reused from call to call
+    if (!alloc(want)) return false;
+    if (grew) *grew = true;
+    return true;
+}
 void DeviceBuf::release() {
     if (ptr) (void)hipFree(ptr);
     ptr = nullptr;

@@ -27,6 +27,8 @@ struct DeviceBuf {
     DeviceBuf& operator=(const DeviceBuf&) = delete;
     ~DeviceBuf() { release(); }
     bool alloc(size_t bytes);
+    // grow-only: keeps the buffer when it is large enough; *grew = true when a new (uninitialised) buffer was allocated
+    bool reserve(size_t bytes, bool* grew = nullptr);
     void release();
     template <class T>
     T* as() const { return reinterpret_cast<T*>(ptr); }

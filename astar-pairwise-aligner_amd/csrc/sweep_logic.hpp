@@ -10,7 +10,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define PA_HD __host__ __device__ inline
+#define PA_HD __host__ __device__ __forceinline__
 #else
 #define PA_HD inline
 #endif
@@ -118,21 +118,22 @@ PA_HD int32_t jr_end_astar(const HeurParams& hp, int32_t is, int32_t ie, int32_t
             // positions p_t = min(v1 + 8t, blen); find the largest t >= 1 such that all p_1..p_{t-1} are ok, i.e. the
             // first t >= 1 with p_t not ok or p_t == blen (the loop then handles p_t itself).
             int32_t lo = 0, hi = 1;  // p_lo ok and != blen
+            // (32-bit: v1 <= blen < 2^30 and the search stops at the first p >= blen, so p < 2 * blen + 8)
             for (;;) {
-                const int64_t p = (int64_t)v1 + 8ll * hi;
-                if (p >= blen || jr_f(hp, gu, u0, u1, v0, (int32_t)p) > f_max) break;
+                const int32_t p = v1 + 8 * hi;
+                if (p >= blen || jr_f(hp, gu, u0, u1, v0, p) > f_max) break;
                 lo = hi;
                 hi *= 2;
             }
             while (hi - lo > 1) {
                 const int32_t mid = lo + (hi - lo) / 2;
-                const int64_t p = (int64_t)v1 + 8ll * mid;
-                if (p < blen && jr_f(hp, gu, u0, u1, v0, (int32_t)p) <= f_max) lo = mid;
+                const int32_t p = v1 + 8 * mid;
+                if (p < blen && jr_f(hp, gu, u0, u1, v0, p) <= f_max) lo = mid;
                 else hi = mid;
             }
             // p_hi is the first position that is not ok or reaches blen: the literal loop arrives there next.
-            const int64_t p = (int64_t)v1 + 8ll * hi;
-            v1 = p >= blen ? blen : (int32_t)p;
+            const int32_t p = v1 + 8 * hi;
+            v1 = p >= blen ? blen : p;
         } else {
             v0 += div_ceil_pos(fv - f_max, 2);
             if (v0 > ie) {

@@ -29,6 +29,22 @@
 #pragma once
 #include "sweep_logic.hpp"
 
+#if defined(__clang__)
+#define PA_NOUNROLL _Pragma("nounroll")
+#else
+#define PA_NOUNROLL _Pragma("GCC unroll 1")
+#endif
+
+// Phase clocks (diagnostics): compiled in with -DPA_SWEEP_PHASE_TIMERS only -- eight 64-bit accumulators are 16 scalar registers
+// the strip state cannot spare.
+#ifdef PA_SWEEP_PHASE_TIMERS
+#define PA_CLK(W) W::clock()
+#define PA_CLK_ADD(acc, expr) acc += (expr)
+#else
+#define PA_CLK(W) 0ull
+#define PA_CLK_ADD(acc, expr) do { } while (0)
+#endif
+
 #ifdef PA_SWEEP_TRACE
 #include <cstdio>
 #define PA_TRACE(...) std::fprintf(stderr, __VA_ARGS__)
@@ -68,30 +84,39 @@ struct Ctx {
     Status* status;
     uint32_t* ticket;
     int32_t nstrips, nwaves;
-    uint64_t spin_limit;      // polls before a wait gives up
+    uint32_t spin_limit;      // polls before a wait gives up
+    uint64_t* timing;         // nullptr, or 8 accumulators of phase clocks (diagnostics)
 };
 
+// NOTE on integer widths: everything a wavefront decides with is uniform and must stay on the scalar unit.  gfx950's SALU has no
+// ordered 64-bit compare, so one int64 `<` sends the value (and everything computed from it: the chunk counter, the block
+// index, every branch on them) to the VALU, where uniform branches turn into EXEC-mask code.  All comparisons here are
+// 32-bit; lengths are < 2^30 (sweep_supported), so k * 256, row and column numbers fit.
 PA_HD int32_t blk_end(const Ctx& c, int32_t k) {  // E_k: one past the last column of block k (block 0 = column 0)
-    const int64_t e = (int64_t)k * kBlockW;
-    return e < c.n ? (int32_t)e : c.n;
+    const int32_t e = k * kBlockW;
+    return e < c.n ? e : c.n;
 }
 PA_HD int32_t col_base_word(const Ctx& c, int32_t k) {  // first V word of block k's column slot
-    const int64_t lo = (int64_t)(k - 1) * kBlockW - c.win;
-    return lo <= 0 ? 0 : (int32_t)(lo >> 6);
+    const int32_t lo = (k - 1) * kBlockW - c.win;
+    return lo <= 0 ? 0 : (lo >> 6);
 }
 PA_HD int64_t col_slot(const Ctx& c, int32_t k) { return c.store_cols ? (int64_t)k : (int64_t)(k & (c.col_ring - 1)); }
 PA_HD uint64_t* pr_word(const Ctx& c, int32_t r, int32_t k) {  // prefix word of strip r for block k (nullptr: outside the window)
-    const int64_t lo = ((int64_t)r * kStripRows - c.win) / kBlockW;
-    const int64_t idx = (int64_t)k - (lo > 0 ? lo : 0);
-    if (idx < 0 || idx >= c.pr_stride) return nullptr;
+    const int32_t lo = (r * kStripRows - c.win) / kBlockW;
+    const int32_t idx = k - (lo > 0 ? lo : 0);
+    if (idx < 0 || idx >= (int32_t)c.pr_stride) return nullptr;
     return c.pring + (int64_t)r * c.pr_stride + idx;
 }
 PA_HD int32_t gran_base(const Ctx& c, int32_t r) {  // first granule (32-column chunk) of the boundary below strip r
-    const int64_t lo = (int64_t)(r + 1) * kStripRows - c.win;
-    return lo <= 0 ? 0 : (int32_t)(lo >> 5);
+    const int32_t lo = (r + 1) * kStripRows - c.win;
+    return lo <= 0 ? 0 : (lo >> 5);
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
+// Flags of the strip state are full ints: byte-sized members next to ints get merged into overlapping wider loads, which
+// keeps that slice of the state in scratch memory -- and whatever is loaded from scratch counts as divergent.
+typedef int32_t flag_t;
+
 template <class W>
 struct StripProg {
     using vec = typename W::vec;
@@ -99,32 +124,36 @@ struct StripProg {
     HeurParams hp;
     int32_t r, row0, rowE;
     // lane state
-    vec lane, lrow0, vp, vm, nb0, nb1, X, acc_lo, acc_hi, snap_p, snap_m, andm, orm, basev;
+    vec lane, lrow0, vp, vm, nb0, nb1, X, acc_lo, acc_hi, snap_p, snap_m, andm, orm, basev, fpend;
     // block state
     int32_t kc;                          // the block lane 0 is in
     int32_t js_c, top_c, fsprev_c;       // top-edge record of block kc
     int32_t je_c, oje_c;                 // bottom-edge record of block kc (valid at its crossing unless bot_interior)
-    bool bot_interior;
+    flag_t bot_interior;
     int32_t js_n, top_n, fs_n, lim_n, found_n;  // top-edge record of block kc + 1
-    bool have_n;
-    bool is_top;                         // the band's first row is (or was) inside this strip: FORCE variant
-    bool gran_on;                        // lane 0 takes its horizontal deltas from the strip above
+    flag_t have_n;
+    flag_t is_top;                         // the band's first row is (or was) inside this strip: FORCE variant
+    flag_t gran_on;                      // lane 0 takes its horizontal deltas from the strip above
     // top-down scan of block kc
-    bool sc_active;
-    int32_t sc_j, sc_e, sc_base, sc_base_prev, sc_base0;
+    flag_t sc_active;
+    int32_t sc_j, sc_e, sc_base0;
     int32_t old_fs_c, old_js_n;          // older passes: fixed start of block kc, range start of block kc + 1
-    bool alive;                          // false: stop (pass over, abort, timeout)
+    flag_t alive;                        // false: stop (pass over, abort, timeout)
     // deferred flag publications (after the payload stores have drained)
-    uint64_t* dq_ptr[4];
-    uint64_t dq_val[4];
-    int dq_n;
+    uint64_t st_num_blocks = 0, st_unique = 0, st_computed = 0, st_incremental = 0;  // my share of the pass's BlockStats
+    uint64_t t_cross2 = 0;
+    uint64_t t_begin = 0, t_cross = 0, t_end = 0, t_bottom = 0, t_plain = 0, t_wait_gran = 0;  // phase clocks (W::clock ticks)
+    int32_t pend_k, pend_p, pend_cont_j;  // deferred publications (see flush_deferred)
+    flag_t pend_cont;
 
     PA_HD StripProg(const Ctx& ctx) : c(ctx) {
         hp.kind = c.heur;
         hp.n = c.n;
         hp.m = c.m;
         hp.sh_h = c.sh_h;
-        dq_n = 0;
+        pend_k = -1;
+        pend_p = pend_cont_j = 0;
+        pend_cont = false;
         alive = true;
     }
 
@@ -142,8 +171,8 @@ struct StripProg {
     PA_HD void abort_pass(int32_t reason) { finish(kStAbort, reason, 0, 0); }
 
     // Poll a tagged word until its tag matches.  Returns false when the pass is over / timed out.
-    PA_HD bool wait_word(const uint64_t* p, uint32_t tag, int32_t* out) {
-        uint64_t spins = 0;
+    PA_HD bool wait_word(const uint64_t* p, uint32_t tag, int32_t* out, bool no_timeout = false) {
+        uint32_t spins = 0;
         for (;;) {
             const uint64_t w = W::load_u64(p);
             if (tw_tag(w) == tag) {
@@ -160,7 +189,7 @@ struct StripProg {
                     PA_TRACE("pass %u strip %d block %d: wait_word slow: tag want %x have %llx  off trec %ld brec %ld pring %ld start %ld\n", c.pass, r, kc, tag,
                              (unsigned long long)W::load_u64(p), (long)((const char*)p - (const char*)c.trec), (long)((const char*)p - (const char*)c.brec),
                              (long)((const char*)p - (const char*)c.pring), (long)((const char*)p - (const char*)c.strip_start));
-                if (spins > c.spin_limit) {
+                if (spins > c.spin_limit && !no_timeout) {
                     PA_TRACE("pass %u strip %d block %d: wait_word timeout: tag want %x have %llx  off trec %ld brec %ld pring %ld start %ld\n", c.pass, r, kc, tag,
                              (unsigned long long)W::load_u64(p), (long)((const char*)p - (const char*)c.trec), (long)((const char*)p - (const char*)c.brec),
                              (long)((const char*)p - (const char*)c.pring), (long)((const char*)p - (const char*)c.strip_start));
@@ -257,9 +286,16 @@ struct StripProg {
             is_top = true;
             return true;
         }
-        if (!wait_word(&t->js, btag(k), &js_n) || !wait_word(&t->top_val, btag(k), &top_n) || !wait_word(&t->fs_prev, btag(k), &fs_n) ||
-            !wait_word(&t->lim, btag(k), &lim_n) || !wait_word(&t->found, btag(k), &found_n))
+        // (locals, not &member: a member whose address is taken stays in scratch, and scratch loads count as divergent)
+        int32_t a_js, a_top, a_fs, a_lim, a_found;
+        if (!wait_word(&t->js, btag(k), &a_js) || !wait_word(&t->top_val, btag(k), &a_top) || !wait_word(&t->fs_prev, btag(k), &a_fs) ||
+            !wait_word(&t->lim, btag(k), &a_lim) || !wait_word(&t->found, btag(k), &a_found))
             return false;
+        js_n = a_js;
+        top_n = a_top;
+        fs_n = a_fs;
+        lim_n = a_lim;
+        found_n = a_found;
         have_n = true;
         return true;
     }
@@ -295,16 +331,14 @@ struct StripProg {
         W::store_u64(&c.trec[kc + 1].state, tw_make(btag(kc + 1), kTEmpty));
         finish(kStNoPath, 0, kc, kc - 1);
     }
-    // Hook of lane `cl` crossing out of block kc.  v of lane cl = its final state of block kc.
-    PA_HD void scan_hook(int32_t cl) {
-        if (cl < sc_e) return;
-        if (cl == sc_e) {
-            sc_base = sc_base0;
-            sc_base_prev = sc_base0;
-        } else {
-            sc_base_prev = sc_base;
-            sc_base += popdiff(W::readlane(snap_p, cl - 1), W::readlane(snap_m, cl - 1));
-        }
+    // The scan probes rows of lane `cl`, which is leaving block kc in this very step: its V is the block's final one, the lanes
+    // above it have left already (their final V is in the snapshot registers).  Called at the few steps per block where the
+    // scanned row's lane crosses -- everything else in a crossing chunk stays on the unrolled step code.
+    PA_HD void scan_probe(int32_t cl) {
+        // index_kc(first row of lane cl) = value at the scan's first lane + the column sums in between
+        const typename W::mask between = W::and_m(W::ge_i(lane, sc_e), W::lt_i(lane, cl));
+        const int32_t base = sc_base0 + (int32_t)W::reduce_add(W::select(between, W::popc_v(snap_p) - W::popc_v(snap_m), W::splat(0u)));
+        const int32_t base_prev = cl > sc_e ? base - popdiff(W::readlane(snap_p, cl - 1), W::readlane(snap_m, cl - 1)) : base;
         const int32_t l0 = row0 + 32 * cl;
         const int32_t ie = blk_end(c, kc);
         while (sc_active && sc_j < l0 + 32) {
@@ -316,22 +350,31 @@ struct StripProg {
                     abort_pass(kAbortOldAbove);
                     return;
                 }
-                scan_finish(old_fs_c, 0, sc_j, e1 == cl ? sc_base : sc_base_prev);
+                scan_finish(old_fs_c, 0, sc_j, e1 == cl ? base : base_prev);
                 return;
             }
             if (past_end) {
                 scan_empty();
                 return;
             }
-            const int32_t f = sc_base + prefix_of(W::readlane(vp, cl), W::readlane(vm, cl), sc_j - l0) + heur_h(hp, ie, sc_j);
+            const int32_t f = base + prefix_of(W::readlane(vp, cl), W::readlane(vm, cl), sc_j - l0) + heur_h(hp, ie, sc_j);
             if (f <= c.f_max) {
                 const int32_t e1 = lane_of(floor64(sc_j));
-                scan_finish(sc_j, 1, sc_j, e1 == cl ? sc_base : sc_base_prev);
+                scan_finish(sc_j, 1, sc_j, e1 == cl ? base : base_prev);
                 return;
             }
             sc_j += c.sparse_h ? div_ceil_pos(f - c.f_max, 2) : 1;
             if (old_fs_c != kNone && sc_j > old_fs_c) sc_j = old_fs_c;
         }
+        // the scan moves on to a later lane: the lanes up to it leave the block with the scan still open
+        if (sc_active) force_pending(cl, lane_of(sc_j));
+    }
+    // Even lanes in (lo, hi] may hold the first row of block kc + 1 (its range starts at a multiple of 64): when they cross they
+    // start forcing their incoming horizontal delta to +1 (blocks.rs:730-734).  Lanes that turn out to lie above the new first
+    // row compute values nobody reads.
+    PA_HD void force_pending(int32_t lo, int32_t hi) {
+        const typename W::mask m = W::and_m(W::and_m(W::gt_i(lane, lo), W::le_i(lane, hi)), W::eq_u(lane & 1u, 0u));
+        fpend = W::select(m, W::splat(1u), fpend);
     }
 
     // ---- one Myers step for all lanes ------------------------------------------------------------------------------
@@ -341,69 +384,109 @@ struct StripProg {
     }
 
     // ---- block boundary, part 1: lane 0 is about to leave block kc ------------------------------------------------------
+    // Everything this boundary needs from other wavefronts is fetched with ONE round of vector loads (lane l reads word l
+    // of a record): the pass status, the bottom-edge progress word, block kc's bottom-edge record, block kc + 1's top-edge
+    // record and the older passes' records of blocks kc and kc + 1.  A second round happens only when something is not
+    // there yet.
+    vec brv_lo, brv_hi;  // BRec[kc], lane l = word l (kept for the bottom-edge logic)
+    vec oldv;            // d_old[kc], d_old[kc + 1] as 16 ints
+    enum { kBjs = 0, kBje = 1, kBojs = 2, kBoje = 3, kBflags = 4, kBfs = 5, kBfe = 6, kBbot = 7, kBtop = 8, kBsmax = 9, kBspec = 10 };
+    enum { kTstate = 0, kTjs = 1, kTtop = 2, kTfs = 3, kTlim = 4, kTfound = 5, kTcont = 6 };
+    PA_HD int32_t old_field(int rec, int f) const { return W::readlane_i(oldv, rec * 8 + f); }  // BlockRec field order
+
     PA_HD bool boundary_begin() {
         PA_TRACE("pass %u strip %d boundary_begin block %d js=%d fsprev=%d\n", c.pass, r, kc, js_c, fsprev_c);
-        if (pass_over()) {
-            alive = false;
-            return false;
-        }
-        old_fs_c = c.d_old[kc].fs;
-        old_js_n = kc + 1 <= c.nblk ? c.d_old[kc + 1].js : kNone;
         have_n = false;
         sc_active = false;
-        // bottom edge of block kc (needed for the resets and the column store of this crossing).  A strip well above the
-        // last decided bottom edge does not wait for the decision of block kc: the bottom edge moves up by at most
-        // kMaxShrink rows per block (checked by the bottom-edge logic for every block), so after `lag` undecided blocks it
-        // is still below my last row.
-        {
-            bot_interior = false;
-            uint64_t spins = 0;
-            for (;;) {  // whichever comes first: the bottom edge is provably below me, or block kc's record is there
-                const uint64_t bp = W::load_u64(c.bprog);
-                const int32_t qb = (tw_tag(bp) >> 20) == (c.pass & 0xFFFu) ? (int32_t)(tw_tag(bp) & 0xFFFFFu) : INT32_MAX;
-                if (qb < kc && (int64_t)rowE + (int64_t)kMaxShrink * (kc - qb) < (int64_t)tw_val(bp)) {
+        bot_interior = false;
+        fpend = W::splat(0u);
+        const bool scan_owner = fsprev_c >= row0 && fsprev_c < rowE && js_c >= row0;
+        const bool dead = !scan_owner && rowE <= js_c;
+        const bool need_t = !scan_owner && !dead;
+        bool bot_done = false, t_done = !need_t;
+        const uint32_t tk = btag(kc), tn = btag(kc + 1);
+        W::load_i32s(reinterpret_cast<const int32_t*>(c.d_old + kc), kc + 1 <= c.nblk ? 16 : 8, oldv);
+        uint32_t spins = 0;
+        for (;;) {
+            vec st_lo, st_hi, bp_lo, bp_hi, tr_lo, tr_hi;
+            W::load_words(reinterpret_cast<const uint64_t*>(c.status), 1, st_lo, st_hi);
+            W::load_words(c.bprog, 1, bp_lo, bp_hi);
+            W::load_words(reinterpret_cast<const uint64_t*>(c.brec + kc), 11, brv_lo, brv_hi);
+            if (!t_done) W::load_words(reinterpret_cast<const uint64_t*>(c.trec + (kc + 1)), 7, tr_lo, tr_hi);
+            if (W::readlane(st_lo, 0) != kStRunning) {
+                alive = false;
+                return false;
+            }
+            if (!bot_done) {
+                // A strip well above the last decided bottom edge does not wait for the decision of block kc: the bottom edge
+                // moves up by at most kMaxShrink rows per block in the sense checked by the bottom-edge logic (see there), so
+                // after `kc - qb` undecided blocks it is still below my last row.
+                const uint32_t bt = W::readlane(bp_hi, 0);
+                const int32_t qb = (bt >> 20) == (c.pass & 0xFFFu) ? (int32_t)(bt & 0xFFFFFu) : INT32_MAX;
+                if (qb < kc && kc - qb < (1 << 19) && rowE + kMaxShrink * (kc - qb) < W::readlane_i(bp_lo, 0)) {
                     bot_interior = true;
-                    break;
-                }
-                const uint64_t wje = W::load_u64(&c.brec[kc].je), woje = W::load_u64(&c.brec[kc].oje);
-                if (tw_tag(wje) == btag(kc) && tw_tag(woje) == btag(kc)) {
-                    je_c = tw_val(wje);
-                    oje_c = tw_val(woje);
+                    bot_done = true;
+                } else if (W::readlane(brv_hi, kBje) == tk && W::readlane(brv_hi, kBoje) == tk) {
+                    je_c = W::readlane_i(brv_lo, kBje);
+                    oje_c = W::readlane_i(brv_lo, kBoje);
                     if (rowE < oje_c) bot_interior = true;  // band rows below my strip in block kc: every lane of mine is inside
-                    break;
-                }
-                W::nap(spins);
-                if ((++spins & 63u) == 0) {
-                    if (pass_over()) {
-                        alive = false;
-                        return false;
-                    }
-                    if (spins > c.spin_limit) {
-                        PA_TRACE("pass %u strip %d block %d: bottom-info timeout\n", c.pass, r, kc);
-                        finish(kStTimeout, 3, 0, 0);
-                        return false;
-                    }
+                    bot_done = true;
                 }
             }
+            if (!t_done && W::readlane(tr_hi, kTstate) == tn) {
+                const int32_t st = W::readlane_i(tr_lo, kTstate);
+                if (st == kTEmpty) {  // the pass ends at block kc; whoever found out has set the status
+                    alive = false;
+                    return false;
+                }
+                if (st == kTCont) {
+                    if (W::readlane(tr_hi, kTcont) == tn) {
+                        int32_t base;  // the strip above has published its prefix word for block kc before the CONT record
+                        if (!wait_pr(r - 1, kc, &base)) return false;
+                        sc_active = true;
+                        sc_j = W::readlane_i(tr_lo, kTcont);
+                        sc_e = 0;
+                        sc_base0 = base;
+                        is_top = true;
+                        t_done = true;
+                        force_pending(0, lane_of(sc_j));
+                    }
+                } else if (W::readlane(tr_hi, kTjs) == tn && W::readlane(tr_hi, kTtop) == tn && W::readlane(tr_hi, kTfs) == tn &&
+                           W::readlane(tr_hi, kTlim) == tn && W::readlane(tr_hi, kTfound) == tn) {
+                    js_n = W::readlane_i(tr_lo, kTjs);
+                    top_n = W::readlane_i(tr_lo, kTtop);
+                    fs_n = W::readlane_i(tr_lo, kTfs);
+                    lim_n = W::readlane_i(tr_lo, kTlim);
+                    found_n = W::readlane_i(tr_lo, kTfound);
+                    have_n = true;
+                    t_done = true;
+                }
+            }
+            if (bot_done && t_done) break;
+            W::nap(spins);
+            if ((++spins & 63u) == 0 && spins > c.spin_limit) {
+                PA_TRACE("pass %u strip %d block %d: boundary timeout bot=%d t=%d\n", c.pass, r, kc, (int)bot_done, (int)t_done);
+                finish(kStTimeout, 3, 0, 0);
+                return false;
+            }
         }
-        // top edge: do I run the scan of block kc?
-        if (fsprev_c >= row0 && fsprev_c < rowE && js_c >= row0) {
+        old_fs_c = old_field(0, 4);
+        old_js_n = kc + 1 <= c.nblk ? old_field(1, 0) : kNone;
+        if (scan_owner) {  // the top-down scan of block kc starts in my rows
             sc_active = true;
             sc_j = fsprev_c;
             sc_e = lane_of(js_c);
             sc_base0 = top_c;
             is_top = true;
             if (old_fs_c != kNone && sc_j > old_fs_c) sc_j = old_fs_c;  // cannot happen for a growing band; keeps the scan sane
-        } else if (rowE <= js_c) {
-            // dead strip finishing its last crossing: nothing to fetch
+            force_pending(sc_e, lane_of(sc_j));
+        } else if (dead) {  // a strip the band has left, finishing its last crossing
             have_n = true;
             js_n = js_c;
             top_n = 0;
             fs_n = fsprev_c;
             lim_n = 0;
             found_n = 0;
-        } else {
-            if (!fetch_trec_desc(kc + 1)) return false;
         }
         // lane 0's input in block kc + 1
         if (kc < c.nblk) {
@@ -420,7 +503,7 @@ struct StripProg {
         const typename W::mask act = W::and_m(W::and_m(W::ge_i(lrow0, js_c), W::lt_i(lrow0, jeb)), W::lt_i(lrow0, mrows));
         // column of block kc (V words, sparse blocks of the traceback: blocks.rs:322-339)
         if (!c.store_cols) {  // ring of columns: the slot's previous block must be behind the bottom-edge logic, its only reader
-            uint64_t spins = 0;
+            uint32_t spins = 0;
             for (;;) {
                 const uint64_t bp = W::load_u64(c.bprog);
                 if ((tw_tag(bp) >> 20) == (c.pass & 0xFFFu) && (int32_t)(tw_tag(bp) & 0xFFFFFu) > kc - c.col_ring) break;
@@ -439,7 +522,7 @@ struct StripProg {
         }
         {
             uint64_t* colk = c.col + (col_slot(c, kc) * c.col_stride - col_base_word(c, kc)) * 2;
-            const int64_t wlo = col_base_word(c, kc), whi = wlo + c.col_stride;
+            const int32_t wlo = col_base_word(c, kc), whi = wlo + (int32_t)c.col_stride;
             const int32_t wfirst = imax32(row0, js_c) >> 6, wlast = (imin32(imin32(rowE, jeb), mrows) >> 6);
             if (wfirst < wlast && (wfirst < wlo || wlast > whi)) {
                 abort_pass(kAbortWindow);
@@ -461,14 +544,13 @@ struct StripProg {
             std::fprintf(stderr, "\n");
         }
 #endif
-        {
-            uint64_t* pw = pr_word(c, r, kc);
-            if (!pw) {
-                abort_pass(kAbortWindow);
-                return;
-            }
-            defer(pw, tw_make(btag(kc), p_end));
+        if (!pr_word(c, r, kc)) {
+            abort_pass(kAbortWindow);
+            return;
         }
+        flush_deferred();  // (nothing pending in practice: the previous boundary's words went out a block ago)
+        pend_k = kc;
+        pend_p = p_end;
 
         // the scan ran off my last lane
         if (sc_active) {
@@ -500,16 +582,19 @@ struct StripProg {
             if (!alive) return;
             if (sc_active) {  // hand the scan to the strip below (it reads my prefix word first)
                 sc_active = false;
-                TRec* t = c.trec + (kc + 1);
-                defer(&t->cont_j, tw_make(btag(kc + 1), sc_j));
-                defer(&t->state, tw_make(btag(kc + 1), kTCont));
+                pend_cont = true;
+                pend_cont_j = sc_j;
                 have_n = true;  // for me: the next block starts below my rows
                 js_n = rowE;
                 top_n = 0;
                 fs_n = sc_j;
             }
         }
-        if (!bot_interior && je_c > row0 && je_c <= rowE) bottom_edge(p_end);
+        if (!bot_interior && je_c > row0 && je_c <= rowE) {
+            const uint64_t tq0 = PA_CLK(W);
+            bottom_edge(p_end);
+            PA_CLK_ADD(t_bottom, W::clock() - tq0);
+        }
     }
 
     // ---- the bottom-edge logic of block kc (domain.rs:318-350, 117-246, 449-455; blocks.rs:205-230) ----------------------
@@ -523,6 +608,14 @@ struct StripProg {
             return true;
         }
         return index_above(kc, js_c, top_c, j, out);
+    }
+    // a word of BRec[kc]: from the record fetched at the start of the boundary, or (written a moment later) from memory
+    PA_HD bool brec_word(int idx, const uint64_t* p, int32_t* out) {
+        if (W::readlane(brv_hi, idx) == btag(kc)) {
+            *out = W::readlane_i(brv_lo, idx);
+            return true;
+        }
+        return wait_word(p, btag(kc), out);
     }
     PA_HD void bottom_edge(int32_t p_end) {
         PA_TRACE("pass %u strip %d bottom edge of block %d: js=%d je=%d oje=%d\n", c.pass, r, kc, js_c, je_c, oje_c);
@@ -538,7 +631,7 @@ struct StripProg {
         }
         const int32_t ie = blk_end(c, kc);
         const int32_t end = imin32(oje_c, c.m);
-        const int32_t old_fe = c.d_old[kc].fe;
+        const int32_t old_fe = old_field(0, 5);
         // bottom-up scan (domain.rs:318-328): the last row >= lim with f <= f_max
         int32_t fe_scan = kNone;
         {
@@ -589,26 +682,32 @@ struct StripProg {
         if (!index_any(fe_final, p_end, bot_val, &gu)) return;
         const int32_t kn = kc + 1;
         int32_t flags_c;
-        if (!wait_word(&b->flags, btag(kc), &flags_c)) return;
-        const NextDecision nd = decide_next(hp, c.f_max, c.sparse_h, ie, blk_end(c, kn), fs_final, fe_final, gu, c.d_old[kn], (flags_c & 2) != 0);
+        if (!brec_word(kBflags, &b->flags, &flags_c)) return;
+        BlockRec old_next;
+        old_next.js = old_field(1, 0);
+        old_next.je = old_field(1, 1);
+        old_next.ojs = old_field(1, 2);
+        old_next.oje = old_field(1, 3);
+        old_next.fs = old_field(1, 4);
+        old_next.fe = old_field(1, 5);
+        old_next.top_val = old_next.bot_val = 0;
+        const NextDecision nd = decide_next(hp, c.f_max, c.sparse_h, ie, blk_end(c, kn), fs_final, fe_final, gu, old_next, (flags_c & 2) != 0);
         if (!nd.ok) {
             finish(kStNoPath, 0, kc, kc);
             return;
         }
         const JRangeOut jr = nd.jr;
-        if (nd.d_num_blocks) {  // the owner of this logic moves from strip to strip: agent-scope adds
-            PassStats& st = c.status->stats;
-            W::add_u64(&st.num_blocks, nd.d_num_blocks);
-            W::add_u64(&st.unique_lanes, nd.d_unique_add - nd.d_unique_sub);
-            W::add_u64(&st.computed_lanes, nd.d_computed);
-            W::add_u64(&st.num_incremental_blocks, nd.d_incremental);
-        }
+        // (the owner of this logic moves from strip to strip: every strip sums its own share and adds it once, when it ends)
+        st_num_blocks += nd.d_num_blocks;
+        st_unique += nd.d_unique_add - nd.d_unique_sub;
+        st_computed += nd.d_computed;
+        st_incremental += nd.d_incremental;
         // The speculation rule of the strips above me: a strip that saw block q's end `oje_q` ran ahead through block k without
         // waiting if its last row was < oje_q - kMaxShrink * (k - q).  Block kn breaks that promise iff a strip boundary lies
         // in [oje_kn, max_q(oje_q - kMaxShrink * (kn - q))): such a strip treated rows as inside the band that are not (and the
         // strip that should run this logic for block kn may be among them) -- the host engine redoes the pass.
         int32_t spec_c;
-        if (!wait_word(&b->specmax, btag(kc), &spec_c)) return;
+        if (!brec_word(kBspec, &b->specmax, &spec_c)) return;
         const int32_t spec_n = imax32(spec_c, oje_c) - kMaxShrink;
         if (jr.js < js_c || (jr.oje < spec_n && ((spec_n - 1) / kStripRows) * kStripRows >= jr.oje)) {
             abort_pass(kAbortNonMonotone);
@@ -618,7 +717,7 @@ struct StripProg {
             abort_pass(kAbortMismatch);
             return;
         }
-        if ((int64_t)jr.je - (int64_t)blk_end(c, kn) > c.win || (int64_t)ie - (int64_t)jr.js > c.win) {
+        if (jr.je - blk_end(c, kn) > c.win || ie - jr.js > c.win) {
             abort_pass(kAbortWindow);
             return;
         }
@@ -630,7 +729,7 @@ struct StripProg {
         W::store_u64(&bn->je, tw_make(btag(kn), jr.je));
         // strips the band covers for the first time start at block kn
         int32_t smax;
-        if (!wait_word(&b->smax, btag(kc), &smax)) return;
+        if (!brec_word(kBsmax, &b->smax, &smax)) return;
         const int32_t mrows = c.wtot * 64;
         const int32_t last_new = (imin32(jr.je, mrows) - 1) / kStripRows;
         for (int32_t rr = smax + 1; rr <= last_new && rr < c.nstrips; ++rr) W::store_u64(c.strip_start + rr, tw_make(c.pass, kn));
@@ -640,16 +739,21 @@ struct StripProg {
     }
 
     // ---- deferred publications ------------------------------------------------------------------------------------------
-    PA_HD void defer(uint64_t* p, uint64_t v) {
-        dq_ptr[dq_n] = p;
-        dq_val[dq_n] = v;
-        dq_n += 1;
-    }
+    // The strip's prefix word of block pend_k (and, if the top-down scan runs on into the strip below, the CONT record of
+    // block pend_k + 1) go out one chunk after the column stores they vouch for, behind an s_waitcnt vmcnt(0).  Plain integers
+    // (no pointers, no arrays): this state must stay in scalar registers -- anything that lands in scratch comes back as a
+    // "divergent" value and drags the whole loop onto the vector unit.
     PA_HD void flush_deferred() {
-        if (dq_n == 0) return;
+        if (pend_k < 0) return;
         W::drain_stores();
-        for (int i = 0; i < dq_n; ++i) W::store_u64(dq_ptr[i], dq_val[i]);
-        dq_n = 0;
+        W::store_u64(pr_word(c, r, pend_k), tw_make(btag(pend_k), pend_p));
+        if (pend_cont) {
+            TRec* t = c.trec + (pend_k + 1);
+            W::store_u64(&t->cont_j, tw_make(btag(pend_k + 1), pend_cont_j));
+            W::store_u64(&t->state, tw_make(btag(pend_k + 1), kTCont));
+        }
+        pend_k = -1;
+        pend_cont = false;
     }
 
     // ---- the strip --------------------------------------------------------------------------------------------------------
@@ -657,27 +761,27 @@ struct StripProg {
     uint64_t* gout;
     int32_t gin_base, gout_base;
     uint32_t pf_lo, pf_hi;
-    uint64_t pf_g;
-    bool pf_has;
+    vec pf_glo, pf_ghi;  // the prefetched granule, not yet broadcast (so that the load stays in flight during the chunk)
+    flag_t pf_has;
 
     PA_HD void prefetch_inputs(int32_t q) {
         W::load_codes2(c.a_codes, q, pf_lo, pf_hi);
-        const int64_t idx = (int64_t)q - gin_base;
-        pf_has = gran_on && 32 * q < c.n && idx >= 0 && idx < c.gran_stride;
-        if (pf_has) pf_g = W::load_u64(gin + idx);
+        const int32_t idx = q - gin_base;
+        pf_has = gran_on && 32 * q < c.n && idx >= 0 && idx < (int32_t)c.gran_stride;
+        if (pf_has) W::load_words(gin + idx, 1, pf_glo, pf_ghi);
     }
     // Lane j (< 32) of XS = packed pipeline input of column 32q + j: its 2-bit code and the delta coming in from above.
     PA_HD bool decode_inputs(int32_t q, vec& XS) {
         const bool want = gran_on && 32 * q < c.n;
         uint32_t glo = 0, ghi = 0;
         if (want) {
-            const int64_t idx = (int64_t)q - gin_base;
-            if (idx < 0 || idx >= c.gran_stride) {
+            const int32_t idx = q - gin_base;
+            if (idx < 0 || idx >= (int32_t)c.gran_stride) {
                 abort_pass(kAbortWindow);
                 return false;
             }
-            uint64_t g = pf_has ? pf_g : W::load_u64(gin + idx);
-            uint64_t spins = 0;
+            uint64_t g = pf_has ? (((uint64_t)W::readlane(pf_ghi, 0) << 32) | W::readlane(pf_glo, 0)) : W::load_u64(gin + idx);
+            uint32_t spins = 0;
             while ((uint32_t)g == 0u) {  // the strip above is not there yet
                 W::nap(spins);
                 g = W::load_u64(gin + idx);
@@ -714,7 +818,7 @@ struct StripProg {
         lrow0 = lane * 32u + (uint32_t)row0;
         // wait until the band reaches my rows
         int32_t k0;
-        if (!wait_word(c.strip_start + r, c.pass, &k0)) return;
+        if (!wait_word(c.strip_start + r, c.pass, &k0, true)) return;  // may take the whole pass: only the end of the pass ends it
         kc = k0;
         PA_TRACE("pass %u strip %d starts at block %d\n", c.pass, r, k0);
         bot_interior = false;
@@ -741,6 +845,7 @@ struct StripProg {
         snap_p = snap_m = basev = W::splat(0u);
         andm = W::splat(0xFFFFFFFFu);
         orm = W::splat(0u);
+        fpend = W::splat(0u);
         if (is_top && js_c > row0) {  // the band's first row is inside my strip: that lane forces +1 from the start
             const typename W::mask first = W::eq_u(lrow0, (uint32_t)js_c);
             andm = W::select(first, W::splat(3u), andm);
@@ -755,68 +860,122 @@ struct StripProg {
 
         int32_t q = blk_end(c, kc - 1) >> 5;
         const int32_t q_first = q;
+        const int32_t q_fin = ((c.n - 1) >> 5) + 3;  // two chunks after the one holding column n - 1, lane 63's accumulators hold the
+                                                     // last granule; the iteration after that closes the last block
         bool crossing = false;
         int32_t cx = 0;
         prefetch_inputs(q);
         for (;; ++q) {
             const int32_t t0 = 32 * q;
-            if (kc < c.nblk && t0 == blk_end(c, kc)) {  // lane 0 leaves block kc with this chunk
-                if (!boundary_begin()) return;
+            // ---- a block boundary starts: lane 0 leaves block kc with this chunk, or (last block) every lane has frozen ----
+            const bool fin = kc == c.nblk && !crossing && q >= q_fin;
+            if (fin || (kc < c.nblk && t0 == blk_end(c, kc))) {
+                // (last block: the strip below needs my last granule to finish ITS block, which my boundary may wait for)
+                if (fin && has_below && q - q_first >= 3) publish_granule(q - 3);
+                const uint64_t tb0 = PA_CLK(W);
+                const bool okb = boundary_begin();
+                PA_CLK_ADD(t_begin, W::clock() - tb0);
+                if (!okb) return;
                 crossing = true;
                 cx = t0;
             }
-            vec XS;
-            if (!decode_inputs(q, XS)) return;
-            if (q - q_first >= 3 && has_below) publish_granule(q - 3);  // completed two chunks ago (lane 63 lags 64 steps)
-            prefetch_inputs(q + 1);
-            flush_deferred();
-            // ---- 32 steps ----
-            const bool tail = t0 + 31 >= c.n;     // some lane runs past the last column: its V freezes there
-            const bool head = q - q_first < 2;    // lanes whose column is still left of the strip's first column do not move
-            if (crossing || tail || head) {
+            bool block_done = false;
+            if (fin) {
+                PA_TRACE("pass %u strip %d final boundary block %d\n", c.pass, r, kc);
+                snap_p = vp;
+                snap_m = vm;
+                PA_NOUNROLL
+                while (sc_active && sc_j < rowE) {
+                    scan_probe(lane_of(sc_j));
+                    if (!alive) return;
+                }
+                block_done = true;
+            } else {
+                vec XS;
+                {
+                    const uint64_t tg0 = PA_CLK(W);
+                    const bool okd = decode_inputs(q, XS);
+                    PA_CLK_ADD(t_wait_gran, W::clock() - tg0);
+                    if (!okd) return;
+                }
+                if (q - q_first >= 3 && has_below) publish_granule(q - 3);  // completed two chunks ago (lane 63 lags 64 steps)
+                flush_deferred();  // (before the prefetch: its drain must not wait for loads issued just now)
+                prefetch_inputs(q + 1);
+                // ---- 32 steps ----
+                const bool tail = t0 + 31 >= c.n;   // some lane runs past the last column: its V freezes there
+                const bool head = q - q_first < 2;  // lanes whose column is still left of the strip's first column do not move
+                const uint64_t tc0 = PA_CLK(W);
                 const int32_t jeb = bot_interior ? INT32_MAX : je_c;
-                for (int32_t j = 0; j < 32; ++j) {
-                    const int32_t t = t0 + j;
-                    const int32_t cl = t - cx;
-                    if (crossing && cl >= 0 && cl < 64) {
-                        const typename W::mask me = W::eq_u(lane, (uint32_t)cl);
-                        snap_p = W::select(me, vp, snap_p);
-                        snap_m = W::select(me, vm, snap_m);
-                        const bool open_before = sc_active && cl >= sc_e;
-                        if (sc_active) {
-                            scan_hook(cl);
-                            if (!alive) return;
+                const int32_t cl0 = t0 - cx;  // the lane that crosses in step 0 of this chunk (crossing chunks)
+                const vec resetm = W::select(W::ge_i(lrow0, jeb), W::splat(1u), W::splat(0u));  // below the band in block kc
+                if (tail || head) {
+                    // strip start / last columns (rare): the general loop, one step at a time
+                    PA_NOUNROLL
+                    for (int32_t j = 0; j < 32; ++j) {
+                        const int32_t t = t0 + j;
+                        const int32_t cl = t - cx;
+                        if (crossing && cl >= 0 && cl < 64) {
+                            if (sc_active && cl == lane_of(sc_j)) {
+                                scan_probe(cl);
+                                if (!alive) return;
+                            }
+                            const typename W::mask me = W::eq_u(lane, (uint32_t)cl);
+                            snap_p = W::select(me, vp, snap_p);
+                            snap_m = W::select(me, vm, snap_m);
+                            const typename W::mask mf = W::and_m(me, W::ne_u(fpend, 0u));
+                            andm = W::select(mf, W::splat(3u), andm);
+                            orm = W::select(mf, W::splat(0x80000000u), orm);
+                            const typename W::mask mr = W::and_m(me, W::ne_u(resetm, 0u));
+                            vp = W::select(mr, W::splat(0xFFFFFFFFu), vp);
+                            vm = W::select(mr, W::splat(0u), vm);
                         }
-                        if (is_top && cl > 0) {
-                            const bool force = open_before && (cl & 1) == 0;
-                            andm = W::select(me, W::splat(force ? 3u : 0xFFFFFFFFu), andm);
-                            orm = W::select(me, W::splat(force ? 0x80000000u : 0u), orm);
-                        }
-                        if (row0 + 32 * cl >= jeb) {  // below the band in block kc: V::one() for block kc + 1
-                            vp = W::select(me, W::splat(0xFFFFFFFFu), vp);
-                            vm = W::select(me, W::splat(0u), vm);
-                        }
-                    }
-                    if (tail || head) {
                         const vec op = vp, om = vm;
                         step(W::readlane(XS, j), j >= 16);
                         // column t - lane in [first column of the strip, n)
                         const typename W::mask live = W::and_m(W::gt_i(lane, t - c.n), W::le_i(lane, t - 32 * q_first));
                         vp = W::select(live, vp, op);
                         vm = W::select(live, vm, om);
-                    } else {
-                        step(W::readlane(XS, j), j >= 16);
                     }
+                    PA_CLK_ADD(t_cross, W::clock() - tc0);
+                } else if (crossing) {
+                    // The lanes cross one per step (lane cl0 + j in step j): snapshot of their block-final V, V::one() below the
+                    // band, pending +1 forcing -- all inside the unrolled step code.  The top-down scan interrupts it only at the
+                    // steps where the lane holding the scanned row crosses (one to three per block).
+                    int32_t j = 0;
+                    PA_NOUNROLL
+                    while (j < 32) {
+                        int32_t stop = 32;
+                        if (sc_active) {
+                            const int32_t jh = lane_of(sc_j) - cl0;  // the step in which the scanned row's lane crosses
+                            if (jh == j) {
+                                scan_probe(cl0 + j);
+                                if (!alive) return;
+                                continue;
+                            }
+                            if (jh > j && jh < 32) stop = jh;
+                        }
+                        if (is_top) W::template chunk_cross<true>(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm, lane, cl0, snap_p, snap_m, resetm, fpend, j, stop);
+                        else W::template chunk_cross<false>(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm, lane, cl0, snap_p, snap_m, resetm, fpend, j, stop);
+                        j = stop;
+                    }
+                    PA_CLK_ADD(t_cross2, W::clock() - tc0);
+                } else {
+                    if (is_top) W::template chunk<true>(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm);
+                    else W::template chunk<false>(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm);
+                    PA_CLK_ADD(t_plain, W::clock() - tc0);
                 }
-            } else {
-                if (is_top) W::template chunk<true>(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm);
-                else W::template chunk<false>(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm);
+                block_done = crossing && t0 + 31 >= cx + 63;  // every lane has left block kc
             }
-            // ---- every lane has left block kc ----
-            if (crossing && t0 + 31 >= cx + 63) {
+            if (block_done) {
+                const uint64_t te0 = PA_CLK(W);
                 boundary_end();
+                PA_CLK_ADD(t_end, W::clock() - te0);
                 if (!alive) return;
                 crossing = false;
+                if (kc == c.nblk) {  // the pass's last block
+                    flush_deferred();
+                    return;
+                }
                 kc += 1;
                 js_c = js_n;
                 top_c = top_n;
@@ -828,31 +987,14 @@ struct StripProg {
                     return;
                 }
             }
-            // ---- the last block: all lanes have frozen at column n - 1 ----
-            // (two chunks after the one holding column n - 1: lane 63's accumulators then hold the last granule)
-            if (kc == c.nblk && !crossing && q >= ((c.n - 1) >> 5) + 2) {
-                PA_TRACE("pass %u strip %d final boundary block %d\n", c.pass, r, kc);
-                // the strip below needs my last granule to finish ITS block, which my boundary logic may wait for
-                if (has_below && q - q_first >= 2) publish_granule(q - 2);
-                if (!boundary_begin()) return;
-                snap_p = vp;
-                snap_m = vm;
-                for (int32_t cl = 0; cl < 64 && sc_active; ++cl) {
-                    scan_hook(cl);
-                    if (!alive) return;
-                }
-                boundary_end();
-                flush_deferred();
-                return;
-            }
         }
     }
 
     // Granule g (columns 32g .. 32g+31 of my bottom row) from lane 63's lagged accumulators.
     PA_HD void publish_granule(int32_t g) {
         if (g < 0 || 32 * g >= c.n) return;
-        const int64_t idx = (int64_t)g - gout_base;
-        if (idx < 0 || idx >= c.gran_stride) return;  // outside the window: the strip below cannot be there
+        const int32_t idx = g - gout_base;
+        if (idx < 0 || idx >= (int32_t)c.gran_stride) return;  // outside the window: the strip below cannot be there
         const uint32_t vlo = W::readlane(acc_lo, 63), vhi = W::readlane(acc_hi, 63);
         W::store_u64(gout + idx, (((uint64_t)vhi << 32) | (uint64_t)vlo) + 0x5555555555555555ull);
     }
@@ -866,6 +1008,22 @@ PA_HD void wave_main(const Ctx& c) {
     for (int32_t strip = (int32_t)w; strip < c.nstrips; strip += c.nwaves) {
         StripProg<W> prog(c);
         prog.run(strip);
+        if (prog.st_num_blocks) {
+            PassStats& st = c.status->stats;
+            W::add_u64(&st.num_blocks, prog.st_num_blocks);
+            W::add_u64(&st.unique_lanes, prog.st_unique);
+            W::add_u64(&st.computed_lanes, prog.st_computed);
+            W::add_u64(&st.num_incremental_blocks, prog.st_incremental);
+        }
+        if (c.timing) {  // phase clocks of all strips, summed (diagnostics: PA_SWEEP_TIMING)
+            W::add_u64(c.timing + 0, prog.t_begin);
+            W::add_u64(c.timing + 1, prog.t_cross);
+            W::add_u64(c.timing + 2, prog.t_end - prog.t_bottom);
+            W::add_u64(c.timing + 3, prog.t_bottom);
+            W::add_u64(c.timing + 4, prog.t_plain);
+            W::add_u64(c.timing + 5, prog.t_wait_gran);
+            W::add_u64(c.timing + 6, prog.t_cross2);
+        }
         if (W::load_u32(&c.status->state) != kStRunning) return;
     }
 }

@@ -120,10 +120,25 @@ struct HostWave {
         return __atomic_compare_exchange_n(p, &expect, v, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
     }
     static void add_u64(uint64_t* p, uint64_t v) { __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
-    static void nap(uint64_t) { std::this_thread::yield(); }
+    static void nap(uint32_t) { std::this_thread::yield(); }
+    static uint64_t clock() { return 0; }
     static void drain_stores() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
     static uint32_t ticket(uint32_t* p) { return __atomic_fetch_add(p, 1u, __ATOMIC_ACQ_REL); }
 
+    // lane l (< n) reads the 8-byte word p[l]
+    static void load_words(const uint64_t* p, int n, vec& lo, vec& hi) {
+        for (int i = 0; i < 64; ++i) {
+            lo.a[i] = hi.a[i] = 0;
+            if (i < n) {
+                const uint64_t w = __atomic_load_n(p + i, __ATOMIC_ACQUIRE);
+                lo.a[i] = (uint32_t)w;
+                hi.a[i] = (uint32_t)(w >> 32);
+            }
+        }
+    }
+    static void load_i32s(const int32_t* p, int n, vec& v) {
+        for (int i = 0; i < 64; ++i) v.a[i] = i < n ? (uint32_t)p[i] : 0u;
+    }
     static void load_codes2(const uint32_t* codes, int32_t q, uint32_t& lo, uint32_t& hi) {
         lo = codes[2 * (int64_t)q];
         hi = codes[2 * (int64_t)q + 1];
@@ -191,6 +206,30 @@ struct HostWave {
     static void chunk(const vec& XS, vec& X, vec& vp, vec& vm, const vec& nb0, const vec& nb1, vec& acc_lo, vec& acc_hi, const vec& andm,
                       const vec& orm) {
         for (int j = 0; j < 32; ++j) myers<FORCE>(XS.a[j], X, vp, vm, nb0, nb1, j < 16 ? acc_lo : acc_hi, andm, orm);
+    }
+    // steps [j0, j1) of a chunk in which lane cl0 + j leaves its block at step j: snapshot of its V, pending +1 forcing,
+    // V::one() if it was below the band
+    template <bool FORCE>
+    static void chunk_cross(const vec& XS, vec& X, vec& vp, vec& vm, const vec& nb0, const vec& nb1, vec& acc_lo, vec& acc_hi, vec& andm,
+                            vec& orm, const vec& lane, int32_t cl0, vec& snap_p, vec& snap_m, const vec& resetm, const vec& fpend, int32_t j0,
+                            int32_t j1) {
+        for (int j = j0; j < j1; ++j) {
+            const int32_t cl = cl0 + j;
+            if (cl >= 0 && cl < 64) {
+                snap_p.a[cl] = vp.a[cl];
+                snap_m.a[cl] = vm.a[cl];
+                if (FORCE && fpend.a[cl]) {
+                    andm.a[cl] = 3u;
+                    orm.a[cl] = 0x80000000u;
+                }
+                if (resetm.a[cl]) {
+                    vp.a[cl] = 0xFFFFFFFFu;
+                    vm.a[cl] = 0;
+                }
+            }
+            myers<FORCE>(XS.a[j], X, vp, vm, nb0, nb1, j < 16 ? acc_lo : acc_hi, andm, orm);
+        }
+        (void)lane;
     }
 };
 

@@ -30,7 +30,7 @@ struct HostLauncher {
     bool trace = false;
     int nwaves = 4;
     uint32_t pass_id = 0;
-    uint64_t spin_limit = 1ull << 24;
+    uint32_t spin_limit = 1u << 24;
     std::vector<uint32_t> codes, prof;
     std::vector<BlockRec> d_old;
     std::vector<BRec> brec;
@@ -129,6 +129,7 @@ struct HostLauncher {
         c.nstrips = geo.nstrips;
         c.nwaves = nwaves < geo.nstrips ? nwaves : geo.nstrips;
         c.spin_limit = spin_limit;
+        c.timing = nullptr;
         std::vector<std::thread> th;
         for (int w = 0; w < c.nwaves; ++w) th.emplace_back([&c]() { wave_main<HostWave>(c); });
         for (auto& t : th) t.join();

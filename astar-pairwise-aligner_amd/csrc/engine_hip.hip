@@ -738,7 +738,7 @@ int align_hip(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, co
     // Domain::Astar with a closed-form / per-column heuristic and the sparse, non-incremental block engine (the `simple`
     // preset and its relatives): every align_for_bounded_dist pass is ONE persistent launch with the band logic in the kernel
     // (sweep_wave.hpp).  A pass the kernel hands back (SweepFallback) is redone by the host-driven engine below.
-    static const bool no_sweep = std::getenv("PA_ENGINE_NO_SWEEP") != nullptr;
+    const bool no_sweep = std::getenv("PA_ENGINE_NO_SWEEP") != nullptr;  // (diagnostics / tests: the host-driven engine)
     if (!no_sweep && !self_check && sweep::sweep_supported(p, a_len, b_len)) {
         try {
             HipSweepLauncher launcher(be, sweep_pool());

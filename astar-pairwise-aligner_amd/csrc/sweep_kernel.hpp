@@ -190,48 +190,61 @@ struct DeviceWave {
             myers_k<FORCE>(s_x, X, vp, vm, nb0, nb1, j < 16 ? acc_lo : acc_hi, andm, orm, k40, k80);
         }
     }
-    // Steps [j0, j1) of a chunk in which lane cl0 + j leaves its block at step j: snapshot of its V (the block's column), the
-    // pending +1 forcing of a lane that may hold the next block's first row, V::one() if the lane was below the band in that
-    // block (blocks.rs:753-767).  One unrolled copy of the 32 steps entered and left through a switch (two scalar
-    // instructions per step): a wavefront alone on its SIMD pays per INSTRUCTION, so the steps must not run in a generic loop.
-    template <bool FORCE>
+    static __device__ __forceinline__ bool any(vec x) { return __builtin_amdgcn_ballot_w64(x != 0) != 0; }
+
+    // A chunk in which lane cl0 + j leaves its block at step j: snapshot of its V (the block's column); EXTRA: a lane that may
+    // hold the next block's first row starts forcing +1 (fpend), a lane that was below the band restarts from V::one()
+    // (resetm; blocks.rs:753-767).  All predicates are per-lane compares against the step number (VALU only: a scalar AND of
+    // two lane masks between a v_cmp and a v_cndmask stalls a lone wavefront), 3 resp. 9 more VALU per step than `chunk`.
+    template <bool FORCE, bool EXTRA>
     static __device__ __forceinline__ void chunk_cross(vec XS, vec& X, vec& vp, vec& vm, vec nb0, vec nb1, vec& acc_lo, vec& acc_hi, vec& andm, vec& orm,
-                                                        vec lane, int32_t cl0, vec& snap_p, vec& snap_m, vec resetm, vec fpend, int32_t j0,
-                                                        int32_t j1) {
+                                                        vec lane, int32_t cl0, vec& snap_p, vec& snap_m, vec resetm, vec fpend) {
         uint32_t k40 = 0x40000000u, k80 = 0x80000000u;
         asm volatile("" : "+v"(k40), "+v"(k80));
-        const uint32_t rel = lane - (uint32_t)cl0;  // == j at the lane's crossing step
-        const bool rs = resetm != 0;
-        const bool fp = fpend != 0;
-        if (j0 == 0 && j1 == 32) {  // the whole chunk (no scan probe in it): straight-line code
+        const uint32_t rel = lane - (uint32_t)cl0;               // == j at the lane's crossing step
+        const uint32_t relr = resetm != 0 ? rel : 0xFFFFFFFFu;   // never matches for lanes that do not reset
+        const uint32_t relf = fpend != 0 ? rel : 0xFFFFFFFFu;
 #pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                const bool me = rel == (uint32_t)j;
-                snap_p = me ? vp : snap_p;
-                snap_m = me ? vm : snap_m;
+        for (int j = 0; j < 32; ++j) {
+            const bool me = rel == (uint32_t)j;
+            snap_p = me ? vp : snap_p;
+            snap_m = me ? vm : snap_m;
+            if (EXTRA) {
                 if (FORCE) {
-                    andm = (me && fp) ? 3u : andm;
-                    orm = (me && fp) ? 0x80000000u : orm;
+                    const bool mf = relf == (uint32_t)j;
+                    andm = mf ? 3u : andm;
+                    orm = mf ? 0x80000000u : orm;
                 }
-                vp = (me && rs) ? 0xFFFFFFFFu : vp;
-                vm = (me && rs) ? 0u : vm;
-                myers_k<FORCE>((uint32_t)__builtin_amdgcn_readlane((int)XS, j), X, vp, vm, nb0, nb1, j < 16 ? acc_lo : acc_hi, andm, orm, k40, k80);
+                const bool mr = relr == (uint32_t)j;
+                vp = mr ? 0xFFFFFFFFu : vp;
+                vm = mr ? 0u : vm;
             }
-            return;
+            myers_k<FORCE>((uint32_t)__builtin_amdgcn_readlane((int)XS, j), X, vp, vm, nb0, nb1, j < 16 ? acc_lo : acc_hi, andm, orm, k40, k80);
         }
+    }
+    // Steps [j0, j1) of such a chunk in the strip that runs the top-down scan (the scan interrupts the chunk where the scanned
+    // row's lane crosses): one unrolled copy of the 32 steps entered and left through a switch.
+    static __device__ __forceinline__ void chunk_cross_range(vec XS, vec& X, vec& vp, vec& vm, vec nb0, vec nb1, vec& acc_lo, vec& acc_hi, vec& andm,
+                                                              vec& orm, vec lane, int32_t cl0, vec& snap_p, vec& snap_m, vec resetm, vec fpend, int32_t j0,
+                                                              int32_t j1) {
+        uint32_t k40 = 0x40000000u, k80 = 0x80000000u;
+        asm volatile("" : "+v"(k40), "+v"(k80));
+        const uint32_t rel = lane - (uint32_t)cl0;
+        const uint32_t relr = resetm != 0 ? rel : 0xFFFFFFFFu;
+        const uint32_t relf = fpend != 0 ? rel : 0xFFFFFFFFu;
 #define PA_XSTEP(J)                                                                                                  \
     case J: {                                                                                                        \
         if (J >= j1) break;                                                                                          \
         const bool me = rel == (uint32_t)(J);                                                                        \
         snap_p = me ? vp : snap_p;                                                                                   \
         snap_m = me ? vm : snap_m;                                                                                   \
-        if (FORCE) {                                                                                                 \
-            andm = (me && fp) ? 3u : andm;                                                                           \
-            orm = (me && fp) ? 0x80000000u : orm;                                                                    \
-        }                                                                                                            \
-        vp = (me && rs) ? 0xFFFFFFFFu : vp;                                                                          \
-        vm = (me && rs) ? 0u : vm;                                                                                   \
-        myers_k<FORCE>((uint32_t)__builtin_amdgcn_readlane((int)XS, J), X, vp, vm, nb0, nb1, (J) < 16 ? acc_lo : acc_hi, andm, orm, k40, k80); \
+        const bool mf = relf == (uint32_t)(J);                                                                       \
+        andm = mf ? 3u : andm;                                                                                       \
+        orm = mf ? 0x80000000u : orm;                                                                                \
+        const bool mr = relr == (uint32_t)(J);                                                                       \
+        vp = mr ? 0xFFFFFFFFu : vp;                                                                                  \
+        vm = mr ? 0u : vm;                                                                                           \
+        myers_k<true>((uint32_t)__builtin_amdgcn_readlane((int)XS, J), X, vp, vm, nb0, nb1, (J) < 16 ? acc_lo : acc_hi, andm, orm, k40, k80); \
     }                                                                                                                \
         [[fallthrough]];
         switch (j0) {

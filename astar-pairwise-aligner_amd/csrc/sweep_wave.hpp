@@ -154,19 +154,30 @@ struct StripProg {
         pend_k = -1;
         pend_p = pend_cont_j = 0;
         pend_cont = false;
+        fin_state = fin_value = fin_k_end = fin_k_fixed = 0;
         alive = true;
     }
 
     // ---- status ------------------------------------------------------------------------------------------------------
     PA_HD bool pass_over() { return W::load_u32(&c.status->state) != kStRunning; }
+    // The end of the pass as this strip sees it: recorded here, written to the status block once, by wave_main (this is
+    // inlined at every wait and every consistency check: it must be a handful of scalar moves, the kernel has to fit the
+    // instruction cache).
+    int32_t fin_state, fin_value, fin_k_end, fin_k_fixed;
     PA_HD void finish(uint32_t state, int32_t value, int32_t k_end, int32_t k_fixed) {
         PA_TRACE("pass %u strip %d block %d: finish state=%u value=%d k_end=%d\n", c.pass, r, kc, state, value, k_end);
-        if (W::cas_u32(&c.status->state, kStRunning, state)) {
-            c.status->value = value;
-            c.status->k_end = k_end;
-            c.status->k_fixed = k_fixed;
-        }
+        fin_state = (int32_t)state;
+        fin_value = value;
+        fin_k_end = k_end;
+        fin_k_fixed = k_fixed;
         alive = false;
+    }
+    PA_HD void commit_finish() {
+        if (fin_state != 0 && W::cas_u32(&c.status->state, kStRunning, (uint32_t)fin_state)) {
+            c.status->value = fin_value;
+            c.status->k_end = fin_k_end;
+            c.status->k_fixed = fin_k_fixed;
+        }
     }
     PA_HD void abort_pass(int32_t reason) { finish(kStAbort, reason, 0, 0); }
 
@@ -378,10 +389,9 @@ struct StripProg {
     }
 
     // ---- one Myers step for all lanes ------------------------------------------------------------------------------
-    PA_HD void step(uint32_t s_x, bool hi_half) {
-        if (is_top) W::template myers<true>(s_x, X, vp, vm, nb0, nb1, hi_half ? acc_hi : acc_lo, andm, orm);
-        else W::template myers<false>(s_x, X, vp, vm, nb0, nb1, hi_half ? acc_hi : acc_lo, andm, orm);
-    }
+    // (always with the +1-forcing op, a no-op in lanes that do not hold the band's first row: one more VALU per step, but one
+    //  copy of each unrolled chunk variant instead of two -- the kernel has to fit the instruction cache)
+    PA_HD void step(uint32_t s_x, bool hi_half) { W::template myers<true>(s_x, X, vp, vm, nb0, nb1, hi_half ? acc_hi : acc_lo, andm, orm); }
 
     // ---- block boundary, part 1: lane 0 is about to leave block kc ------------------------------------------------------
     // Everything this boundary needs from other wavefronts is fetched with ONE round of vector loads (lane l reads word l
@@ -390,6 +400,23 @@ struct StripProg {
     // there yet.
     vec brv_lo, brv_hi;  // BRec[kc], lane l = word l (kept for the bottom-edge logic)
     vec oldv;            // d_old[kc], d_old[kc + 1] as 16 ints
+    vec pfb_st, pfb_bp_lo, pfb_bp_hi, pfb_tr_lo, pfb_tr_hi;  // the same loads issued one chunk ahead of the boundary (in flight
+    flag_t pfb_valid;                                        // during the chunk; the boundary only waits if something is missing)
+    vec pfp_lo, pfp_hi;  // the strip above's prefix word of block kc, issued one chunk ahead of boundary_end
+    flag_t pfp_valid;
+
+    PA_HD void boundary_loads(vec& st_lo, vec& bp_lo, vec& bp_hi, vec& tr_lo, vec& tr_hi) {
+        vec dummy;
+        W::load_words(reinterpret_cast<const uint64_t*>(c.status), 1, st_lo, dummy);
+        W::load_words(c.bprog, 1, bp_lo, bp_hi);
+        W::load_words(reinterpret_cast<const uint64_t*>(c.brec + kc), 11, brv_lo, brv_hi);
+        W::load_words(reinterpret_cast<const uint64_t*>(c.trec + (kc + 1)), 7, tr_lo, tr_hi);
+    }
+    PA_HD void prefetch_boundary() {  // at the start of the last chunk of block kc
+        W::load_i32s(reinterpret_cast<const int32_t*>(c.d_old + kc), kc + 1 <= c.nblk ? 16 : 8, oldv);
+        boundary_loads(pfb_st, pfb_bp_lo, pfb_bp_hi, pfb_tr_lo, pfb_tr_hi);
+        pfb_valid = true;
+    }
     enum { kBjs = 0, kBje = 1, kBojs = 2, kBoje = 3, kBflags = 4, kBfs = 5, kBfe = 6, kBbot = 7, kBtop = 8, kBsmax = 9, kBspec = 10 };
     enum { kTstate = 0, kTjs = 1, kTtop = 2, kTfs = 3, kTlim = 4, kTfound = 5, kTcont = 6 };
     PA_HD int32_t old_field(int rec, int f) const { return W::readlane_i(oldv, rec * 8 + f); }  // BlockRec field order
@@ -405,14 +432,20 @@ struct StripProg {
         const bool need_t = !scan_owner && !dead;
         bool bot_done = false, t_done = !need_t;
         const uint32_t tk = btag(kc), tn = btag(kc + 1);
-        W::load_i32s(reinterpret_cast<const int32_t*>(c.d_old + kc), kc + 1 <= c.nblk ? 16 : 8, oldv);
+        if (!pfb_valid) W::load_i32s(reinterpret_cast<const int32_t*>(c.d_old + kc), kc + 1 <= c.nblk ? 16 : 8, oldv);
         uint32_t spins = 0;
         for (;;) {
-            vec st_lo, st_hi, bp_lo, bp_hi, tr_lo, tr_hi;
-            W::load_words(reinterpret_cast<const uint64_t*>(c.status), 1, st_lo, st_hi);
-            W::load_words(c.bprog, 1, bp_lo, bp_hi);
-            W::load_words(reinterpret_cast<const uint64_t*>(c.brec + kc), 11, brv_lo, brv_hi);
-            if (!t_done) W::load_words(reinterpret_cast<const uint64_t*>(c.trec + (kc + 1)), 7, tr_lo, tr_hi);
+            vec st_lo, bp_lo, bp_hi, tr_lo, tr_hi;
+            if (pfb_valid) {  // first round: the loads issued a chunk ago
+                st_lo = pfb_st;
+                bp_lo = pfb_bp_lo;
+                bp_hi = pfb_bp_hi;
+                tr_lo = pfb_tr_lo;
+                tr_hi = pfb_tr_hi;
+                pfb_valid = false;
+            } else {
+                boundary_loads(st_lo, bp_lo, bp_hi, tr_lo, tr_hi);
+            }
             if (W::readlane(st_lo, 0) != kStRunning) {
                 alive = false;
                 return false;
@@ -532,18 +565,24 @@ struct StripProg {
         }
         const vec val = W::select(act, W::popc_v(snap_p) - W::popc_v(snap_m), W::splat(0u));
         int32_t pbase;
-        if (js_c >= row0) pbase = top_c;
-        else if (!wait_pr(r - 1, kc, &pbase)) return;
-        const vec excl = W::prefix_excl(val);
-        basev = excl + (uint32_t)pbase;
-        const int32_t p_end = pbase + (int32_t)(W::readlane(excl, 63) + W::readlane(val, 63));
-#ifdef PA_SWEEP_TRACE
-        if (kc <= PA_SWEEP_TRACE) {
-            std::fprintf(stderr, "strip %d block %d js=%d je=%d top=%d pbase=%d:", r, kc, js_c, bot_interior ? -1 : je_c, top_c, pbase);
-            for (int l = 0; l < 64; ++l) std::fprintf(stderr, " %d", W::readlane_i(basev, l));
-            std::fprintf(stderr, "\n");
+        if (js_c >= row0) {
+            pbase = top_c;
+        } else if (pfp_valid && W::readlane(pfp_hi, 0) == btag(kc)) {  // fetched during the last crossing chunk
+            pbase = W::readlane_i(pfp_lo, 0);
+        } else if (!wait_pr(r - 1, kc, &pbase)) {
+            return;
         }
-#endif
+        pfp_valid = false;
+        // index_kc at every lane's first row is only needed where a scan looks at the column: in the strips at the band's edges
+        const bool edge = sc_active || (!bot_interior && je_c > row0 && je_c <= rowE);
+        int32_t p_end;
+        if (edge) {
+            const vec excl = W::prefix_excl(val);
+            basev = excl + (uint32_t)pbase;
+            p_end = pbase + (int32_t)(W::readlane(excl, 63) + W::readlane(val, 63));
+        } else {
+            p_end = pbase + (int32_t)W::reduce_add(val);
+        }
         if (!pr_word(c, r, kc)) {
             abort_pass(kAbortWindow);
             return;
@@ -846,6 +885,8 @@ struct StripProg {
         andm = W::splat(0xFFFFFFFFu);
         orm = W::splat(0u);
         fpend = W::splat(0u);
+        pfb_valid = false;
+        pfp_valid = false;
         if (is_top && js_c > row0) {  // the band's first row is inside my strip: that lane forces +1 from the start
             const typename W::mask first = W::eq_u(lrow0, (uint32_t)js_c);
             andm = W::select(first, W::splat(3u), andm);
@@ -899,16 +940,25 @@ struct StripProg {
                     if (!okd) return;
                 }
                 if (q - q_first >= 3 && has_below) publish_granule(q - 3);  // completed two chunks ago (lane 63 lags 64 steps)
-                flush_deferred();  // (before the prefetch: its drain must not wait for loads issued just now)
+                flush_deferred();  // (before the prefetches: its drain must not wait for loads issued just now)
                 prefetch_inputs(q + 1);
+                // the next boundary's records / the strip above's prefix word: in flight during this chunk's steps
+                if (!crossing && kc < c.nblk && t0 + 32 == blk_end(c, kc)) prefetch_boundary();
+                if (crossing && t0 + 31 >= cx + 63 && js_c < row0) {
+                    const uint64_t* pw = pr_word(c, r - 1, kc);
+                    if (pw) {
+                        W::load_words(pw, 1, pfp_lo, pfp_hi);
+                        pfp_valid = true;
+                    }
+                }
                 // ---- 32 steps ----
                 const bool tail = t0 + 31 >= c.n;   // some lane runs past the last column: its V freezes there
                 const bool head = q - q_first < 2;  // lanes whose column is still left of the strip's first column do not move
                 const uint64_t tc0 = PA_CLK(W);
                 const int32_t jeb = bot_interior ? INT32_MAX : je_c;
                 const int32_t cl0 = t0 - cx;  // the lane that crosses in step 0 of this chunk (crossing chunks)
-                const vec resetm = W::select(W::ge_i(lrow0, jeb), W::splat(1u), W::splat(0u));  // below the band in block kc
                 if (tail || head) {
+                    const vec resetm = W::select(W::ge_i(lrow0, jeb), W::splat(1u), W::splat(0u));  // below the band in block kc
                     // strip start / last columns (rare): the general loop, one step at a time
                     PA_NOUNROLL
                     for (int32_t j = 0; j < 32; ++j) {
@@ -941,27 +991,35 @@ struct StripProg {
                     // The lanes cross one per step (lane cl0 + j in step j): snapshot of their block-final V, V::one() below the
                     // band, pending +1 forcing -- all inside the unrolled step code.  The top-down scan interrupts it only at the
                     // steps where the lane holding the scanned row crosses (one to three per block).
-                    int32_t j = 0;
-                    PA_NOUNROLL
-                    while (j < 32) {
-                        int32_t stop = 32;
-                        if (sc_active) {
-                            const int32_t jh = lane_of(sc_j) - cl0;  // the step in which the scanned row's lane crosses
-                            if (jh == j) {
-                                scan_probe(cl0 + j);
-                                if (!alive) return;
-                                continue;
+                    const bool probe_here = sc_active && lane_of(sc_j) - cl0 < 32;
+                    if (!probe_here) {
+                        // straight-line variants: (force op in the step) x (lanes that start forcing / reset when they cross)
+                        const bool extra = !bot_interior || (is_top && W::any(fpend));
+                        const vec resetm = W::select(W::ge_i(lrow0, jeb), W::splat(1u), W::splat(0u));  // below the band in block kc
+                        if (extra) W::template chunk_cross<true, true>(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm, lane, cl0, snap_p, snap_m, resetm, fpend);
+                        else W::template chunk_cross<true, false>(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm, lane, cl0, snap_p, snap_m, resetm, fpend);
+                    } else {
+                        const vec resetm = W::select(W::ge_i(lrow0, jeb), W::splat(1u), W::splat(0u));
+                        int32_t j = 0;
+                        PA_NOUNROLL
+                        while (j < 32) {
+                            int32_t stop = 32;
+                            if (sc_active) {
+                                const int32_t jh = lane_of(sc_j) - cl0;  // the step in which the scanned row's lane crosses
+                                if (jh == j) {
+                                    scan_probe(cl0 + j);
+                                    if (!alive) return;
+                                    continue;
+                                }
+                                if (jh > j && jh < 32) stop = jh;
                             }
-                            if (jh > j && jh < 32) stop = jh;
+                            W::chunk_cross_range(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm, lane, cl0, snap_p, snap_m, resetm, fpend, j, stop);
+                            j = stop;
                         }
-                        if (is_top) W::template chunk_cross<true>(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm, lane, cl0, snap_p, snap_m, resetm, fpend, j, stop);
-                        else W::template chunk_cross<false>(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm, lane, cl0, snap_p, snap_m, resetm, fpend, j, stop);
-                        j = stop;
                     }
                     PA_CLK_ADD(t_cross2, W::clock() - tc0);
                 } else {
-                    if (is_top) W::template chunk<true>(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm);
-                    else W::template chunk<false>(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm);
+                    W::template chunk<true>(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm);
                     PA_CLK_ADD(t_plain, W::clock() - tc0);
                 }
                 block_done = crossing && t0 + 31 >= cx + 63;  // every lane has left block kc
@@ -1008,6 +1066,7 @@ PA_HD void wave_main(const Ctx& c) {
     for (int32_t strip = (int32_t)w; strip < c.nstrips; strip += c.nwaves) {
         StripProg<W> prog(c);
         prog.run(strip);
+        prog.commit_finish();
         if (prog.st_num_blocks) {
             PassStats& st = c.status->stats;
             W::add_u64(&st.num_blocks, prog.st_num_blocks);

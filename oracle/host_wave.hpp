@@ -208,17 +208,16 @@ struct HostWave {
         for (int j = 0; j < 32; ++j) myers<FORCE>(XS.a[j], X, vp, vm, nb0, nb1, j < 16 ? acc_lo : acc_hi, andm, orm);
     }
     // steps [j0, j1) of a chunk in which lane cl0 + j leaves its block at step j: snapshot of its V, pending +1 forcing,
-    // V::one() if it was below the band
-    template <bool FORCE>
-    static void chunk_cross(const vec& XS, vec& X, vec& vp, vec& vm, const vec& nb0, const vec& nb1, vec& acc_lo, vec& acc_hi, vec& andm,
-                            vec& orm, const vec& lane, int32_t cl0, vec& snap_p, vec& snap_m, const vec& resetm, const vec& fpend, int32_t j0,
-                            int32_t j1) {
+    // V::one() if it was below the band.  (The device has several specialised copies; they all mean this.)
+    static void chunk_cross_range(const vec& XS, vec& X, vec& vp, vec& vm, const vec& nb0, const vec& nb1, vec& acc_lo, vec& acc_hi, vec& andm,
+                                  vec& orm, const vec& lane, int32_t cl0, vec& snap_p, vec& snap_m, const vec& resetm, const vec& fpend, int32_t j0,
+                                  int32_t j1) {
         for (int j = j0; j < j1; ++j) {
             const int32_t cl = cl0 + j;
             if (cl >= 0 && cl < 64) {
                 snap_p.a[cl] = vp.a[cl];
                 snap_m.a[cl] = vm.a[cl];
-                if (FORCE && fpend.a[cl]) {
+                if (fpend.a[cl]) {
                     andm.a[cl] = 3u;
                     orm.a[cl] = 0x80000000u;
                 }
@@ -227,9 +226,19 @@ struct HostWave {
                     vm.a[cl] = 0;
                 }
             }
-            myers<FORCE>(XS.a[j], X, vp, vm, nb0, nb1, j < 16 ? acc_lo : acc_hi, andm, orm);
+            myers<true>(XS.a[j], X, vp, vm, nb0, nb1, j < 16 ? acc_lo : acc_hi, andm, orm);
         }
         (void)lane;
+    }
+    template <bool FORCE, bool EXTRA>
+    static void chunk_cross(const vec& XS, vec& X, vec& vp, vec& vm, const vec& nb0, const vec& nb1, vec& acc_lo, vec& acc_hi, vec& andm,
+                            vec& orm, const vec& lane, int32_t cl0, vec& snap_p, vec& snap_m, const vec& resetm, const vec& fpend) {
+        chunk_cross_range(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm, lane, cl0, snap_p, snap_m, resetm, fpend, 0, 32);
+    }
+    static bool any(const vec& x) {
+        for (int i = 0; i < 64; ++i)
+            if (x.a[i]) return true;
+        return false;
     }
 };
 

@@ -960,6 +960,7 @@ class AstarPa2Instance {
     std::unique_ptr<Heuristic> heur;  // Some for Domain::Astar
     AstarPa2Stats stats;
     bool self_check = false;
+    std::function<void(const Blocks<Backend>&, std::optional<Cost>, Cost)> pass_hook;  // test hook (never set by the library)
 
     AstarPa2Instance(const AstarPa2Params& p, Backend& backend) : params(p), be(backend) {  // lib.rs:87-120
         const double t0 = now_s();
@@ -1152,6 +1153,7 @@ class AstarPa2Instance {
         }
 
         const auto dist = blocks->last_block().get(blen());
+        if (pass_hook) pass_hook(*blocks, f_max, dist.has_value() ? *dist : -1);  // tests: the blocks of a completed pass, before the trace pops them
         if (!dist) return std::nullopt;
         if (trace && *dist <= f_max.value_or(INT32_MAX)) {
             auto [cigar, tstats] = blocks->trace(0, 0, alen(), blen());
@@ -1199,9 +1201,11 @@ std::pair<Cost, std::optional<Cigar>> band_search(Cost first_s, std::function<Co
 
 // lib.rs:122-175
 template <class Backend>
-AlignResult cost_or_align(const AstarPa2Params& params, Backend& be, bool trace, bool self_check = false) {
+AlignResult cost_or_align(const AstarPa2Params& params, Backend& be, bool trace, bool self_check = false,
+                          std::function<void(const Blocks<Backend>&, std::optional<Cost>, Cost)> pass_hook = nullptr) {
     AstarPa2Instance<Backend> nw(params, be);
     nw.self_check = self_check;
+    nw.pass_hook = std::move(pass_hook);
     const Cost h0 = nw.heur ? nw.heur->h(0, 0) : 0;
     AlignResult out;
     std::pair<Cost, std::optional<Cigar>> r;

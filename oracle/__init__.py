@@ -309,3 +309,27 @@ def sweep_emu_align(a: bytes, b: bytes, params: AstarPa2ParamsC, trace: bool = T
         s = C.string_at(cig.value).decode()
         engine_lib().pa_cpu_free(cig)
     return rc, cost.value, s, stats.as_dict(), info.tolist()
+
+
+def cpu_align_blocks(a: bytes, b: bytes, params: AstarPa2ParamsC):
+    """The blocks of the engine's last completed pass (traceback mode, before the trace): (cost, f_max, [dict per block]).
+    v of a block = list of (p, m) words covering rows [js, je)."""
+    L = engine_lib()
+    L.pa_cpu_align_blocks.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(AstarPa2ParamsC), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    L.pa_cpu_align_blocks.restype = C.c_int
+    nb = len(a) // max(1, params.block_width) + 4
+    rec = np.zeros((nb, 12), np.int32)
+    v = np.zeros(2 * nb * (len(b) // 64 + 2), np.uint64)
+    cost, f_max = C.c_int32(0), C.c_int32(0)
+    n = L.pa_cpu_align_blocks(_buf(a), len(a), _buf(b), len(b), C.byref(params), C.byref(cost), C.byref(f_max), _p(rec), rec.size, _p(v), v.size)
+    if n < 0:
+        raise RuntimeError(f"pa_cpu_align_blocks rc={n}")
+    keys = ["i0", "i1", "ojs", "oje", "js", "je", "fs", "fe", "top_val", "bot_val"]
+    out = []
+    for k in range(n):
+        d = {key: int(rec[k, i]) for i, key in enumerate(keys)}
+        off, w = int(rec[k, 10]), int(rec[k, 11])
+        d["v"] = [(int(v[2 * (off + j)]), int(v[2 * (off + j) + 1])) for j in range(w)]
+        out.append(d)
+    return cost.value, f_max.value, out

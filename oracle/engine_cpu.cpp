@@ -73,3 +73,54 @@ extern "C" int pa_cpu_gcsh_probe(const uint8_t* a, size_t n, const uint8_t* b, s
     }
     return (int)cnt;
 }
+
+// Test hook: the blocks of the LAST completed pass (before the traceback) as flat arrays, so that tests can check the band
+// logic against a dense DP without going through the engine's own accessors.  rec[k] = {i0, i1, ojs, oje, js, je, fs, fe,
+// top_val, bot_val, v_offset, v_words}; v = concatenated V words (p, m).  Returns the number of blocks, or < 0.
+extern "C" int pa_cpu_align_blocks(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params* params,
+                                   int32_t* cost_out, int32_t* f_max_out, int32_t* rec, size_t rec_cap, uint64_t* v, size_t v_cap) {
+    if (!params || !params_valid(*params)) return -4;
+    CpuBackend be(a, a_len, b, b_len);
+    if (!be.ok) return -1;
+    const AstarPa2Params p = params_from_c(*params);
+    int nblocks = 0;
+    size_t vused = 0;
+    bool overflow = false;
+    try {
+        const AlignResult r = cost_or_align<CpuBackend>(p, be, true, false, [&](const Blocks<CpuBackend>& bl, std::optional<Cost> f_max, Cost) {
+            nblocks = 0;
+            vused = 0;
+            if (f_max_out) *f_max_out = f_max.value_or(-1);
+            for (size_t k = 0; k <= bl.last_block_idx; ++k) {
+                const Block& x = bl.blocks[k];
+                if ((size_t)(nblocks + 1) * 12 > rec_cap || vused + 2 * x.v.size() > v_cap) {
+                    overflow = true;
+                    return;
+                }
+                int32_t* o = rec + (size_t)nblocks * 12;
+                o[0] = x.i_range.s;
+                o[1] = x.i_range.e;
+                o[2] = x.original_j_range.s;
+                o[3] = x.original_j_range.e;
+                o[4] = x.j_range.s;
+                o[5] = x.j_range.e;
+                o[6] = x.fixed_j_range ? x.fixed_j_range->s : -1;
+                o[7] = x.fixed_j_range ? x.fixed_j_range->e : -2;
+                o[8] = x.top_val;
+                o[9] = x.bot_val;
+                o[10] = (int32_t)(vused / 2);
+                o[11] = (int32_t)x.v.size();
+                for (const V& w : x.v) {
+                    v[vused++] = w.p;
+                    v[vused++] = w.m;
+                }
+                nblocks += 1;
+            }
+        });
+        if (cost_out) *cost_out = r.cost;
+    } catch (const EnginePanic& e) {
+        std::fprintf(stderr, "astarpa2 engine panic: %s\n", e.what());
+        return -5;
+    }
+    return overflow ? -6 : nblocks;
+}

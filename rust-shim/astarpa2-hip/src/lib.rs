@@ -1,0 +1,153 @@
+//! `pa_types::Aligner` backed by `pa_align` of `libastarpa_c_hip.so` (`include/pa_astarpa2.h`): the whole A*PA2 aligner on an
+//! MI355X (band doubling, sparse blocks, DT-trace, SH / GCSH, incremental doubling; `astarpa2/src/lib.rs:122-214`).
+//!
+//! NOT COMPILED IN THIS REPOSITORY (no Rust toolchain in the build image).  The structs below mirror `include/pa_astarpa2.h`
+//! field for field, in order; `tests/c_abi/layout_check.c` pins the offsets on the C side and
+//! `tests/test_capi_symbols.py::test_rust_mirror_matches_header` compares the field lists of this file with the header.
+use pa_types::{Aligner, Cigar, CigarElem, CigarOp, Cost, Seq};
+use std::os::raw::c_char;
+
+/// `pa_block_params` = `BlockParams` (astarpa2/src/blocks.rs:31-60).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct PaBlockParams {
+    pub sparse: i32,
+    pub simd: i32,
+    pub no_ilp: i32,
+    pub incremental_doubling: i32,
+    pub dt_trace: i32,
+    pub max_g: i32,
+    pub fr_drop: i32,
+}
+
+/// `pa_astarpa2_params` = `AstarPa2Params` (astarpa2/src/params.rs:8-42).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct PaAstarPa2Params {
+    pub domain: i32,
+    pub heuristic: i32,
+    pub heuristic_k: i32,
+    pub heuristic_p: i32,
+    pub doubling: i32,
+    pub doubling_start: i32,
+    pub factor: f32,
+    pub delta: f32,
+    pub block_width: i32,
+    pub front: PaBlockParams,
+    pub sparse_h: i32,
+    pub prune: i32,
+}
+
+/// `pa_astarpa2_stats` = `AstarPa2Stats` + `BlockStats` + `TraceStats` (domain.rs:31-43, blocks.rs:76-84, trace.rs:3-14).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct PaAstarPa2Stats {
+    pub num_blocks: u64,
+    pub num_incremental_blocks: u64,
+    pub computed_lanes: u64,
+    pub unique_lanes: u64,
+    pub dt_trace_tries: u64,
+    pub dt_trace_success: u64,
+    pub dt_trace_fallback: u64,
+    pub fill_tries: u64,
+    pub fill_success: u64,
+    pub fill_fallback: u64,
+    pub f_max_tries: u64,
+    pub sanity_violations: u64,
+    pub t_compute: f64,
+    pub t_dt: f64,
+    pub t_fill: f64,
+    pub t_precomp: f64,
+    pub t_j_range: f64,
+    pub t_fixed_j_range: f64,
+    pub t_pruning: f64,
+    pub t_contours_update: f64,
+}
+
+#[link(name = "astarpa_c_hip")]
+extern "C" {
+    pub fn pa_params_nw(p: *mut PaAstarPa2Params);
+    pub fn pa_params_simple(p: *mut PaAstarPa2Params);
+    pub fn pa_params_full(p: *mut PaAstarPa2Params);
+    pub fn pa_align(a: *const u8, a_len: usize, b: *const u8, b_len: usize, params: *const PaAstarPa2Params, trace: i32,
+                    cost_out: *mut i32, cigar_out: *mut *mut c_char, stats_out: *mut PaAstarPa2Stats) -> i32;
+    pub fn astarpa_free_cigar(cigar: *mut u8);
+    pub fn pa_last_error() -> *const c_char;
+}
+
+/// The text form of `Cigar::to_string` (count omitted when 1; `=`, `X`, `I`, `D`; astarpa-c/example.cpp:16 `"=I4=X="`).
+pub fn parse_cigar(s: &str) -> Cigar {
+    let mut ops = Vec::new();
+    let mut cnt: i32 = 0;
+    let mut have = false;
+    for ch in s.bytes() {
+        if ch.is_ascii_digit() {
+            cnt = cnt * 10 + (ch - b'0') as i32;
+            have = true;
+            continue;
+        }
+        let op = match ch {
+            b'=' => CigarOp::Match,
+            b'X' => CigarOp::Sub,
+            b'I' => CigarOp::Ins,
+            b'D' => CigarOp::Del,
+            _ => panic!("unexpected CIGAR character {}", ch as char),
+        };
+        ops.push(CigarElem { op, cnt: if have { cnt } else { 1 } });
+        cnt = 0;
+        have = false;
+    }
+    Cigar { ops }
+}
+
+#[derive(Debug, Clone, Copy)]
+pub struct HipAstarPa2 {
+    pub params: PaAstarPa2Params,
+    pub trace: bool,
+}
+
+impl HipAstarPa2 {
+    /// `AstarPa2Params::simple().make_aligner(trace)` (params.rs:70-96,132).
+    pub fn simple(trace: bool) -> Self {
+        let mut params = PaAstarPa2Params::default();
+        unsafe { pa_params_simple(&mut params) };
+        Self { params, trace }
+    }
+    /// `AstarPa2Params::full().make_aligner(trace)` (params.rs:98-128).
+    pub fn full(trace: bool) -> Self {
+        let mut params = PaAstarPa2Params::default();
+        unsafe { pa_params_full(&mut params) };
+        Self { params, trace }
+    }
+    /// `AstarPa2Params::nw().make_aligner(trace)` (params.rs:46-68).
+    pub fn nw(trace: bool) -> Self {
+        let mut params = PaAstarPa2Params::default();
+        unsafe { pa_params_nw(&mut params) };
+        Self { params, trace }
+    }
+
+    /// `AstarPa2StatsAligner::align_with_stats` (astarpa2/src/lib.rs:200-208).
+    pub fn align_with_stats(&mut self, a: Seq, b: Seq) -> (Cost, Option<Cigar>, PaAstarPa2Stats) {
+        let mut cost = 0i32;
+        let mut ptr: *mut c_char = std::ptr::null_mut();
+        let mut stats = PaAstarPa2Stats::default();
+        let rc = unsafe { pa_align(a.as_ptr(), a.len(), b.as_ptr(), b.len(), &self.params, self.trace as i32, &mut cost, &mut ptr, &mut stats) };
+        if rc != 0 {
+            // the reference panics on invalid input / internal inconsistencies; keep that contract
+            panic!("pa_align failed ({}): {}", rc, unsafe { std::ffi::CStr::from_ptr(pa_last_error()) }.to_string_lossy());
+        }
+        let cigar = (!ptr.is_null()).then(|| {
+            let s = unsafe { std::ffi::CStr::from_ptr(ptr) }.to_str().unwrap().to_owned();
+            unsafe { astarpa_free_cigar(ptr as *mut u8) };
+            parse_cigar(&s)
+        });
+        (cost, cigar, stats)
+    }
+}
+
+impl Aligner for HipAstarPa2 {
+    fn align(&mut self, a: Seq, b: Seq) -> (Cost, Option<Cigar>) {
+        let (cost, cigar, _) = self.align_with_stats(a, b);
+        (cost, cigar)
+    }
+}

@@ -1,0 +1,74 @@
+//! Drop-in replacements for the `pa_bitpacking` operators the A*PA2 block engine calls
+//! (`astarpa2/src/blocks.rs:112,631,719-724`), computed on an MI355X by `libastarpa_c_hip.so`
+//! (`include/pa_bitpacking_hip.h`).
+//!
+//! NOT COMPILED IN THIS REPOSITORY (no Rust toolchain in the build image).  The C side of every declaration is pinned by
+//! `tests/c_abi/layout_check.c` and `tests/test_capi_symbols.py`.
+//!
+//! Rust tuples and tuple structs are not `repr(C)`.  `V(u64, u64)`, `Bits(u64, u64)` and `(u64, u64)` are two consecutive
+//! `u64` in practice; the `const` assertions below check size and alignment, and the recommended two-line change to the
+//! reference is `#[repr(C)]` on `V` (`pa-bitpacking/src/encoding.rs:5`) and `Bits` (`profile.rs:92`).
+use pa_bitpacking::{Bits, V};
+use pa_types::Cost;
+use std::os::raw::c_char;
+
+#[link(name = "astarpa_c_hip")]
+extern "C" {
+    /// `BitProfile::build` (profile.rs:112-133). `a2` has `2 n` u64, `b2` has `2 ceil(m / 64)` u64.
+    pub fn pa_bp_profile_build(a: *const u8, n: usize, b: *const u8, m: usize, a2: *mut u64, b2: *mut u64) -> i32;
+    /// `simd::compute` (simd.rs:98-226): returns the sum of the bottom deltas, `i32::MIN` on error.
+    pub fn pa_bp_compute(a2: *const u64, n: usize, b2: *const u64, w: usize, h2: *mut u64, v2: *mut u64, exact_end: i32) -> i32;
+    /// `simd::fill` (simd.rs:326-437): additionally `values[(i * w + j) * 2 + {0, 1}]`.
+    pub fn pa_bp_fill(a2: *const u64, n: usize, b2: *const u64, w: usize, h2: *mut u64, v2: *mut u64, values: *mut u64) -> i32;
+    pub fn pa_last_error() -> *const c_char;
+    pub fn pa_device_count() -> i32;
+    pub fn pa_set_device(device: i32) -> i32;
+}
+
+const _: () = assert!(std::mem::size_of::<(u64, u64)>() == 16 && std::mem::align_of::<(u64, u64)>() == 8);
+const _: () = assert!(std::mem::size_of::<V>() == 16 && std::mem::size_of::<Bits>() == 16);
+
+fn last_error() -> String {
+    unsafe { std::ffi::CStr::from_ptr(pa_last_error()) }.to_string_lossy().into_owned()
+}
+
+/// `pa_bitpacking::BitProfile::build(a, b)` (profile.rs:112).
+pub fn build(a: &[u8], b: &[u8]) -> (Vec<Bits>, Vec<Bits>) {
+    let w = (b.len() + 63) / 64;
+    let mut pa = vec![Bits(0, 0); a.len()];
+    let mut pb = vec![Bits(0, 0); w];
+    let rc = unsafe { pa_bp_profile_build(a.as_ptr(), a.len(), b.as_ptr(), b.len(), pa.as_mut_ptr() as *mut u64, pb.as_mut_ptr() as *mut u64) };
+    assert!(rc == 0, "pa_bp_profile_build: {}", last_error()); // the reference panics on a non-ACGT base as well
+    (pa, pb)
+}
+
+/// `pa_bitpacking::simd::compute::<N, (u64, u64), L>` (simd.rs:98-104).
+pub fn compute(a: &[Bits], b: &[Bits], h: &mut [(u64, u64)], v: &mut [V], exact_end: bool) -> Cost {
+    assert_eq!(a.len(), h.len());
+    assert_eq!(b.len(), v.len());
+    let r = unsafe {
+        pa_bp_compute(a.as_ptr() as *const u64, a.len(), b.as_ptr() as *const u64, b.len(), h.as_mut_ptr() as *mut u64,
+                      v.as_mut_ptr() as *mut u64, exact_end as i32)
+    };
+    assert!(r != i32::MIN, "pa_bp_compute: {}", last_error());
+    r
+}
+
+/// `pa_bitpacking::simd::fill::<N, (u64, u64), L>` (simd.rs:326-333): `values[i][j]` from the flat `n x w` buffer.
+pub fn fill(a: &[Bits], b: &[Bits], h: &mut [(u64, u64)], v: &mut [V], _exact_end: bool, values: &mut [Vec<V>]) -> Cost {
+    assert_eq!(a.len(), h.len());
+    assert_eq!(b.len(), v.len());
+    assert_eq!(values.len(), h.len());
+    let (n, w) = (a.len(), b.len());
+    let mut flat = vec![V::zero(); n * w];
+    let r = unsafe {
+        pa_bp_fill(a.as_ptr() as *const u64, n, b.as_ptr() as *const u64, w, h.as_mut_ptr() as *mut u64, v.as_mut_ptr() as *mut u64,
+                   flat.as_mut_ptr() as *mut u64)
+    };
+    assert!(r != i32::MIN, "pa_bp_fill: {}", last_error());
+    for (i, vv) in values.iter_mut().enumerate() {
+        vv.clear();
+        vv.extend_from_slice(&flat[i * w..(i + 1) * w]);
+    }
+    r
+}

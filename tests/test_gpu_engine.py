@@ -131,6 +131,30 @@ def test_c_program_links_and_runs(tmp_path):
         assert cost == "2" and int(n) == len(cigar) and re.fullmatch(r"(\d*[=XID])+", cigar)
 
 
+def test_c_layout_program(tmp_path):
+    """tests/c_abi/layout_check.c from plain C: struct layouts pinned with _Static_assert, pa_params_{nw,simple,full} + pa_align and
+    the operator boundary (pa_bp_profile_build / pa_bp_compute) on the reference's example pair."""
+    import os
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    libdir = root / "astar-pairwise-aligner_amd"
+    gcc = shutil.which("gcc") or shutil.which("cc")
+    if gcc is None or not (libdir / "libastarpa_c_hip.so").exists():
+        pytest.skip("no C compiler or library")
+    exe = tmp_path / "layout_check"
+    subprocess.run([gcc, str(root / "tests" / "c_abi" / "layout_check.c"), "-I", str(root / "include"), "-L", str(libdir),
+                    "-lastarpa_c_hip", "-Wl,-rpath," + str(libdir), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, LD_LIBRARY_PATH=str(libdir) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))).stdout
+    lines = out.strip().splitlines()
+    assert [l.split()[1] for l in lines[:3]] == ["nw", "simple", "full"]
+    assert all("rc=0 cost=2" in l and "block_width=256" in l for l in lines[:3])
+    assert lines[3] == "pa_bp_compute sum=%d cost=2" % int(lines[3].split("sum=")[1].split()[0])
+
+
 def test_c_abi_is_reentrant_across_threads(pa, oracle):
     """astarpa-c is stateless and re-entrant: several host threads align different pairs at the same time."""
     import threading

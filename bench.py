@@ -50,6 +50,9 @@ def parse_args():
     ap.add_argument("--no-c4", action="store_true", help="skip the batched alignment-with-traceback leg")
     ap.add_argument("--no-banded", action="store_true", help="skip the banded leg")
     ap.add_argument("--c4-pairs", type=int, default=10_000)
+    ap.add_argument("--no-engine", action="store_true", help="skip the single-pair A*PA2 legs (C3, drop-in loop)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the 10 Mbp A*PA2 leg")
+    ap.add_argument("--no-c4-sharded", action="store_true", help="skip the C4 strong-scaling leg (sharded_align over all ranks)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 
@@ -118,6 +121,36 @@ def main():
     else:
         checksum = int(costs.astype("int64").sum())
 
+    # ---- C4 strong scaling (BASELINE configs[3]: "10 000 x 10 kbp sharded across the GPUs"): every rank aligns its LPT shard with
+    #      traceback on its GPU, one tensor gather of costs + one of CIGAR bytes; total work fixed as N grows ----
+    c4_sharded = None
+    if not args.no_c4_sharded:
+        from astar_pairwise_aligner_amd.sharding import sharded_align
+
+        divs = (0.01, 0.05, 0.10, 0.15)
+        c4s = [generate_pair(10_000, divs[i % 4], seed=1_000_000 + i) for i in range(args.c4_pairs)]
+        sharded_align(c4s[: 64 * world])  # warm-up (buffers, pinned staging)
+        barrier()
+        t0s = time.perf_counter()
+        res = sharded_align(c4s)
+        barrier()
+        dts = time.perf_counter() - t0s
+        if dist is not None:
+            tt = torch.tensor([dts], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dts = float(tt.item())
+        c4_sharded = {
+            "workload": f"C4 strong scaling: {args.c4_pairs} x 10 kbp pairs (1/5/10/15 %), global alignment with traceback, LPT-sharded over {world} GPU(s), "
+                        "every rank ends with all (cost, CIGAR) results",
+            "pairs_per_sec": round(args.c4_pairs / dts, 1),
+            "ms": round(dts * 1e3, 2),
+            "n_gpus": world,
+            "scaling": "strong",
+            "cost_checksum": int(sum(c for c, _ in res)),
+            "cigar_bytes": int(sum(len(g) for _, g in res)),
+        }
+        del res, c4s
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -153,7 +186,7 @@ def main():
             "cost_checksum": checksum,
         },
         "roofline": {
-            "bound": "hbm",
+            "bound": "hbm",  # the contract's roofline; the kernel's real bound is VALU issue, see valu_roofline
             "achieved": round(achieved_gbs, 4),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -180,6 +213,8 @@ def main():
         },
         "batch_shape": {"k": shape["k"], "sequential": shape["sequential"]},
     }
+    if c4_sharded is not None:
+        out["c4_sharded"] = c4_sharded
 
     # ---- the literal single-pair C2 case (latency bound) ----
     if not args.no_single_pair and args.pairs != 1:
@@ -251,6 +286,70 @@ def main():
         }
         bt.close()
 
+    # ---- PCIe-inclusive rate of the headline workload: host buffers -> device layout -> one pass (never `value`) ----
+    if world == 1:
+        t = time.perf_counter()
+        bp = pa.Batch(pairs)
+        bp.run()
+        dtp = time.perf_counter() - t
+        bp.close()
+        out["pcie_inclusive_gcups"] = round(st["cells"] / dtp / 1e9, 1)
+
+    # ---- C3 (BASELINE configs[2]): ONE 100 kbp pair, A*PA2 with traceback through pa_align (the drop-in path).  `simple` runs as
+    #      one persistent launch per band-doubling pass with the band logic in the kernel (csrc/sweep_wave.hpp); `full` (GCSH +
+    #      pruning + incremental doubling: host-side heuristic) runs one launch per 256-column block ----
+    if not args.no_engine and world == 1:
+        import oracle as _orc
+
+        a3, b3 = generate_pair(100_000, 0.05, seed=1)
+        leg = {}
+        for name, mk, oprm in (("simple", pa.AstarPa2Params.simple, _orc.params_simple()), ("full", pa.AstarPa2Params.full, _orc.params_full())):
+            al = mk().make_aligner(True)
+            al.align(a3, b3)
+            best = 1e9
+            for _ in range(3):
+                t = time.perf_counter()
+                c3, g3, s3 = al.align_with_stats(a3, b3)
+                best = min(best, time.perf_counter() - t)
+            leg[name] = {"ms": round(best * 1e3, 2), "cost": int(c3), "f_max_tries": int(s3["f_max_tries"]), "blocks": int(s3["num_blocks"]),
+                         "computed_lanes": int(s3["computed_lanes"])}
+            if not args.no_cpu_baseline:
+                t = time.perf_counter()
+                wc, wg, _ = _orc.cpu_align(a3, b3, oprm)
+                leg[name]["cpu_engine_1core_ms"] = round((time.perf_counter() - t) * 1e3, 2)
+                assert (c3, g3) == (wc, wg), "C3: GPU engine and CPU-kernel engine disagree"
+        out["c3_engine"] = {"workload": "C3: one 100 kbp x 100 kbp pair, 5 %, A*PA2 with traceback via pa_align (cost + CIGAR), best of 3", **leg}
+        # a loop over the astarpa2_simple symbol on C4-shaped pairs: what a relinked astarpa-c user gets
+        divs = (0.01, 0.05, 0.10, 0.15)
+        loop_pairs = [generate_pair(10_000, divs[i % 4], seed=1_000_000 + i) for i in range(200)]
+        pa.c_abi_align("astarpa2_simple", *loop_pairs[0])
+        t = time.perf_counter()
+        got = [pa.c_abi_align("astarpa2_simple", a, b) for a, b in loop_pairs]
+        dtl = time.perf_counter() - t
+        out["dropin_loop"] = {"workload": "200 x 10 kbp pairs (1/5/10/15 %), one astarpa2_simple() call after the other (cost + CIGAR each)",
+                              "pairs_per_sec": round(len(loop_pairs) / dtl, 1)}
+        if not args.no_cpu_baseline:
+            t = time.perf_counter()
+            want = [_orc.cpu_align(a, b, _orc.params_simple())[:2] for a, b in loop_pairs[:50]]
+            out["dropin_loop"]["cpu_engine_1core_pairs_per_sec"] = round(50 / (time.perf_counter() - t), 1)
+            assert got[:50] == want, "drop-in loop: GPU and CPU-kernel engine disagree"
+
+    # ---- C5 (BASELINE configs[4]): ONE 10 Mbp x 10 Mbp pair, 5 %, doubling-band A*PA2 (`simple`), traceback off, through pa_align ----
+    if not args.no_c5 and world == 1:
+        a5, b5 = generate_pair(10_000_000, 0.05, seed=1)
+        al5 = pa.AstarPa2Params.simple().make_aligner(False)
+        t = time.perf_counter()
+        c5, _, s5 = al5.align_with_stats(a5, b5)
+        dt5 = time.perf_counter() - t
+        out["c5"] = {"workload": "C5: one 10 Mbp x 10 Mbp pair, 5 %, A*PA2 simple (GapCost band doubling from h0 + 256), traceback off, via pa_align: "
+                                 "one persistent launch per pass, j_range / fixed_j_range decided in the kernel",
+                     "seconds": round(dt5, 3), "cost": int(c5), "f_max_tries": int(s5["f_max_tries"]), "blocks": int(s5["num_blocks"]),
+                     "computed_lanes": int(s5["computed_lanes"]),
+                     "gcups_computed": round(s5["computed_lanes"] * 64 * 256 / dt5 / 1e9, 1),
+                     "gcups_equivalent": round(len(a5) * len(b5) / dt5 / 1e9, 1),
+                     "sanity_violations": int(s5["sanity_violations"])}
+        del a5, b5
+
     # ---- CPU baseline: the AVX2 port of the reference's SIMD schedule, 1 core, bounded sample ----
     if not args.no_cpu_baseline:
         import oracle
@@ -276,6 +375,8 @@ def main():
                       "the reference is single-threaded)",
         }
         out["speedup_vs_cpu_1core"] = round(value / out["cpu_baseline"]["value"], 1)
+        if "single_pair" in out:  # the literal C2 configuration ("single pair") against the same 1-core baseline
+            out["single_pair_speedup_vs_cpu_1core"] = round(out["single_pair"]["gcups"] / out["cpu_baseline"]["value"], 1)
 
     # PMC-derived HBM traffic of the dominant kernel (separate rocprofv3 --pmc passes, tools/pmc_run.sh; committed
     # summary in profiles/pmc_latest.json).  Traffic is per strip wave, so it scales with the batch.

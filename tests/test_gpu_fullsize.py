@@ -111,7 +111,7 @@ def test_bench_two_rank_code_path_dry_run(tmp_path):
     env = dict(os.environ, PA_BENCH_DRY_MULTI="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29617", str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "8",
-           "--seq-len", "20000", "--no-cpu-baseline", "--no-single-pair", "--no-c4", "--no-banded"]
+           "--seq-len", "20000", "--no-cpu-baseline", "--no-single-pair", "--no-c4", "--no-banded", "--c4-pairs", "300"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -119,3 +119,6 @@ def test_bench_two_rank_code_path_dry_run(tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["value"] > 0
     assert j["config"]["pairs_per_gpu"] == 8
+    # the C4 strong-scaling leg: both ranks aligned their shard with traceback and every rank got all results
+    assert j["c4_sharded"]["n_gpus"] == 2 and j["c4_sharded"]["scaling"] == "strong" and j["c4_sharded"]["pairs_per_sec"] > 0
+    assert j["c4_sharded"]["cost_checksum"] > 0 and j["c4_sharded"]["cigar_bytes"] > 300

@@ -21,13 +21,19 @@ uint64_t run(const uint8_t* a, uintptr_t a_len, const uint8_t* b, uintptr_t b_le
              uint8_t** cigar_ptr, uintptr_t* cigar_len, const char* who) {
     int32_t cost = 0;
     std::string cigar;
-    const int rc = pa::align_hip(a, a_len, b, b_len, p, true, false, &cost, &cigar, nullptr);
+    int rc = pa::align_hip(a, a_len, b, b_len, p, true, false, &cost, &cigar, nullptr);
+    if (rc == PA_E_TIMEOUT) rc = pa::align_hip(a, a_len, b, b_len, p, true, false, &cost, &cigar, nullptr);  // a device-side bounded
+    // spin expired (another process starving the GPU): the buffers are re-initialised, try once more before giving up
     if (rc != 0) {
         // The reference has no error channel: invalid input panics across FFI (lib.rs has no Result).
         std::fprintf(stderr, "%s: fatal: %s (rc=%d)\n", who, pa_last_error(), rc);
         std::abort();
     }
     char* out = (char*)std::malloc(cigar.size() + 1);
+    if (!out) {
+        std::fprintf(stderr, "%s: fatal: out of memory\n", who);
+        std::abort();
+    }
     std::memcpy(out, cigar.c_str(), cigar.size() + 1);
     if (cigar_len) *cigar_len = cigar.size();
     if (cigar_ptr) *cigar_ptr = (uint8_t*)out;

@@ -791,6 +791,10 @@ extern "C" int pa_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t
         *cigar_out = nullptr;
         if (rc == 0 && trace) {
             *cigar_out = (char*)std::malloc(cigar.size() + 1);
+            if (!*cigar_out) {
+                set_error("out of memory");
+                return PA_E_NOMEM;
+            }
             std::memcpy(*cigar_out, cigar.c_str(), cigar.size() + 1);
         }
     }

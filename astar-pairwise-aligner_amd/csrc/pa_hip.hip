@@ -12,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -157,11 +158,15 @@ template __global__ void pair_kernel<8, true>(const StripJob*, const int32_t*, i
 
 // ---- device context -----------------------------------------------------------------------------
 
-int g_device_props_cus = 0;
+static thread_local int g_device_props_cus = 0;  // of the device this thread last initialised (pa_set_device is per thread)
+static thread_local int g_device_props_dev = -1;
 
 bool ensure_device() {
     static thread_local bool inited = false;
-    if (inited) return true;
+    if (inited) {
+        int cur = 0;
+        if (hipGetDevice(&cur) == hipSuccess && cur == g_device_props_dev) return true;
+    }
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt == 0) {
         set_error("no HIP device available: the MI355X path is required (there is no CPU fallback)");
@@ -172,6 +177,7 @@ bool ensure_device() {
     hipDeviceProp_t prop;
     if (!hip_ok(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties")) return false;
     g_device_props_cus = prop.multiProcessorCount;
+    g_device_props_dev = dev;
     inited = true;
     return true;
 }
@@ -299,16 +305,24 @@ static unsigned residency_lds_bytes(int blocks) {
     return ((lds_total / (unsigned)(W + 1)) + 1024u) & ~1023u;  // W blocks fit, W + 1 do not
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (kernel, device), from any
+// thread (the library is re-entrant; pa_set_device selects the device per thread).
+static bool ensure_max_lds(const void* kern) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    if (!hip_ok(hipGetDevice(&dev), "hipGetDevice")) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kern, dev})) return true;
+    if (!hip_ok(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(max dynamic LDS)")) return false;
+    done.insert({kern, dev});
+    return true;
+}
+
 template <class Kern>
 static bool launch_one(Kern kern, int grid, int block_waves, unsigned lds, hipStream_t s, const StripJob* d_jobs, int njobs,
                        uint32_t* d_ticket_err) {
-    static bool attr_set = false;  // one static per kernel instantiation
-    if (!attr_set) {
-        if (!hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                    "hipFuncSetAttribute(max dynamic LDS)"))
-            return false;
-        attr_set = true;
-    }
+    if (!ensure_max_lds(reinterpret_cast<const void*>(kern))) return false;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * block_waves), lds, s, d_jobs, njobs, d_ticket_err, d_ticket_err + 1);
     return hip_ok(hipGetLastError(), "strip_kernel launch");
 }
@@ -345,13 +359,7 @@ bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_tic
 
 template <int K, bool CKPT>
 static bool launch_pairs_k(const StripJob* d_jobs, const int32_t* d_first, int npairs, uint32_t* d_err, hipStream_t s, int grid, unsigned lds) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (!hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(pair_kernel<K, CKPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
-                    "hipFuncSetAttribute(max dynamic LDS)"))
-            return false;
-        attr_set = true;
-    }
+    if (!ensure_max_lds(reinterpret_cast<const void*>(pair_kernel<K, CKPT>))) return false;
     hipLaunchKernelGGL((pair_kernel<K, CKPT>), dim3(grid), dim3(64 * kStripBlockWaves), lds, s, d_jobs, d_first, npairs, d_err);
     return hip_ok(hipGetLastError(), "pair_kernel launch");
 }
@@ -888,12 +896,22 @@ extern "C" int pa_search_trace(const uint8_t* pattern, size_t plen, const uint8_
     const size_t np = path.size() / 2;
     if (cigar_out) {
         *cigar_out = (char*)std::malloc(text_cigar.size() + 1);
-        if (!*cigar_out) return PA_E_ARG;
+        if (!*cigar_out) {
+            set_error("out of memory");
+            return PA_E_NOMEM;
+        }
         std::memcpy(*cigar_out, text_cigar.c_str(), text_cigar.size() + 1);
     }
     if (path_out) {
         *path_out = (int32_t*)std::malloc(std::max<size_t>(np, 1) * 2 * sizeof(int32_t));
-        if (!*path_out) return PA_E_ARG;
+        if (!*path_out) {
+            if (cigar_out) {  // nothing half-delivered: the caller owns outputs only on success
+                std::free(*cigar_out);
+                *cigar_out = nullptr;
+            }
+            set_error("out of memory");
+            return PA_E_NOMEM;
+        }
         for (size_t k = 0; k < np; ++k) {
             (*path_out)[2 * k] = path[2 * (np - 1 - k)];
             (*path_out)[2 * k + 1] = path[2 * (np - 1 - k) + 1];
@@ -1606,12 +1624,24 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
     }
     mark("pack kernel + text D2H");
     const pa_astarpa2_params fallback = traced_batch_params();
+    // a failure after the first string has been handed out: free them all again, the caller owns outputs only on success
+    auto fail_out = [&](size_t produced, int code) {
+        if (cigar_out)
+            for (size_t k = 0; k < produced; ++k) {
+                std::free(cigar_out[k]);
+                cigar_out[k] = nullptr;
+            }
+        return code;
+    };
     for (size_t i = 0; i < P; ++i) {
         cost_out[i] = costs[i];
         if (!cigar_out) continue;
         if (lens[i] != kTraceFailed) {  // the common case: one allocation, one copy out of the packed buffer
             char* out = (char*)std::malloc((size_t)tlens[i] + 1);
-            if (!out) return PA_E_ARG;
+            if (!out) {
+                set_error("out of memory");
+                return fail_out(i, PA_E_NOMEM);
+            }
             if (tlens[i]) std::memcpy(out, packed + dst_off[i], tlens[i]);
             out[tlens[i]] = 0;
             cigar_out[i] = out;
@@ -1623,16 +1653,19 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
         std::vector<uint8_t> ba(p->n[i]), bb(p->m[i]);
         if ((p->n[i] && !hip_ok(hipMemcpy(ba.data(), p->d_a.as<uint8_t>() + p->a_off[i], p->n[i], hipMemcpyDeviceToHost), "D2H a")) ||
             (p->m[i] && !hip_ok(hipMemcpy(bb.data(), p->d_b.as<uint8_t>() + p->b_off[i], p->m[i], hipMemcpyDeviceToHost), "D2H b")))
-            return PA_E_HIP;
+            return fail_out(i, PA_E_HIP);
         int32_t c = 0;
         const int rc = align_hip(ba.data(), p->n[i], bb.data(), p->m[i], fallback, true, false, &c, &text, nullptr);
-        if (rc != 0) return rc;
+        if (rc != 0) return fail_out(i, rc);
         if (c != costs[i]) {
             set_error("traceback fallback disagrees with the batched cost (pair %zu: %d vs %d)", i, c, costs[i]);
-            return PA_E_INTERNAL;
+            return fail_out(i, PA_E_INTERNAL);
         }
         cigar_out[i] = (char*)std::malloc(text.size() + 1);
-        if (!cigar_out[i]) return PA_E_ARG;
+        if (!cigar_out[i]) {
+            set_error("out of memory");
+            return fail_out(i, PA_E_NOMEM);
+        }
         std::memcpy(cigar_out[i], text.c_str(), text.size() + 1);
     }
     mark("strings to the caller");

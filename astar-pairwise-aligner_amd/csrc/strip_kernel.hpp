@@ -548,7 +548,8 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void strip_kernel(const Stri
 }
 
 // One rectangle of the A*PA2 block engine per launch, described entirely by kernel arguments (no descriptor upload):
-// block s of the grid is strip s (all strips of one rectangle are resident together, so no ticket is needed).  `v`, the
+// strips are handed out by a ticket (counter[1]) in dependency order, so a strip never waits on one that has not
+// started, whatever order the dispatcher picks workgroups in and however many are resident.  `v`, the
 // sum, the error word and the completion word live in host-mapped memory: the engine's host thread spins on `done`
 // instead of paying a stream synchronisation per 256-column block.
 struct RectArgs {
@@ -562,15 +563,18 @@ struct RectArgs {
     int32_t* sum_out;       // host-mapped
     uint32_t* err;          // host-mapped
     uint32_t* done;         // host-mapped: receives `seq` when every strip has finished
-    uint32_t* counter;      // device: strips finished so far, left at zero
+    uint32_t* counter;      // device: [0] strips finished so far, [1] the strip ticket; both left at zero
     int32_t n, col0, w0, w1, exact_end;
     uint32_t seq;
 };
 
 template <int K>
 __global__ __launch_bounds__(64) void rect_kernel(RectArgs r) {
-    const int s = (int)blockIdx.x, S = (int)gridDim.x;
+    const int S = (int)gridDim.x;
     const int lane = (int)(threadIdx.x & 63);
+    uint32_t tk = 0;
+    if (lane == 0) tk = __hip_atomic_fetch_add(r.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int s = (int)rfl(tk);
     constexpr int wps = 32 * K;
     StripJob j;
     j.a_codes = r.a_codes;
@@ -605,6 +609,7 @@ __global__ __launch_bounds__(64) void rect_kernel(RectArgs r) {
     c = rfl(c);
     if (c == (uint32_t)(S - 1) && lane == 0) {
         __hip_atomic_store(r.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(r.counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(r.done, r.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -632,8 +637,11 @@ struct ChainArgs {
 
 template <int K>
 __global__ __launch_bounds__(64) void rect_chain_kernel(ChainArgs r) {
-    const int b = (int)blockIdx.x, total = (int)gridDim.x;
+    const int total = (int)gridDim.x;
     const int lane = (int)(threadIdx.x & 63);
+    uint32_t tk = 0;
+    if (lane == 0) tk = __hip_atomic_fetch_add(r.counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int b = (int)rfl(tk);  // ticket order == dependency order (see rect_kernel)
     constexpr int wps = 32 * K;
     int g = 0, s = b;
     for (; g < r.nseg; ++g) {
@@ -676,6 +684,7 @@ __global__ __launch_bounds__(64) void rect_chain_kernel(ChainArgs r) {
     c = rfl(c);
     if (c == (uint32_t)(total - 1) && lane == 0) {
         __hip_atomic_store(r.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(r.counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(r.done, r.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

@@ -32,11 +32,15 @@ uint64_t astarpa2_simple(const uint8_t *a, uintptr_t a_len, const uint8_t *b, ui
 uint64_t astarpa2_full(const uint8_t *a, uintptr_t a_len, const uint8_t *b, uintptr_t b_len,
                        uint8_t **cigar_ptr, uintptr_t *cigar_len);
 
-/* astarpa-c/astarpa.h:39-51, src/lib.rs:54-65: A*PA v1 entry point (symbol kept). */
+/* astarpa-c/astarpa.h:39-51, src/lib.rs:54-65: A*PA v1 entry point.
+ * DEVIATION (stated here, not only in INTEGRATION.md): A*PA v1 is a priority-queue A* outside this library's scope.  The two v1
+ * symbols below are served by the A*PA2-simple engine: the returned cost is the exact edit distance and the CIGAR is a valid
+ * optimal alignment, but NOT necessarily v1's choice among equally good alignments (astarpa-c/example.cpp:16 pins v1's "=I4=X=");
+ * `r`, `k` and `prune_end` only tune v1's heuristic and are ignored. */
 uint64_t astarpa(const uint8_t *a, uintptr_t a_len, const uint8_t *b, uintptr_t b_len,
                  uint8_t **cigar_ptr, uintptr_t *cigar_len);
 
-/* astarpa-c/astarpa.h:53-63, src/lib.rs:69-96 */
+/* astarpa-c/astarpa.h:53-63, src/lib.rs:69-96 (see the DEVIATION note above: r, k, prune_end are accepted and ignored) */
 uint64_t astarpa_gcsh(const uint8_t *a, uintptr_t a_len, const uint8_t *b, uintptr_t b_len,
                       uintptr_t r, uintptr_t k, bool prune_end,
                       uint8_t **cigar_ptr, uintptr_t *cigar_len);

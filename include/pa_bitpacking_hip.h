@@ -35,6 +35,7 @@ extern "C" {
 #define PA_E_TIMEOUT (-3)      /* device-side bounded spin expired */
 #define PA_E_ARG (-4)
 #define PA_E_INTERNAL (-5)     /* engine invariant violated (where the reference would panic) */
+#define PA_E_NOMEM (-6)        /* host allocation failed; no output pointer is left owned by the caller */
 
 const char* pa_last_error(void);
 

@@ -359,8 +359,17 @@ bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_tic
 
 template <int K, bool CKPT>
 static bool launch_pairs_k(const StripJob* d_jobs, const int32_t* d_first, int npairs, uint32_t* d_err, hipStream_t s, int grid, unsigned lds) {
-    if (!ensure_max_lds(reinterpret_cast<const void*>(pair_kernel<K, CKPT>))) return false;
-    hipLaunchKernelGGL((pair_kernel<K, CKPT>), dim3(grid), dim3(64 * kStripBlockWaves), lds, s, d_jobs, d_first, npairs, d_err);
+    // tall strips take their eq words from LDS (strip_kernel.hpp LdsEq): one slice per wavefront of the block
+    static const bool no_ldseq = getenv("PA_PAIR_NO_LDSEQ") != nullptr;
+    if (K >= 4 && !no_ldseq) {
+        constexpr bool L = K >= 4;  // (keeps the K < 4 instantiations out of the binary)
+        const unsigned need = (unsigned)kStripBlockWaves * LdsEq<K>::kWaveBytes;
+        if (!ensure_max_lds(reinterpret_cast<const void*>(pair_kernel<K, CKPT, L>))) return false;
+        hipLaunchKernelGGL((pair_kernel<K, CKPT, L>), dim3(grid), dim3(64 * kStripBlockWaves), std::max(lds, need), s, d_jobs, d_first, npairs, d_err);
+        return hip_ok(hipGetLastError(), "pair_kernel launch");
+    }
+    if (!ensure_max_lds(reinterpret_cast<const void*>(pair_kernel<K, CKPT, false>))) return false;
+    hipLaunchKernelGGL((pair_kernel<K, CKPT, false>), dim3(grid), dim3(64 * kStripBlockWaves), lds, s, d_jobs, d_first, npairs, d_err);
     return hip_ok(hipGetLastError(), "pair_kernel launch");
 }
 

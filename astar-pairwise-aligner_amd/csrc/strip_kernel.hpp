@@ -131,20 +131,56 @@ __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin
 // instructions per 2048 cells.  Larger K trades per-step latency (single-pair speed) for throughput.
 // SCATTER: eq comes from a ScatterProfile (profile.rs:25-75): four match masks per word, selected by the text code
 // (A0 C1 T2 G3), so pattern wildcards (N, *, Y, R) work.
-template <int K, bool PRED, bool PASS, bool SCATTER>
+//
+// LDSEQ (tall strips of big batches): the four possible `eq` words of every subword sit in the wavefront's LDS slice
+// ([code][K/4][lane] x 16 bytes, filled once per strip), and the packed register carries, next to the delta of column c,
+// the LDS offset of the code of column c + 1: each step issues the K/4 ds_read_b128 of the NEXT step's eq (`eqn`) and
+// consumes the ones the previous step fetched.  That moves 2 of the 12 VALU instructions per subword (and the two code
+// extracts) to the LDS port, which issues beside the VALU: 107 -> 89 VALU instructions per K = 8 step.
+template <int K>
+struct LdsEq {
+    static constexpr int kCodeShift = K >= 8 ? 11 : 10;  // one code's eq words of all 64 lanes: 64 * 4K bytes
+    static constexpr uint32_t kCodeMask = 3u << kCodeShift;
+    static constexpr uint32_t kWaveBytes = 4u * 64u * 4u * (uint32_t)K;
+};
+typedef uint32_t pa_u32x4 __attribute__((ext_vector_type(4)));
+typedef pa_u32x4 __attribute__((address_space(3))) pa_lds_u32x4;
+typedef pa_lds_u32x4* pa_lds4;
+
+template <int K>
+__device__ __forceinline__ void lds_eq_fetch(uint32_t addr, uint32_t (&e)[K]) {
+#pragma unroll
+    for (int i = 0; i < K / 4; ++i) {
+        const pa_u32x4 t = *(pa_lds4)(uintptr_t)(addr + 1024u * (uint32_t)i);
+        e[4 * i] = t.x;
+        e[4 * i + 1] = t.y;
+        e[4 * i + 2] = t.z;
+        e[4 * i + 3] = t.w;
+    }
+}
+
+template <int K, bool PRED, bool PASS, bool SCATTER, bool LDSEQ = false>
 __device__ __forceinline__ void myers_step(uint32_t s_x, uint32_t& X, uint32_t (&vp)[K], uint32_t (&vm)[K],
                                            const uint32_t (&nb0)[K], const uint32_t (&nb1)[K], const uint32_t (&nb2)[K],
                                            const uint32_t (&nb3)[K], uint32_t& acc, bool active, bool pass_lane, uint32_t k40,
-                                           uint32_t k80) {
+                                           uint32_t k80, uint32_t (&eqn)[K], uint32_t lds_lane, uint32_t kcm) {
     acc = __builtin_amdgcn_alignbit(acc, X, 30);  // (acc << 2) | (X >> 30)
     const uint32_t Xin = dpp_wave_shr1(s_x, X);
-    const uint32_t a0 = (uint32_t)__builtin_amdgcn_sbfe((int)Xin, 0, 1);
-    const uint32_t a1 = (uint32_t)__builtin_amdgcn_sbfe((int)Xin, 1, 1);
-    const uint32_t hm0 = (Xin >> 30) & 1u;
+    uint32_t a0 = 0, a1 = 0;
     uint32_t eq[K], vx[K], sm[K], hp[K], hm[K];
+    if (LDSEQ) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) eq[k] = eqn[k];
+        lds_eq_fetch<K>((Xin & kcm) | lds_lane, eqn);
+    } else {
+        a0 = (uint32_t)__builtin_amdgcn_sbfe((int)Xin, 0, 1);
+        a1 = (uint32_t)__builtin_amdgcn_sbfe((int)Xin, 1, 1);
+    }
+    const uint32_t hm0 = (Xin >> 30) & 1u;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        if (SCATTER) {
+        if (LDSEQ) {
+        } else if (SCATTER) {
             const uint32_t e01 = __builtin_amdgcn_bitop3_b32(a0, nb1[k], nb0[k], 0xCA);  // a0 ? mask[1] : mask[0]
             const uint32_t e23 = __builtin_amdgcn_bitop3_b32(a0, nb3[k], nb2[k], 0xCA);
             eq[k] = __builtin_amdgcn_bitop3_b32(a1, e23, e01, 0xCA);
@@ -199,17 +235,19 @@ __device__ __forceinline__ void myers_step(uint32_t s_x, uint32_t& X, uint32_t (
 
 // One chunk = 32 columns = 32 unrolled steps.  Lane j (< 32) of XS carries the packed pipeline input of column 32q+j.
 // The lagged accumulator of steps 0..15 is acc_lo, of steps 16..31 acc_hi (static, so no register moves).
-template <int K, bool PRED, bool PASS, bool FILL, bool SCATTER, bool CKPT>
+template <int K, bool PRED, bool PASS, bool FILL, bool SCATTER, bool CKPT, bool LDSEQ = false>
 __device__ __forceinline__ void run_chunk(const StripJob& job, int q, uint32_t XS, uint32_t& X, uint32_t (&vp)[K],
                                           uint32_t (&vm)[K], const uint32_t (&nb0)[K], const uint32_t (&nb1)[K],
                                           const uint32_t (&nb2)[K], const uint32_t (&nb3)[K], uint32_t& acc_lo,
-                                          uint32_t& acc_hi, int lane, bool pass_lane, gu32 vout, uint32_t k40, uint32_t k80) {
+                                          uint32_t& acc_hi, int lane, bool pass_lane, gu32 vout, uint32_t k40, uint32_t k80,
+                                          uint32_t (&eqn)[K], uint32_t lds_lane, uint32_t kcm) {
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         const uint32_t s_x = (uint32_t)__builtin_amdgcn_readlane((int)XS, j);
         const int col = q * 32 + j - lane;
         const bool active = PRED ? ((unsigned)col < (unsigned)job.n) : true;
-        myers_step<K, PRED, PASS, SCATTER>(s_x, X, vp, vm, nb0, nb1, nb2, nb3, j < 16 ? acc_lo : acc_hi, active, pass_lane, k40, k80);
+        myers_step<K, PRED, PASS, SCATTER, LDSEQ>(s_x, X, vp, vm, nb0, nb1, nb2, nb3, j < 16 ? acc_lo : acc_hi, active, pass_lane, k40,
+                                                  k80, eqn, lds_lane, kcm);
         if (FILL) {
             if (active) {
 #pragma unroll
@@ -289,8 +327,10 @@ __device__ __forceinline__ bool resolve_granule(gcu64 g, uint64_t pre, int q, ui
 // K = 32-row subwords per lane: the strip covers 64*K subwords = 32*K reference words.
 // LOCAL: the granules are produced and consumed by the SAME wavefront (pair_kernel, trace_kernel): workgroup-scope
 // accesses, so the rows stay in the L2 instead of being written through / fetched around it 8 bytes at a time.
-template <int K, bool FILL, bool SCATTER, bool CKPT = false, bool LOCAL = false>
-__device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
+// LDSEQ: eq words come from the wavefront's LDS slice at byte offset `lds_wave` (LdsEq<K>::kWaveBytes, aligned to its size).
+template <int K, bool FILL, bool SCATTER, bool CKPT = false, bool LOCAL = false, bool LDSEQ = false>
+__device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, uint32_t lds_wave = 0) {
+    static_assert(!LDSEQ || (K >= 4 && !SCATTER && !FILL), "LDSEQ: tall cost-only strips");
     constexpr int kGranScope = LOCAL ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT;
     const int lane = (int)(threadIdx.x & 63);
     const int n = job.n;
@@ -326,6 +366,28 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
     }
     gu32 vout = nullptr;
     if (FILL) vout = (gu32)job.values + (size_t)job.fill_word0 * 4;
+    uint32_t eqn[K];
+    uint32_t kcm = LdsEq<K>::kCodeMask;
+    const uint32_t lds_lane = lds_wave + 16u * (uint32_t)lane;
+#pragma unroll
+    for (int k = 0; k < K; ++k) eqn[k] = 0;
+    if (LDSEQ) {
+        asm volatile("" : "+v"(kcm));  // a VGPR operand: gfx9 VOP3 takes no literal
+        // eq of code c (A0 C1 G2 T3) against the negated bit planes: (c0 ^ nb0) & (c1 ^ nb1), profile.rs:141-144
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t m0 = (c & 1) ? 0xFFFFFFFFu : 0u, m1 = (c & 2) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+            for (int i = 0; i < K / 4; ++i) {
+                pa_u32x4 t;
+                t.x = (m0 ^ nb0[4 * i]) & (m1 ^ nb1[4 * i]);
+                t.y = (m0 ^ nb0[4 * i + 1]) & (m1 ^ nb1[4 * i + 1]);
+                t.z = (m0 ^ nb0[4 * i + 2]) & (m1 ^ nb1[4 * i + 2]);
+                t.w = (m0 ^ nb0[4 * i + 3]) & (m1 ^ nb1[4 * i + 3]);
+                *(pa_lds4)(uintptr_t)(lds_lane + ((uint32_t)c << LdsEq<K>::kCodeShift) + 1024u * (uint32_t)i) = t;
+            }
+        }
+    }
 
     uint32_t X = 0, acc_lo = 0, acc_hi = 0;
     int32_t sum = 0;
@@ -425,7 +487,15 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
         }
         const uint64_t codes64 = decode_codes(codes_next, q);
         const uint32_t cw = upper ? (uint32_t)(codes64 >> 32) : (uint32_t)codes64;
-        const uint32_t code = (32 * q + (lane & 31) < n) ? ((cw >> sh) & 3u) : 0u;
+        uint32_t code = (32 * q + (lane & 31) < n) ? ((cw >> sh) & 3u) : 0u;
+        if (LDSEQ) {
+            // the pipeline carries the code of the NEXT column (its eq is fetched one step ahead), as an LDS offset
+            const unsigned s2 = 2u * (unsigned)((job.col0 + 32 * (q < Cm1 ? q : Cm1)) & 15);
+            const uint64_t ahead = (codes64 >> 2) | ((uint64_t)((codes_next.w2 >> s2) & 3u) << 62);
+            const uint32_t cwa = upper ? (uint32_t)(ahead >> 32) : (uint32_t)ahead;
+            code = (32 * q + (lane & 31) + 1 < n) ? (((cwa >> sh) & 3u) << LdsEq<K>::kCodeShift) : 0u;
+            if (q == 0) lds_eq_fetch<K>((((uint32_t)codes64 & 3u) << LdsEq<K>::kCodeShift) | lds_lane, eqn);  // column 0, for lane 0's step 0
+        }
         // top delta of this lane's column as (p << 31) | (m << 30); H::one() when there is no top row (blocks.rs:732)
         uint32_t hin2 = has_hin ? (((hinb_next & 1u) << 31) | ((hinb_next & 2u) << 29)) : 0x80000000u;
         if (q < C && has_gran && (job.hin_n == 0 || q * 32 < job.hin_n)) {
@@ -448,7 +518,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err) {
         // 255 (mod 256) at step 32q + j = 255 + l.  Only those chunks pay for the checkpoint test.
         const bool ck_chunk = CKPT && job.ckpt != nullptr && ((q & 7) <= 1 || (q & 7) == 7);
 #define PA_RUN_CHUNK(PRED_, PASS_, FILL_, CK_) \
-    run_chunk<K, PRED_, PASS_, FILL_, SCATTER, CK_>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80)
+    run_chunk<K, PRED_, PASS_, FILL_, SCATTER, CK_, LDSEQ>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80, eqn, lds_lane, kcm)
         if (CKPT && ck_chunk) {
             if (interior) {
                 if (exact_tail) PA_RUN_CHUNK(false, true, FILL, CKPT);
@@ -693,18 +763,23 @@ __global__ __launch_bounds__(64) void rect_chain_kernel(ChainArgs r) {
 // jobs[first[p+1]-1]); the bottom row of strip s goes through the same granule rows (two per rectangle, ping-pong) but
 // is produced and consumed by the same wavefront, so nothing ever polls.  With >= one rectangle per SIMD this removes the
 // strip-to-strip coupling that costs chained strips 40-70 % at 2-7 wavefronts per SIMD (profiles/r01_runs/chain_probe2.log).
-template <int K, bool CKPT = false>
-__global__ __launch_bounds__(64 * kStripBlockWaves) void pair_kernel(const StripJob* __restrict__ jobs,
+// The second launch bound asks for four wavefronts per SIMD (<= 128 VGPRs; the K = 8 step fits without spilling in its loops):
+// a 4096-pair batch is exactly four per SIMD, three would leave a quarter of it for a second, mostly empty round.
+// LDSEQ (K >= 4): the launch provides kStripBlockWaves * LdsEq<K>::kWaveBytes of dynamic LDS, the kernel's only LDS, so the
+// slices start at offset 0 and are aligned to their size.
+template <int K, bool CKPT = false, bool LDSEQ = false>
+__global__ __launch_bounds__(64 * kStripBlockWaves, 4) void pair_kernel(const StripJob* __restrict__ jobs,
                                                                       const int32_t* __restrict__ first, int npairs,
                                                                       uint32_t* err) {
     const int p = (int)rfl((uint32_t)(blockIdx.x * kStripBlockWaves + (threadIdx.x >> 6)));
     if (p >= npairs) return;
+    const uint32_t lds_wave = rfl((uint32_t)(threadIdx.x >> 6)) * LdsEq<K>::kWaveBytes;
     const int j0 = first[p], j1 = first[p + 1];
     for (int j = j0; j < j1; ++j) {
         const StripJob job = jobs[j];
         // the ragged bottom of a pair runs as short 32-row-per-lane strips instead of one mostly empty tall one
         if (K > 1 && job.k == 1) run_strip<1, false, false, CKPT, true>(job, err);
-        else run_strip<K, false, false, CKPT, true>(job, err);
+        else run_strip<K, false, false, CKPT, true, LDSEQ>(job, err, lds_wave);
         // the next strip reads what this one stored (granules): drain and order the stores first (same wavefront, same CU)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }

@@ -340,6 +340,16 @@ bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_tic
         set_error("fill / scatter strips are built for k = 1 without checkpoints only");
         return false;
     }
+    // tall cost-only strips take their eq words from LDS: one slice per wavefront of the block
+    static const bool no_ldseq = getenv("PA_STRIP_NO_LDSEQ") != nullptr;
+    if (!no_ldseq && !scatter && !fill && (k == 4 || k == 8)) {
+        const unsigned need = (unsigned)block_waves * (k == 8 ? LdsEq<8>::kWaveBytes : LdsEq<4>::kWaveBytes);
+        const unsigned l = std::max(lds, need);
+        if (ckpt && k == 4) return launch_one(strip_kernel<4, false, false, true, true>, grid, block_waves, l, s, d_jobs, njobs, d_ticket_err);
+        if (ckpt && k == 8) return launch_one(strip_kernel<8, false, false, true, true>, grid, block_waves, l, s, d_jobs, njobs, d_ticket_err);
+        if (k == 4) return launch_one(strip_kernel<4, false, false, false, true>, grid, block_waves, l, s, d_jobs, njobs, d_ticket_err);
+        return launch_one(strip_kernel<8, false, false, false, true>, grid, block_waves, l, s, d_jobs, njobs, d_ticket_err);
+    }
     if (ckpt) {
         if (k == 1) return launch_one(strip_kernel<1, false, false, true>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
         if (k == 2) return launch_one(strip_kernel<2, false, false, true>, grid, block_waves, lds, s, d_jobs, njobs, d_ticket_err);
@@ -1697,7 +1707,9 @@ extern "C" void pa_batch_shape(const pa_batch* p, int* k, int* sequential, doubl
         double t = 0;
         for (const StripJob& j : p->jobs) {
             const int kj = p->sequential ? j.k : p->k;
-            t += 32.0 * (double)((j.n + 31) / 32 + 2) * (11.0 + 12.0 * kj);  // run_strip: (C + 2) chunks of 32 steps
+            // run_strip: (C + 2) chunks of 32 steps; tall strips read their eq words from LDS (strip_kernel.hpp LdsEq)
+            const bool lds_eq = kj >= 4 && !getenv(p->sequential ? "PA_PAIR_NO_LDSEQ" : "PA_STRIP_NO_LDSEQ");
+            t += 32.0 * (double)((j.n + 31) / 32 + 2) * (lds_eq ? 10.0 + 10.0 * kj : 11.0 + 12.0 * kj);
         }
         *valu_instructions = t;
     }

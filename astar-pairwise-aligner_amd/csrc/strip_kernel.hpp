@@ -603,7 +603,8 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
 // crowded SIMD, so balance is worth more than anything else at 1-4 wavefronts per SIMD.
 // `ticket` and `err` must be zeroed (and every hin/hout granule buffer cleared) before the launch.
 constexpr int kStripBlockWaves = 4;
-template <int K, bool FILL, bool SCATTER = false, bool CKPT = false>
+// LDSEQ (K >= 4, cost-only): eq words from LDS, see LdsEq; the launch provides one slice per wavefront of the block.
+template <int K, bool FILL, bool SCATTER = false, bool CKPT = false, bool LDSEQ = false>
 __global__ __launch_bounds__(64 * kStripBlockWaves) void strip_kernel(const StripJob* __restrict__ jobs, int njobs,
                                                    uint32_t* ticket, uint32_t* err) {
     uint32_t t = 0;
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void strip_kernel(const Stri
     PA_DBG(0, t + 1);
     if (t < (uint32_t)njobs) {
         const StripJob job = jobs[t];
-        run_strip<K, FILL, SCATTER, CKPT>(job, err);
+        run_strip<K, FILL, SCATTER, CKPT, false, LDSEQ>(job, err, rfl((uint32_t)(threadIdx.x >> 6)) * LdsEq<K>::kWaveBytes);
     }
     PA_DBG(0, 0x1000 + t);
 }

@@ -205,7 +205,8 @@ def main():
             "probe_mixed_stream_rate": round(VALU_MIXED_CEILING / 1e9, 1),
             "ratio_to_probe_mixed_stream": round(shape["valu_instructions"] / avg_kernel_s / VALU_MIXED_CEILING, 4),
             "instructions_per_2048_cells": round(shape["valu_instructions"] / (st["cells"] / 2048.0), 2),
-            "note": "(11 + 12k) VALU instructions per 64-lane x 32k-row strip step (ISA count, PMC SQ_INSTS_VALU agrees). "
+            "note": "(10 + 10k) VALU instructions per 64-lane x 32k-row strip step for k >= 4 (eq words come from LDS: 2 ds_read_b128 per "
+                    "k = 8 step, issued a step ahead), (11 + 12k) below (ISA count; PMC SQ_INSTS_VALU is 1.7 % above it). "
                     "peak = 1 instruction / 2 clk / SIMD, reached only by unbroken runs of simple VOP2 / 3-VGPR v_bitop3 ops; "
                     "probe_mixed_stream_rate = what tools/issue_probe measures for a 50/50 stream of those and of carry, "
                     "v_alignbit, v_bfe, DPP or SGPR-operand ops in blocks of >= 8 (1.57 ns per instruction per SIMD); a Myers "

@@ -96,7 +96,8 @@ int pa_batch_run(pa_batch* plan, int32_t* cost_out, float* kernel_ms);
 void pa_batch_stats(const pa_batch* plan, double* cells, double* word_updates, double* strips, double* algo_bytes);
 /* How the batch was laid out on the GPU (reporting only): k = 32-row subwords per lane of the tall strips (1, 2, 4, 8),
  * sequential = 1 when one wavefront runs a whole pair strip after strip (pair_kernel), 0 for chained strips
- * (strip_kernel); valu_instructions = wavefront VALU instructions one pass executes, (11 + 12 k) per strip step. */
+ * (strip_kernel); valu_instructions = wavefront VALU instructions one pass executes: (11 + 12 k) per strip step,
+ * (10 + 10 k) for k >= 4 (eq words read from LDS). */
 void pa_batch_shape(const pa_batch* plan, int* k, int* sequential, double* valu_instructions);
 void pa_batch_destroy(pa_batch* plan);
 

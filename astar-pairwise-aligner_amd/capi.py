@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "pa_batch_create", "pa_batch_run", "pa_batch_stats", "pa_batch_shape", "pa_batch_destroy",
     "pa_batch_create_banded", "pa_batch_create_trace", "pa_batch_align", "pa_batch_trace_fallbacks", "pa_params_batch_align",
     "pa_pairs_read", "pa_pairs_count", "pa_pairs_get", "pa_pairs_free", "pa_write_results_csv", "pa_align_file",
-    "pa_align",
+    "pa_align", "pa_batch_align_multi",
 ]
 
 _lib = None
@@ -83,6 +83,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_pairs_free.argtypes = [vp]
     L.pa_write_results_csv.argtypes = [C.c_char_p, vp, vp, sz]
     L.pa_write_results_csv.restype = C.c_int
+    L.pa_batch_align_multi.argtypes = [vp, vp, vp, vp, sz, C.POINTER(C.c_int), C.c_int, vp, vp]
+    L.pa_batch_align_multi.restype = C.c_int
     L.pa_align_file.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(sz)]
     L.pa_align_file.restype = C.c_int
     for name in ("astarpa2_simple", "astarpa2_full", "astarpa"):
@@ -204,6 +206,33 @@ def align_file(input_path: str, output_path: str) -> int:
     if rc != 0:
         raise PaError(f"pa_align_file rc={rc}: {last_error()}")
     return int(n.value)
+
+
+def align_multi(pairs: list[tuple[bytes, bytes]], devices: list[int], trace: bool = True):
+    """pa_batch_align_multi: shard `pairs` over `devices` (one host thread each, inside the library) -> (costs, CIGARs or None)."""
+    L = load()
+    n = len(pairs)
+    ap = (C.c_void_p * n)(*[C.cast(C.c_char_p(a), C.c_void_p) for a, _ in pairs])
+    bp = (C.c_void_p * n)(*[C.cast(C.c_char_p(b), C.c_void_p) for _, b in pairs])
+    al = (C.c_size_t * n)(*[len(a) for a, _ in pairs])
+    bl = (C.c_size_t * n)(*[len(b) for _, b in pairs])
+    dev = (C.c_int * len(devices))(*devices)
+    out = np.zeros(n, np.int32)
+    cig = (C.c_void_p * n)() if trace else None
+    rc = L.pa_batch_align_multi(ap, al, bp, bl, n, dev, len(devices), _p(out), cig)
+    if rc == -1:
+        raise ValueError("sequence contains a character outside ACGT")
+    if rc != 0:
+        raise PaError(f"pa_batch_align_multi rc={rc}: {last_error()}")
+    if not trace:
+        return out, None
+    try:
+        cigars = [C.string_at(cig[i]).decode() if cig[i] else "" for i in range(n)]
+    finally:
+        for i in range(n):
+            if cig[i]:
+                L.astarpa_free_cigar(C.c_void_p(cig[i]))
+    return out, cigars
 
 
 class Batch:

@@ -17,6 +17,7 @@
 #include <fstream>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pa_hip_internal.hpp"
@@ -173,4 +174,97 @@ extern "C" int pa_align_file(const char* input_path, const char* output_path, si
     if (rc == 0 && output_path) rc = pa_write_results_csv(output_path, costs.data(), cigars.data(), n);
     for (char* c : cigars) std::free(c);
     return rc;
+}
+
+// Many-pair mode over several GPUs from ONE process (the reference aligns pairs one after another,
+// pa-bin/src/main.rs:24-35, so they shard with no data-path exchange).  Pairs are assigned longest-processing-time-first by
+// n * ceil(m / 64) (the same plan as sharding.py plan_shards); one host thread per entry of `devices` selects its device
+// (pa_set_device is per thread), runs one pa_batch_align (or the cost-only batch when cigar_out is NULL) over its shard and
+// scatters the results back.  A device may be listed more than once (two shards in flight on one GPU).
+extern "C" int pa_batch_align_multi(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len,
+                                    size_t pairs, const int* devices, int ndevices, int32_t* cost_out, char** cigar_out) {
+    if (ndevices <= 0 || !devices || !cost_out || (pairs && (!a || !b || !a_len || !b_len))) {
+        pa::set_error("pa_batch_align_multi: bad arguments");
+        return PA_E_ARG;
+    }
+    const int ndev = pa_device_count();
+    for (int d = 0; d < ndevices; ++d)
+        if (devices[d] < 0 || devices[d] >= ndev) {
+            pa::set_error("pa_batch_align_multi: device %d not visible (%d device(s))", devices[d], ndev);
+            return PA_E_ARG;
+        }
+    if (cigar_out)
+        for (size_t i = 0; i < pairs; ++i) cigar_out[i] = nullptr;
+    // longest-processing-time-first, ties by index: deterministic
+    std::vector<size_t> order(pairs);
+    std::vector<uint64_t> work(pairs);
+    for (size_t i = 0; i < pairs; ++i) {
+        order[i] = i;
+        work[i] = (uint64_t)a_len[i] * ((b_len[i] + 63) / 64) + 1;
+    }
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return work[x] != work[y] ? work[x] > work[y] : x < y; });
+    std::vector<std::vector<size_t>> shard((size_t)ndevices);
+    std::vector<uint64_t> load((size_t)ndevices, 0);
+    for (size_t i : order) {
+        size_t r = 0;
+        for (size_t k = 1; k < (size_t)ndevices; ++k)
+            if (load[k] < load[r]) r = k;
+        shard[r].push_back(i);
+        load[r] += work[i];
+    }
+    std::vector<int> rcs((size_t)ndevices, 0);
+    std::vector<std::string> errs((size_t)ndevices);
+    auto worker = [&](int r) {
+        std::vector<size_t>& mine = shard[(size_t)r];
+        std::sort(mine.begin(), mine.end());
+        if (mine.empty()) return;
+        int rc = pa_set_device(devices[r]);
+        if (rc == 0) {
+            const size_t k = mine.size();
+            std::vector<const uint8_t*> ap(k), bp(k);
+            std::vector<size_t> al(k), bl(k);
+            for (size_t j = 0; j < k; ++j) {
+                ap[j] = a[mine[j]];
+                bp[j] = b[mine[j]];
+                al[j] = a_len[mine[j]];
+                bl[j] = b_len[mine[j]];
+            }
+            std::vector<int32_t> costs(k, 0);
+            std::vector<char*> cigars(cigar_out ? k : 0, nullptr);
+            pa_batch* plan = cigar_out ? pa_batch_create_trace(ap.data(), al.data(), bp.data(), bl.data(), k)
+                                       : pa_batch_create(ap.data(), al.data(), bp.data(), bl.data(), k);
+            if (!plan) rc = PA_E_HIP;
+            else {
+                rc = cigar_out ? pa_batch_align(plan, costs.data(), cigars.data(), nullptr, nullptr) : pa_batch_run(plan, costs.data(), nullptr);
+                pa_batch_destroy(plan);
+            }
+            if (rc == 0)
+                for (size_t j = 0; j < k; ++j) {
+                    cost_out[mine[j]] = costs[j];
+                    if (cigar_out) cigar_out[mine[j]] = cigars[j];
+                }
+        }
+        if (rc != 0) {
+            rcs[(size_t)r] = rc;
+            errs[(size_t)r] = pa_last_error();  // (the error text is per thread)
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int r = 1; r < ndevices; ++r) threads.emplace_back(worker, r);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    worker(0);  // the calling thread takes the first shard
+    (void)pa_set_device(cur);
+    for (std::thread& t : threads) t.join();
+    for (int r = 0; r < ndevices; ++r)
+        if (rcs[(size_t)r] != 0) {
+            if (cigar_out)
+                for (size_t i = 0; i < pairs; ++i) {
+                    std::free(cigar_out[i]);
+                    cigar_out[i] = nullptr;
+                }
+            pa::set_error("pa_batch_align_multi: shard %d (device %d): %s", r, devices[r], errs[(size_t)r].c_str());
+            return rcs[(size_t)r];
+        }
+    return 0;
 }

@@ -116,6 +116,14 @@ int pa_batch_align(pa_batch* plan, int32_t* cost_out, char** cigar_out, float* f
 /* Pairs (summed over all pa_batch_align calls of this plan) whose traceback was redone by the host engine. */
 size_t pa_batch_trace_fallbacks(const pa_batch* plan);
 
+/* Many-pair mode over several GPUs from ONE process (independent pairs shard with no data-path exchange; the
+ * reference runs them one after another, pa-bin/src/main.rs:24-35).  Pairs are assigned longest-processing-time-first by
+ * n * ceil(m / 64); one host thread per entry of devices[0..ndevices) binds its device and runs one pa_batch_align over its
+ * shard (the cost-only batch when cigar_out is NULL); results land at the pairs' original indices.  A device may be listed
+ * twice (two shards in flight on one GPU).  One process per GPU with torch.distributed (sharding.py) is the other recipe. */
+int pa_batch_align_multi(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len, size_t pairs,
+                         const int* devices, int ndevices, int32_t* cost_out, char** cigar_out);
+
 /* ---- pa-bin's data formats (pa-bin/src/lib.rs:67-114, pa-bin/src/main.rs:24-35) ------------------------- */
 /* Input: `.seq` (line pairs, '>' then '<' markers), `.txt` (plain line pairs), `.fna`/`.fa`/`.fasta` (records taken two at
  * a time), or a directory of such files.  Output: one line "{cost},{cigar}" per pair.  Host code only. */

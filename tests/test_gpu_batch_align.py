@@ -133,3 +133,55 @@ def test_batch_align_equals_engine_with_pa_params_batch_align(pa):
     al = p.make_aligner(True)
     for (a, b), (c, g) in zip(pairs, got):
         assert al.align(a, b) == (c, g)
+
+
+def test_two_shards_in_one_process_on_one_device(pa, oracle):
+    """pa_batch_align_multi with devices = {0, 0}: two host threads inside the library, each binding device 0 (pa_set_device is
+    per thread) and running its own batch concurrently -- the per-(kernel, device) launch attributes, the per-thread device
+    properties and the error text must not interfere.  Results equal the single-batch call, pair for pair."""
+    pairs = [gen_pair(n, e, seed=n + int(100 * e)) for n in (300, 5000, 10_000, 20_000, 2049, 777) for e in (0.02, 0.1, 0.2)]
+    pairs += [(b"", b"ACGT"), (b"ACGT", b"")]
+    costs, cigars = pa.align_multi(pairs, [0, 0])
+    single = pa.Batch(pairs, trace=True)
+    want_costs, want_cigars, _, _ = single.align()
+    single.close()
+    assert costs.tolist() == want_costs.tolist() and cigars == want_cigars
+    cost_only, none = pa.align_multi(pairs, [0, 0, 0], trace=False)
+    assert none is None and cost_only.tolist() == want_costs.tolist()
+    with pytest.raises(pa.PaError):
+        pa.align_multi(pairs, [0, 99])
+
+
+def test_concurrent_host_threads_through_the_c_abi(pa, oracle):
+    """Python threads calling different entry points at once (ctypes releases the GIL): pa_align through the sweep, a cost-only
+    batch and a traced batch, all on device 0."""
+    import threading
+
+    from tests.test_gpu_engine import gpu_params
+
+    a, b = gen_pair(30_000, 0.05, seed=9)
+    pairs = [gen_pair(4000, 0.1, seed=s) for s in range(40)]
+    out = {}
+
+    def t_engine():
+        out["engine"] = [gpu_params(pa, oracle.params_simple()).make_aligner(True).align(a, b) for _ in range(3)]
+
+    def t_batch():
+        out["batch"] = [pa.Batch(pairs).run()[0].tolist() for _ in range(3)]
+
+    def t_trace():
+        bt = pa.Batch(pairs, trace=True)
+        out["trace"] = [bt.align()[:2] for _ in range(2)]
+        bt.close()
+
+    ts = [threading.Thread(target=f) for f in (t_engine, t_batch, t_trace)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    want = oracle.cpu_align(a, b, oracle.params_simple())
+    assert all((c, g) == (want[0], want[1]) for c, g in out["engine"])
+    want_costs = [oracle.levenshtein(x, y) for x, y in pairs]
+    assert all(c == want_costs for c in out["batch"])
+    assert all(c.tolist() == want_costs for c, _ in out["trace"])
+    assert all(oracle.cigar_verify(g, x, y) == w for _, gs in out["trace"] for g, (x, y), w in zip(gs, pairs, want_costs))

@@ -73,6 +73,30 @@ def test_c4_batch_10kbp_mixed_divergence(pa, oracle):
     assert by_div == sorted(by_div)
 
 
+def test_c4_full_10000_pairs_with_traceback(pa, oracle):
+    """C4 as BASELINE.json states it: 10 000 pairs of 10 kbp, divergence 1 / 5 / 10 / 15 % by pair index, global alignment WITH
+    traceback in one pa_batch_align call.  Every CIGAR replays to its pair at exactly the reported cost; a 1 % sample equals the
+    CPU engine over the oracle kernels (cost and CIGAR string, the parameter set `pa_params_batch_align` names); the costs equal
+    the cost-only batch (an independent kernel path); no pair fell back to the host."""
+    from tests.test_gpu_batch_align import traced_params
+
+    divs = (0.01, 0.05, 0.10, 0.15)
+    pairs = [gen_pair(10_000, divs[i % 4], seed=2_000_000 + i) for i in range(10_000)]
+    batch = pa.Batch(pairs, trace=True)
+    costs, cigars, _, _ = batch.align()
+    assert batch.trace_fallbacks() == 0
+    batch.close()
+    assert len(cigars) == 10_000
+    for (a, b), c, cg in zip(pairs, costs, cigars):
+        assert oracle.cigar_verify(cg, a, b) == c
+    prm = traced_params(oracle)
+    for i in range(37, 10_000, 100):  # 100 pairs, every divergence class
+        want_cost, want_cigar, _ = oracle.cpu_align(*pairs[i], prm)
+        assert (int(costs[i]), cigars[i]) == (want_cost, want_cigar), i
+    plain, _ = pa.Batch(pairs).run()
+    assert np.array_equal(np.asarray(costs), np.asarray(plain))
+
+
 def test_c4_properties_suffix_and_substitutions(pa):
     a = rand_seq(50_000, seed=77)
     suffix = rand_seq(1234, seed=78)

@@ -332,10 +332,11 @@ bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_tic
     if (njobs == 0) return true;
     // d_ticket_err[0] = ticket, [1] = err
     if (zero_ticket && !hip_ok(hipMemsetAsync(d_ticket_err, 0, 2 * sizeof(uint32_t), s), "memset ticket")) return false;
-    if (block_waves != 1 && block_waves != kStripBlockWaves) block_waves = kStripBlockWaves;
+    if (block_waves < 1 || block_waves > kStripMaxBlockWaves) block_waves = kStripBlockWaves;
+    if (const char* e = getenv("PA_STRIP_BLOCK_WAVES")) block_waves = std::min(std::max(atoi(e), 1), kStripMaxBlockWaves);  // experiments
     const int grid = (njobs + block_waves - 1) / block_waves;  // one wave per job; jobs beyond residency queue behind their
                                                                // producers (ticket order)
-    const unsigned lds = block_waves == kStripBlockWaves ? residency_lds_bytes(grid) : 0;
+    const unsigned lds = block_waves >= kStripBlockWaves ? residency_lds_bytes(grid) : 0;
     if ((scatter || fill) && (k != 1 || ckpt)) {
         set_error("fill / scatter strips are built for k = 1 without checkpoints only");
         return false;
@@ -945,7 +946,7 @@ extern "C" int pa_search_trace(const uint8_t* pattern, size_t plen, const uint8_
 struct pa_batch {
     size_t pairs = 0;
     std::vector<size_t> n, m, a_off, b_off, code_off, prof_off, gran_off;
-    DeviceBuf d_a, d_b, d_codes, d_prof, d_v, d_gran, d_jobs, d_sums, d_misc, d_desc;
+    DeviceBuf d_a, d_b, d_codes, d_prof, d_v, d_gran, d_jobs, d_sums, d_misc, d_desc, d_wavelog;
     size_t max_n = 0, max_m = 0;
     std::vector<StripJob> jobs;
     std::vector<int> last_job;  // per pair (or -1 when w == 0)
@@ -995,7 +996,9 @@ struct BatchShape {
     int block_waves = 1;
 };
 static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, size_t pairs) {
-    static const double kLone[4] = {52.9, 76.5, 121.0, 210.0}, kSatChain[4] = {50.8, 65.0, 112.5, 170.0};
+    // ns per strip step (measured, profiles/r02_runs): a wavefront alone on its SIMD; one of W fairly served wavefronts of a SIMD
+    // (rotating issue priority + paced top strips, per wavefront and per W); chained strips queueing beyond residency
+    static const double kLone[4] = {52.9, 76.5, 121.0, 200.0}, kFair[4] = {40.0, 58.0, 82.0, 138.0}, kSatChain[4] = {50.8, 65.0, 100.0, 150.0};
     static const double kShare[4] = {1.0, 0.85, 0.80, 0.78};  // per-wavefront step cost at 1, 2, 3, >= 4 wavefronts per SIMD
     static const int kK[4] = {1, 2, 4, 8};
     const double simds = (double)(g_device_props_cus > 0 ? g_device_props_cus : 256) * 4.0;
@@ -1028,13 +1031,17 @@ static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, s
         if (live == 0) return best_shape;
         if (env_mode != 2) {  // chained strips
             const double avg = strips / simds;
-            const double per_col = avg <= 1.0 ? kLone[t] : (avg + 1.0) * kSatChain[t];
+            const double wmax = std::ceil(std::ceil(strips / (simds / 4.0)) / 4.0);  // one workgroup per CU, waves round-robin over its SIMDs
+            const double per_col = avg <= 1.0 ? kLone[t] : (strips <= 4.0 * simds ? wmax * kFair[t] : (avg + 1.0) * kSatChain[t]);
             const double cost = per_col * colsteps / strips;
             if (best < 0 || cost < best) {
                 best = cost;
                 best_shape.k = k;
                 best_shape.sequential = false;
-                best_shape.block_waves = strips <= simds ? kStripBlockWaves : 1;
+                // The waves of ONE workgroup are spread round-robin over the four SIMDs of its CU; separate workgroups are not
+                // (PA_STRIP_WAVELOG: 1792 single-wave workgroups leave 8 SIMDs with three wavefronts, and every chain that
+                // touches one runs at a third of a SIMD).  So: one workgroup per CU, as tall as the batch needs.
+                best_shape.block_waves = (strips <= simds || strips > 4.0 * simds) ? kStripBlockWaves : (int)std::ceil(strips / (simds / 4.0));
             }
         }
         if (env_mode != 1) {  // one wavefront per pair
@@ -1147,7 +1154,7 @@ static void choose_band_shape(pa_batch* p) {
         if (best < 0 || cost < best) {
             best = cost;
             best_k = kK[t];
-            p->block_waves = (p->sequential || strips <= simds) ? kStripBlockWaves : 1;
+            p->block_waves = (p->sequential || strips <= simds || strips > 4.0 * simds) ? kStripBlockWaves : (int)std::ceil(strips / (simds / 4.0));
         }
     }
     p->k = best_k;
@@ -1225,7 +1232,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             return nullptr;
     }
     if (!p->d_a.alloc(ta) || !p->d_b.alloc(tb) || !p->d_codes.alloc(tc * 4) || !p->d_prof.alloc(tp * 16) ||
-        !p->d_v.alloc(tp * 16) || !p->d_gran.alloc(tg * 8) || !p->d_sums.alloc(std::max<size_t>(pairs * 4, 16)) || !p->d_misc.alloc(16))
+        !p->d_v.alloc(tp * 16) || !p->d_gran.alloc(tg * 8) || !p->d_sums.alloc(std::max<size_t>(pairs * 4, 16)) || !p->d_misc.alloc(32))
         return nullptr;
     if (!hip_ok(hipStreamCreate(&p->stream), "hipStreamCreate") || !hip_ok(hipEventCreate(&p->ev0), "event") ||
         !hip_ok(hipEventCreate(&p->ev1), "event") || !hip_ok(hipEventCreate(&p->ev2), "event"))
@@ -1366,6 +1373,37 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             !hip_ok(hipStreamSynchronize(p->stream), "sync"))
             return nullptr;
     }
+    if (!p->sequential && !p->trace && !p->banded && !p->jobs.empty()) {
+        // Chained batches beyond one wavefront per SIMD: a SIMD serves its OLDEST wavefront first, the younger ones get what is
+        // left, and a chain advances at the pace of its most starved strip -- so pairs finish staggered by wave slot and the
+        // tail of the launch runs on a mostly idle chip (PA_STRIP_WAVELOG shows it).  The top strip of every pair therefore
+        // paces itself against the average progress of all pairs (strip_kernel.hpp kJobPace).
+        // Both need every strip resident (at most four wavefronts per SIMD at <= 128 VGPRs); beyond that strips queue in ticket
+        // order and only the priority rotation is kept.
+        static const bool no_pace = getenv("PA_STRIP_NO_PACE") != nullptr;
+        static const int prio = getenv("PA_STRIP_PRIO") ? atoi(getenv("PA_STRIP_PRIO")) : 3;  // 0 = off, 3 = rotate (1, 2: experiments)
+        static const int lag = getenv("PA_STRIP_LAG") ? atoi(getenv("PA_STRIP_LAG")) : 0;
+        const size_t simds = (size_t)(g_device_props_cus > 0 ? g_device_props_cus : 256) * 4;
+        int tops = 0;
+        for (const StripJob& j : p->jobs) tops += j.hin_gran == nullptr;
+        for (StripJob& j : p->jobs) {
+            if (p->jobs.size() > simds) j.flags |= (prio & 3) << 1;
+            if (lag) j.flags |= kJobLag;
+            if (!no_pace && p->jobs.size() > simds && p->jobs.size() <= 4 * simds && j.hin_gran == nullptr && tops > 1) {
+                j.flags |= kJobPace;
+                j.ckpt = p->d_misc.as<uint32_t>() + 4;  // the u64 progress counter (zeroed with the ticket before every pass)
+                j.ckpt_stride = tops;
+            }
+        }
+    }
+    if (getenv("PA_STRIP_WAVELOG") && !p->trace && !p->jobs.empty()) {
+        // diagnostics: every strip wavefront leaves {HW_ID, XCC_ID, start, end (100 MHz), chunks that had to poll} behind
+        if (!p->d_wavelog.alloc(p->jobs.size() * 32)) return nullptr;
+        for (size_t j = 0; j < p->jobs.size(); ++j) {
+            p->jobs[j].values = p->d_wavelog.as<uint32_t>() + 8 * j;
+            p->jobs[j].flags |= kJobLog;
+        }
+    }
     if (!p->d_jobs.alloc(p->jobs.size() * sizeof(StripJob))) return nullptr;
     if (!p->jobs.empty() &&
         !hip_ok(hipMemcpyAsync(p->d_jobs.ptr, p->jobs.data(), p->jobs.size() * sizeof(StripJob), hipMemcpyHostToDevice, p->stream), "H2D jobs"))
@@ -1397,7 +1435,7 @@ extern "C" pa_batch* pa_batch_create_trace(const uint8_t* const* a, const size_t
 static int batch_forward(pa_batch* p) {
     hipStream_t s = p->stream;
     // (1) profiles (BitProfile::build, once per pair: blocks.rs:112)
-    if (!hip_ok(hipMemsetAsync(p->d_misc.ptr, 0, 16, s), "memset")) return PA_E_HIP;
+    if (!hip_ok(hipMemsetAsync(p->d_misc.ptr, 0, 32, s), "memset")) return PA_E_HIP;  // (+ the pace counter of chained batches)
     for (size_t base = 0; base < p->pairs; base += 32768) {  // gridDim.y limit
         const unsigned ny = (unsigned)std::min<size_t>(32768, p->pairs - base);
         const PairDesc* dd = p->d_desc.as<PairDesc>() + base;
@@ -1523,6 +1561,22 @@ extern "C" int pa_batch_run(pa_batch* p, int32_t* cost_out, float* kernel_ms) {
         return PA_E_TIMEOUT;
     }
     p->gran_dirty = p->banded && !p->sequential;  // clean finish (banded chained strips leave unconsumed granules behind)
+    if (p->d_wavelog.ptr) {
+        std::vector<uint32_t> log(p->jobs.size() * 8);
+        if (hip_ok(hipMemcpy(log.data(), p->d_wavelog.ptr, log.size() * 4, hipMemcpyDeviceToHost), "D2H wavelog")) {
+            if (FILE* f = std::fopen(getenv("PA_STRIP_WAVELOG"), "w")) {
+                std::fprintf(f, "job k word0 xcc se cu simd wave t0 t1 polled\n");
+                for (size_t j = 0; j < p->jobs.size(); ++j) {
+                    const uint32_t* r = &log[8 * j];
+                    const uint32_t hw = r[0];
+                    std::fprintf(f, "%zu %d %d %u %u %u %u %u %llu %llu %u\n", j, p->sequential ? p->jobs[j].k : p->k, p->jobs[j].word0, r[1] & 15u,
+                                 (hw >> 13) & 7u, (hw >> 8) & 15u, (hw >> 4) & 3u, hw & 15u, (unsigned long long)(r[2] | ((uint64_t)r[3] << 32)),
+                                 (unsigned long long)(r[4] | ((uint64_t)r[5] << 32)), r[6]);
+                }
+                std::fclose(f);
+            }
+        }
+    }
     if (kernel_ms) {
         *kernel_ms = 0.f;
         if (!p->jobs.empty() && !hip_ok(hipEventElapsedTime(kernel_ms, p->ev0, p->ev1), "elapsed")) return PA_E_HIP;

@@ -92,7 +92,20 @@ struct StripJob {
     int32_t* vsum_out;        // banded strips: atomically add the sum of this strip's right-edge vertical deltas (rows
                               // below tail_rows excluded); cost = n + sum over the strips of a pair.  Or nullptr
 };
-enum : int32_t { kJobVInitOne = 1 };
+enum : int32_t {
+    kJobVInitOne = 1,
+    kJobLag = 8,       // chained strips: a strip that had to poll for granule q keeps waiting until granule q + 4 is there too, so
+                       // that its next prefetches (issued one chunk ahead) hit instead of polling again at every chunk
+    kJobLog = 16,      // diagnostics (cost-only strips): `values` points at 8 words that receive HW_ID, XCC_ID, start and end
+                       // time and the number of chunks that had to poll (PA_STRIP_WAVELOG)
+    kJobPace = 32,     // top strip of a pair in a chained batch (cost-only): `ckpt` points at a u64 counter that every such strip
+                       // increments once per chunk, `ckpt_stride` = number of such strips; a strip more than kPaceLead chunks
+                       // ahead of the average naps until the others caught up (bounded), one that finished adds kPaceDone so
+                       // that nobody waits for it
+    kJobPrioMask = 6,  // chained strips: 1 = a strip that found its granule ready (it is behind its producer) raises its issue
+                       // priority, one that had to poll lowers it; 2 = additionally the top strip of a chain runs at the
+                       // highest priority.  Wavefronts of a SIMD are otherwise served oldest first.
+};
 static_assert(sizeof(StripJob) == 136, "StripJob layout");
 
 enum : uint32_t {
@@ -100,6 +113,8 @@ enum : uint32_t {
     PA_ERR_SPIN_TIMEOUT = 1,  // a producer strip never delivered its granule
 };
 
+constexpr int kPaceLead = 6;
+constexpr unsigned long long kPaceDone = 1ull << 40;
 constexpr uint64_t kSpinTimeoutTicks = 30ull * 100000000ull;  // 30 s of the 100 MHz wall clock: a lost producer ends the
                                                                  // wave with PA_ERR_SPIN_TIMEOUT instead of hanging the GPU
 
@@ -461,6 +476,10 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
                __builtin_popcount(vlo & 0x55555555u) - __builtin_popcount(vhi & 0x55555555u);
     };
 
+    if (!LOCAL && ((job.flags & kJobPrioMask) >> 1) >= 2 && !has_gran) __builtin_amdgcn_s_setprio(3);
+    const uint32_t prio_slot = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 4);  // HW_ID.wave_id: the slot on this SIMD
+    const uint64_t log_t0 = (!FILL && (job.flags & kJobLog)) ? wall_clock64() : 0;
+    uint32_t log_polled = 0;
     RawCodes codes_next = load_codes(0);
     uint64_t gran_next = load_gran(0);
     uint32_t hinb_next = load_hin_byte(0);
@@ -500,10 +519,46 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
         uint32_t hin2 = has_hin ? (((hinb_next & 1u) << 31) | ((hinb_next & 2u) << 29)) : 0x80000000u;
         if (q < C && has_gran && (job.hin_n == 0 || q * 32 < job.hin_n)) {
             uint32_t glo, ghi;
-            alive = resolve_granule<LOCAL>(g_gran, gran_next, q, glo, ghi);
+            if (!LOCAL && (job.flags & kJobPrioMask) && (job.flags & kJobPrioMask) != kJobPrioMask) {
+                if (rfl((uint32_t)gran_next) == 0u) __builtin_amdgcn_s_setprio(0);
+                else __builtin_amdgcn_s_setprio(2);
+            }
+            if (!FILL && rfl((uint32_t)gran_next) == 0u) ++log_polled;
+            if (!LOCAL && (job.flags & kJobLag) && rfl((uint32_t)gran_next) == 0u) {
+                const int lastg = (job.hin_n == 0 || job.hin_n >= n ? C : job.hin_n / 32) - 1;
+                const int qa = q + 4 < lastg ? q + 4 : lastg;
+                uint32_t dl, dh;
+                if (qa > q) alive = resolve_granule<LOCAL>(g_gran, 0, qa, dl, dh);
+            }
+            if (alive) alive = resolve_granule<LOCAL>(g_gran, gran_next, q, glo, ghi);
             hin2 = ((upper ? ghi : glo) << sh) & 0xC0000000u;
             // every granule has exactly one consumer: hand it back zeroed, so the buffer needs clearing only once
             if (lane == 0) __hip_atomic_store((gu64)job.hin_gran + q, (uint64_t)0, __ATOMIC_RELAXED, kGranScope);
+        }
+        if (!LOCAL && (job.flags & kJobPrioMask) == kJobPrioMask) {
+            // rotate the issue priority chunk by chunk, with a phase per wave slot: the SIMD serves the highest priority
+            // first and the OLDEST wavefront among equals, which starves the younger wavefronts of a shared SIMD -- and a
+            // chain advances at the pace of its most starved strip
+            const uint32_t ph = ((uint32_t)q + prio_slot) & 3u;
+            if (ph == 0) __builtin_amdgcn_s_setprio(0);
+            else if (ph == 1) __builtin_amdgcn_s_setprio(1);
+            else if (ph == 2) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(3);
+        }
+        if (!LOCAL && !CKPT && !FILL && (job.flags & kJobPace) && q < C) {
+            typedef PA_GLOBAL unsigned long long* gull;
+            const gull ctr = (gull)job.ckpt;
+            unsigned long long g = 0;
+            if (lane == 0) g = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t glo_ = rfl((uint32_t)g), ghi_ = rfl((uint32_t)(g >> 32));
+            const unsigned long long mine = (unsigned long long)(q > kPaceLead ? q - kPaceLead : 0) * (unsigned long long)job.ckpt_stride;
+            // ahead of the average by more than kPaceLead chunks: nap (a chunk is ~5 us of work), at most ~8 chunks' worth
+            for (int nap = 0; nap < 16 && (((unsigned long long)ghi_ << 32) | glo_) < mine; ++nap) {
+                __builtin_amdgcn_s_sleep(127);
+                if (lane == 0) g = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                glo_ = rfl((uint32_t)g);
+                ghi_ = rfl((uint32_t)(g >> 32));
+            }
         }
         const uint32_t XS = code | hin2;
         // ---- publish the granule completed by the previous chunk (q-1) ----
@@ -539,6 +594,19 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
 #undef PA_RUN_CHUNK
     }
     if (alive) publish(C - 1);  // the last granule (completed by chunk Q-1 = C+1)
+    if (!LOCAL && !CKPT && !FILL && (job.flags & kJobPace) && lane == 0)
+        (void)__hip_atomic_fetch_add((PA_GLOBAL unsigned long long*)job.ckpt, kPaceDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!FILL && (job.flags & kJobLog) && lane == 0) {
+        const uint64_t t1 = wall_clock64();
+        gu32 lg = (gu32)job.values;
+        lg[0] = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
+        lg[1] = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+        lg[2] = (uint32_t)log_t0;
+        lg[3] = (uint32_t)(log_t0 >> 32);
+        lg[4] = (uint32_t)t1;
+        lg[5] = (uint32_t)(t1 >> 32);
+        lg[6] = log_polled;
+    }
     PA_DBG(1, 2);
     if (!alive) {
         if (lane == 0) __hip_atomic_store((gu32)err, (uint32_t)PA_ERR_SPIN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -603,9 +671,10 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
 // crowded SIMD, so balance is worth more than anything else at 1-4 wavefronts per SIMD.
 // `ticket` and `err` must be zeroed (and every hin/hout granule buffer cleared) before the launch.
 constexpr int kStripBlockWaves = 4;
+constexpr int kStripMaxBlockWaves = 16;  // chained batches beyond one wavefront per SIMD: one workgroup per CU (<= 128 VGPRs)
 // LDSEQ (K >= 4, cost-only): eq words from LDS, see LdsEq; the launch provides one slice per wavefront of the block.
 template <int K, bool FILL, bool SCATTER = false, bool CKPT = false, bool LDSEQ = false>
-__global__ __launch_bounds__(64 * kStripBlockWaves) void strip_kernel(const StripJob* __restrict__ jobs, int njobs,
+__global__ __launch_bounds__(64 * kStripMaxBlockWaves) void strip_kernel(const StripJob* __restrict__ jobs, int njobs,
                                                    uint32_t* ticket, uint32_t* err) {
     uint32_t t = 0;
     if ((threadIdx.x & 63) == 0) t = atomicAdd(ticket, 1u);

@@ -419,14 +419,52 @@ static HipBackend& pooled_backend() {
 
 // ---- the device-side sweep: one launch per align_for_bounded_dist pass (sweep_wave.hpp) ---------------------------------
 // Launcher of sweep::SweepAligner over HIP.  Its buffers are pooled per host thread like the backend's.
+// Passes of one band search run pipelined (sweep_host.hpp search()): every pass in flight has a SLOT with its own records,
+// buffers and stream; the merged block records of the completed passes alternate between two arrays.
+struct SweepSlot {
+    DeviceBuf d_brec, d_trec, d_misc, d_start, d_pring, d_gran, d_col;
+    hipStream_t s = nullptr;
+    hipEvent_t merged_ev = nullptr;  // recorded behind the merge of the pass that ran here
+    sweep::Status* h_status = nullptr;  // pinned
+    // the pass that runs (or ran last) here
+    int seq = 0, mbuf = 0;
+    uint32_t pass = 0;
+    bool live = false;
+    int32_t f_max = 0, waves = 0;
+    sweep::PassGeometry geo{};
+    double t_launch = 0;
+    // bprog @0, ticket @16, done @24, cancel @56 (directly before the status block), status @64, phase clocks @512
+    uint64_t* bprog() { return d_misc.as<uint64_t>(); }
+    uint32_t* ticket() { return d_misc.as<uint32_t>() + 4; }
+    uint64_t* done() { return d_misc.as<uint64_t>() + 3; }
+    uint64_t* cancel() { return d_misc.as<uint64_t>() + 7; }
+    sweep::Status* status() { return reinterpret_cast<sweep::Status*>(d_misc.as<uint8_t>() + 64); }
+};
 struct SweepPool {
-    DeviceBuf d_old, d_brec, d_trec, d_misc, d_start, d_pring, d_gran, d_col, d_sh, d_recs, d_offs, d_pack;
+    static constexpr int kSlots = 6;
+    SweepSlot slots[kSlots];
+    DeviceBuf d_merged[2], d_sh, d_recs, d_offs, d_pack;
+    hipStream_t ctl = nullptr;  // cancel words go out here, past the running passes
     void* h_pin = nullptr;
     size_t h_pin_size = 0;
     uint32_t pass_id = 0;
     int device = -1;
+    bool ok = false;
+    SweepPool() {
+        ok = hip_ok(hipStreamCreateWithFlags(&ctl, hipStreamNonBlocking), "hipStreamCreate");
+        for (SweepSlot& sl : slots)
+            ok = ok && hip_ok(hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking), "hipStreamCreate") &&
+                 hip_ok(hipEventCreateWithFlags(&sl.merged_ev, hipEventDisableTiming), "hipEventCreate") &&
+                 hip_ok(hipHostMalloc((void**)&sl.h_status, sizeof(sweep::Status), hipHostMallocDefault), "hipHostMalloc");
+    }
     ~SweepPool() {
         if (h_pin) (void)hipHostFree(h_pin);
+        for (SweepSlot& sl : slots) {
+            if (sl.h_status) (void)hipHostFree(sl.h_status);
+            if (sl.merged_ev) (void)hipEventDestroy(sl.merged_ev);
+            if (sl.s) (void)hipStreamDestroy(sl.s);
+        }
+        if (ctl) (void)hipStreamDestroy(ctl);
     }
     void* pinned(size_t bytes) {
         if (bytes > h_pin_size) {
@@ -458,87 +496,125 @@ struct HipSweepLauncher {
     bool trace = false;
     bool has_sh = false;
     int32_t heur_kind = sweep::kHeurGap;
-    sweep::PassGeometry geo{};
-    sweep::BlockRec old1{};
-    float kernel_ms = 0.0f;  // device time of the sweep kernels of this pair
 
     HipSweepLauncher(HipBackend& backend, SweepPool& p) : be(backend), pool(p) {}
+    ~HipSweepLauncher() { cancel_after(0); }
 
     void hip_fail(const char* what) { throw sweep::SweepFallback(what, -2); }
     static bool timing_on() {
         static const bool on = std::getenv("PA_SWEEP_TIMING") != nullptr;
         return on;
     }
+    SweepSlot& slot_of(int seq) { return pool.slots[seq % SweepPool::kSlots]; }
+    // (a pass's records must outlive its successor, which reads them: one slot more than passes in flight)
+    // Passes in flight run on separate streams, and streams only run side by side on separate hardware queues: the ROCm runtime
+    // multiplexes all streams of a process over GPU_MAX_HW_QUEUES of them (default 4; pa_sweep_runtime_hints below asks for 16
+    // when the library is loaded before the runtime starts).  A pass queued BEHIND a later one would only cost time, never
+    // correctness: passes are submitted in order and wait for their predecessors only.
+    int max_in_flight() const {
+        static const int depth = [] {
+            if (const char* e = std::getenv("PA_SWEEP_DEPTH")) return std::min(std::max(std::atoi(e), 1), SweepPool::kSlots - 1);
+            const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+            return (q && std::atoi(q) >= 8) ? SweepPool::kSlots - 1 : 3;
+        }();
+        return depth;
+    }
+    // wavefronts: one per strip the band can cover at a time (+ slack), one workgroup each
+    int pass_waves(int32_t f_max) const {
+        const sweep::PassGeometry g = sweep::pass_geometry(n, m, f_max);
+        int64_t waves = (2ll * g.win) / sweep::kStripRows + 6;
+        if (waves > g.nstrips) waves = g.nstrips;
+        if (waves > 1024) waves = 1024;
+        return (int)waves;
+    }
+    // Wavefronts of all passes in flight.  Most of a pass's wavefronts idle (a pass reserves one per strip its window can hold,
+    // the band covers a fraction of them at a time), so somewhat more than one per SIMD is fine; far more would only slow
+    // the passes that matter.
+    int wave_budget() const {
+        static const int budget = std::getenv("PA_SWEEP_WAVE_BUDGET") ? std::atoi(std::getenv("PA_SWEEP_WAVE_BUDGET")) : 1024;
+        return budget;
+    }
 
     // bytes of a zero-initialised tagged buffer: cleared only when it is new (tags of older passes never match)
-    void reserve_tagged(DeviceBuf& b, size_t bytes) {
+    void reserve_tagged(DeviceBuf& b, size_t bytes, hipStream_t st) {
         bool grew = false;
         if (!b.reserve(bytes, &grew)) hip_fail("hipMalloc");
-        if (grew && !hip_ok(hipMemsetAsync(b.ptr, 0, b.size, be.s), "memset")) hip_fail("memset");
+        if (grew && !hip_ok(hipMemsetAsync(b.ptr, 0, b.size, st), "memset")) hip_fail("memset");
     }
 
     void begin_pair(int32_t n_, int32_t m_, int32_t nblk_, const int32_t* sh, bool tr) {
+        using namespace sweep;
+        if (!pool.ok) hip_fail("sweep pool");
         n = n_;
         m = m_;
         nblk = nblk_;
         trace = tr;
         has_sh = sh != nullptr;
-        old1.js = sweep::kNone;
         const size_t recs = (size_t)nblk + 2;
-        if (!pool.d_old.reserve(recs * sizeof(sweep::BlockRec)) ||
-            !hip_ok(hipMemsetD32Async((hipDeviceptr_t)pool.d_old.ptr, (int)sweep::kNone, recs * sizeof(sweep::BlockRec) / 4, be.s), "memset d_old"))
-            hip_fail("d_old");
-        reserve_tagged(pool.d_brec, recs * sizeof(sweep::BRec));
-        reserve_tagged(pool.d_trec, recs * sizeof(sweep::TRec));
-        reserve_tagged(pool.d_misc, 1024);
+        if (pool.pass_id >= 3000) {  // tags wrap at 4095: start over with clean tagged buffers (nothing is in flight between pairs)
+            for (SweepSlot& sl : pool.slots)
+                for (DeviceBuf* b : {&sl.d_brec, &sl.d_trec, &sl.d_start, &sl.d_pring, &sl.d_misc})
+                    if (b->ptr && !hip_ok(hipMemsetAsync(b->ptr, 0, b->size, be.s), "memset")) hip_fail("memset");
+            pool.pass_id = 0;
+        }
+        for (int k = 0; k < 2; ++k)
+            if (!pool.d_merged[k].reserve(recs * sizeof(BlockRec))) hip_fail("merged records");
+        if (!hip_ok(hipMemsetD32Async((hipDeviceptr_t)pool.d_merged[0].ptr, (int)kNone, recs * sizeof(BlockRec) / 4, be.s), "memset merged")) hip_fail("merged records");
+        for (SweepSlot& sl : pool.slots) {
+            reserve_tagged(sl.d_brec, recs * sizeof(BRec), be.s);
+            reserve_tagged(sl.d_trec, recs * sizeof(TRec), be.s);
+            reserve_tagged(sl.d_misc, 1024, be.s);
+            sl.live = false;
+            sl.seq = 0;
+        }
         if (has_sh) {
             if (!pool.d_sh.reserve(((size_t)n + 1) * 4) ||
                 !hip_ok(hipMemcpyAsync(pool.d_sh.ptr, sh, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, be.s), "H2D sh"))
                 hip_fail("sh table");
         }
+        // the passes run on the slots' streams: everything set up on the pair's stream (profiles, codes, the above) is done first
+        if (!hip_ok(hipStreamSynchronize(be.s), "sync")) hip_fail("begin_pair");
     }
 
-    sweep::BlockRec read_old(int32_t k) {
-        if (k == 1) return old1;
+    sweep::BlockRec read_merged(int seq, int32_t k) {  // after wait_pass(seq)
         sweep::BlockRec r;
-        if (!hip_ok(hipMemcpyAsync(&r, pool.d_old.as<sweep::BlockRec>() + k, sizeof(r), hipMemcpyDeviceToHost, be.s), "D2H rec") ||
+        const int mb = seq == 0 ? 0 : slot_of(seq).mbuf;
+        if (!hip_ok(hipMemcpyAsync(&r, pool.d_merged[mb].as<sweep::BlockRec>() + k, sizeof(r), hipMemcpyDeviceToHost, be.s), "D2H rec") ||
             !hip_ok(hipStreamSynchronize(be.s), "sync"))
-            hip_fail("read_old");
+            hip_fail("read_merged");
         return r;
     }
-    void write_old(int32_t, const sweep::BlockRec&) {}  // the first column's record is only read by the host
 
-    uint64_t* misc_bprog() { return pool.d_misc.as<uint64_t>(); }
-    uint32_t* misc_ticket() { return pool.d_misc.as<uint32_t>() + 4; }
-    sweep::Status* misc_status() { return reinterpret_cast<sweep::Status*>(pool.d_misc.as<uint8_t>() + 64); }
-
-    sweep::Status run_pass(int32_t f_max, int32_t sparse_h, const sweep::PassInit& init) {
+    void launch_pass(int seq, int prev_seq, int32_t f_max, int32_t sparse_h, const sweep::PassInit& init) {
         using namespace sweep;
-        if (pool.pass_id >= 4000) {  // tags wrap: start over with clean tagged buffers
-            for (DeviceBuf* b : {&pool.d_brec, &pool.d_trec, &pool.d_start, &pool.d_pring})
-                if (b->ptr && !hip_ok(hipMemsetAsync(b->ptr, 0, b->size, be.s), "memset")) hip_fail("memset");
-            pool.pass_id = 0;
-        }
+        SweepSlot& sl = slot_of(seq);
+        if (sl.live) hip_fail("sweep slot busy");
+        SweepSlot* pv = prev_seq ? &slot_of(prev_seq) : nullptr;
         pool.pass_id += 1;
-        geo = pass_geometry(n, m, f_max);
-        const size_t slots = trace ? (size_t)nblk + 1 : (size_t)geo.col_ring;
+        sl.seq = seq;
+        sl.pass = pool.pass_id;
+        sl.mbuf = pv ? 1 - pv->mbuf : 1;  // (before any pass the merged records are d_merged[0])
+        sl.f_max = f_max;
+        sl.geo = pass_geometry(n, m, f_max);
+        const PassGeometry& geo = sl.geo;
+        const size_t nslots = trace ? (size_t)nblk + 1 : (size_t)geo.col_ring;
         const size_t gran_bytes = (size_t)geo.nstrips * (size_t)geo.gran_stride * 8;
-        const size_t col_bytes = slots * (size_t)geo.col_stride * 16;
+        const size_t col_bytes = nslots * (size_t)geo.col_stride * 16;
         const size_t pr_bytes = (size_t)geo.nstrips * (size_t)geo.pr_stride * 8;
-        if (gran_bytes + col_bytes + pr_bytes > (size_t)96 << 30) throw SweepFallback("sweep buffers too large", -3);
-        reserve_tagged(pool.d_start, (size_t)geo.nstrips * 8);
-        reserve_tagged(pool.d_pring, pr_bytes);
-        if (!pool.d_gran.reserve(gran_bytes) || !pool.d_col.reserve(col_bytes)) hip_fail("hipMalloc");
-        if (!hip_ok(hipMemsetAsync(pool.d_gran.ptr, 0, gran_bytes, be.s), "memset granules")) hip_fail("memset");
+        if (gran_bytes + col_bytes + pr_bytes > (size_t)40 << 30) throw SweepFallback("sweep buffers too large", -3);
+        reserve_tagged(sl.d_start, (size_t)geo.nstrips * 8, sl.s);
+        reserve_tagged(sl.d_pring, pr_bytes, sl.s);
+        if (!sl.d_gran.reserve(gran_bytes) || !sl.d_col.reserve(col_bytes)) hip_fail("hipMalloc");
+        if (!hip_ok(hipMemsetAsync(sl.d_gran.ptr, 0, gran_bytes, sl.s), "memset granules")) hip_fail("memset");
 
         InitArgs ia;
-        ia.brec = pool.d_brec.as<BRec>();
-        ia.trec = pool.d_trec.as<TRec>();
-        ia.bprog = misc_bprog();
-        ia.strip_start = pool.d_start.as<uint64_t>();
-        ia.status = misc_status();
-        ia.ticket = misc_ticket();
-        ia.pass = pool.pass_id;
+        ia.brec = sl.d_brec.as<BRec>();
+        ia.trec = sl.d_trec.as<TRec>();
+        ia.bprog = sl.bprog();
+        ia.strip_start = sl.d_start.as<uint64_t>();
+        ia.status = sl.status();
+        ia.ticket = sl.ticket();
+        ia.pass = sl.pass;
         ia.js1 = init.js1;
         ia.je1 = init.je1;
         ia.ojs1 = init.ojs1;
@@ -548,7 +624,7 @@ struct HipSweepLauncher {
         ia.fs0 = init.fs0;
         ia.last_strip = init.last_strip;
         ia.nstrips = geo.nstrips;
-        hipLaunchKernelGGL(sweep_init_kernel, dim3(1), dim3(64), 0, be.s, ia);
+        hipLaunchKernelGGL(sweep_init_kernel, dim3(1), dim3(64), 0, sl.s, ia);
 
         Ctx c;
         c.a_codes = be.d_codes.as<uint32_t>();
@@ -558,84 +634,92 @@ struct HipSweepLauncher {
         c.nblk = nblk;
         c.wtot = geo.wtot;
         c.f_max = f_max;
-        c.pass = pool.pass_id;
+        c.pass = sl.pass;
         c.heur = heur_kind;
         c.sparse_h = sparse_h;
         c.sh_h = has_sh ? pool.d_sh.as<int32_t>() : nullptr;
         c.store_cols = trace ? 1 : 0;
-        c.d_old = pool.d_old.as<BlockRec>();
-        c.brec = pool.d_brec.as<BRec>();
-        c.trec = pool.d_trec.as<TRec>();
-        c.bprog = misc_bprog();
-        c.strip_start = pool.d_start.as<uint64_t>();
-        c.pring = pool.d_pring.as<uint64_t>();
+        c.d_old = pool.d_merged[1 - sl.mbuf].as<BlockRec>();
+        c.prev_brec = pv ? pv->d_brec.as<BRec>() : nullptr;
+        c.prev_pass = pv ? pv->pass : 0;
+        c.prev_done = pv ? pv->done() : sl.done();
+        c.cancel = sl.cancel();
+        c.brec = sl.d_brec.as<BRec>();
+        c.trec = sl.d_trec.as<TRec>();
+        c.bprog = sl.bprog();
+        c.strip_start = sl.d_start.as<uint64_t>();
+        c.pring = sl.d_pring.as<uint64_t>();
         c.pr_stride = geo.pr_stride;
-        c.gran = pool.d_gran.as<uint64_t>();
+        c.gran = sl.d_gran.as<uint64_t>();
         c.gran_stride = geo.gran_stride;
         c.win = geo.win;
-        c.col = pool.d_col.as<uint64_t>();
+        c.col = sl.d_col.as<uint64_t>();
         c.col_stride = geo.col_stride;
         c.col_ring = geo.col_ring;
-        c.status = misc_status();
-        c.ticket = misc_ticket();
+        c.status = sl.status();
+        c.ticket = sl.ticket();
         c.nstrips = geo.nstrips;
-        // wavefronts: one per strip the band can cover at a time (+ slack), one workgroup each; at most one per SIMD
-        int64_t waves = (2ll * geo.win) / kStripRows + 6;
-        if (waves > geo.nstrips) waves = geo.nstrips;
-        if (waves > 1024) waves = 1024;
-        c.nwaves = (int32_t)waves;
+        c.nwaves = pass_waves(f_max);
+        sl.waves = c.nwaves;
         c.spin_limit = 1u << 19;  // ~2 s of backed-off polls
         c.timing = nullptr;
         if (timing_on()) {
-            c.timing = pool.d_misc.as<uint64_t>() + 64;  // bytes 512..575 of d_misc
-            (void)hipMemsetAsync(c.timing, 0, 64, be.s);
+            c.timing = sl.d_misc.as<uint64_t>() + 64;  // bytes 512..575 of d_misc
+            (void)hipMemsetAsync(c.timing, 0, 64, sl.s);
+            sl.t_launch = engine::now_s();
         }
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool timing = timing_on();
-        if (timing) {
-            (void)hipEventCreate(&e0);
-            (void)hipEventCreate(&e1);
-            (void)hipEventRecord(e0, be.s);
-        }
-        hipLaunchKernelGGL(sweep_kernel, dim3((unsigned)c.nwaves), dim3(64), 0, be.s, c);
-        if (timing) (void)hipEventRecord(e1, be.s);
-        hipLaunchKernelGGL(sweep_commit_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, be.s, pool.d_brec.as<BRec>(), pool.d_old.as<BlockRec>(),
-                           misc_status(), nblk);
-        Status* hs = static_cast<Status*>(pool.pinned(sizeof(Status)));
-        if (!hs) hip_fail("pinned");
-        if (!hip_ok(hipGetLastError(), "sweep launch") ||
-            !hip_ok(hipMemcpyAsync(hs, misc_status(), sizeof(Status), hipMemcpyDeviceToHost, be.s), "D2H status") ||
-            !hip_ok(hipStreamSynchronize(be.s), "sync"))
+        hipLaunchKernelGGL(sweep_kernel, dim3((unsigned)c.nwaves), dim3(64), 0, sl.s, c);
+        // behind the pass: merge its records into the older ones (after the previous pass's merge), then the done word
+        if (pv && !hip_ok(hipStreamWaitEvent(sl.s, pv->merged_ev, 0), "hipStreamWaitEvent")) hip_fail("event");
+        hipLaunchKernelGGL(sweep_merge_kernel, dim3((unsigned)((nblk + 2 + 255) / 256)), dim3(256), 0, sl.s, sl.d_brec.as<BRec>(),
+                           pool.d_merged[1 - sl.mbuf].as<BlockRec>(), pool.d_merged[sl.mbuf].as<BlockRec>(), sl.status(), nblk);
+        hipLaunchKernelGGL(sweep_done_kernel, dim3(1), dim3(1), 0, sl.s, sl.done(), sl.pass);
+        if (!hip_ok(hipEventRecord(sl.merged_ev, sl.s), "hipEventRecord") || !hip_ok(hipGetLastError(), "sweep launch") ||
+            !hip_ok(hipMemcpyAsync(sl.h_status, sl.status(), sizeof(Status), hipMemcpyDeviceToHost, sl.s), "D2H status"))
             hip_fail("sweep pass");
-        if (timing) {
-            float ms = 0;
-            (void)hipEventElapsedTime(&ms, e0, e1);
-            kernel_ms += ms;
+        sl.live = true;
+    }
+
+    sweep::Status wait_pass(int seq) {
+        SweepSlot& sl = slot_of(seq);
+        if (sl.seq != seq) hip_fail("sweep slot lost");
+        if (!hip_ok(hipStreamSynchronize(sl.s), "sync")) hip_fail("sweep pass");
+        sl.live = false;
+        const sweep::Status st = *sl.h_status;
+        if (timing_on()) {
             uint64_t tm[8] = {0};
-            (void)hipMemcpy(tm, c.timing, 64, hipMemcpyDeviceToHost);
-            std::fprintf(stderr, "sweep pass %u: f_max=%d waves=%d state=%u value=%d k_end=%d kernel %.3f ms | strip-us: begin %.0f slow %.0f cross %.0f end %.0f bottom %.0f plain %.0f gran %.0f\n",
-                         pool.pass_id, f_max, c.nwaves, hs->state, hs->value, hs->k_end, ms, tm[0] * 0.01, tm[1] * 0.01, tm[6] * 0.01, tm[2] * 0.01, tm[3] * 0.01, tm[4] * 0.01,
-                         tm[5] * 0.01);
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
-        }
-        const Status st = *hs;
-        if ((st.state == kStDone || st.state == kStNoPath) && st.k_end >= 1) {  // block 1's committed record, as the host needs it next pass
-            old1.js = init.js1;
-            old1.je = init.je1;
-            old1.ojs = init.ojs1;
-            old1.oje = init.oje1;
+            (void)hipMemcpy(tm, sl.d_misc.as<uint64_t>() + 64, 64, hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "sweep pass %u (seq %d): f_max=%d waves=%d state=%u value=%d k_end=%d  %.3f ms after its launch | strip-us: begin %.0f slow %.0f cross %.0f end %.0f bottom %.0f plain %.0f gran %.0f\n",
+                         sl.pass, seq, sl.f_max, sl.waves, st.state, st.value, st.k_end, (engine::now_s() - sl.t_launch) * 1e3, tm[0] * 0.01, tm[1] * 0.01,
+                         tm[6] * 0.01, tm[2] * 0.01, tm[3] * 0.01, tm[4] * 0.01, tm[5] * 0.01);
         }
         return st;
     }
-    void commit(int32_t, int32_t) {}  // done on the device right behind the pass (sweep_commit_kernel)
+
+    // Give up every launched pass behind `seq` and wait until they (and their merges) are gone.
+    void cancel_after(int seq) {
+        bool any = false;
+        for (SweepSlot& sl : pool.slots)
+            if (sl.live && sl.seq > seq) {
+                any = hip_ok(hipMemsetD32Async((hipDeviceptr_t)sl.cancel(), (int)sl.pass, 1, pool.ctl), "cancel") || any;
+            }
+        if (!any) return;
+        (void)hipStreamSynchronize(pool.ctl);
+        for (int q = seq + 1; q <= seq + SweepPool::kSlots; ++q) {  // in launch order
+            SweepSlot& sl = slot_of(q);
+            if (!sl.live || sl.seq <= seq) continue;
+            (void)hipStreamSynchronize(sl.s);
+            sl.live = false;
+        }
+    }
 
     // The blocks of the pass that just succeeded, for Blocks::trace.
-    void read_blocks(std::vector<engine::Block>& blocks) {
+    void read_blocks(int seq, std::vector<engine::Block>& blocks) {
         using namespace sweep;
+        SweepSlot& sl = slot_of(seq);
         const size_t recs = (size_t)nblk + 1;
         if (!pool.d_recs.reserve(recs * sizeof(BlockOut)) || !pool.d_offs.reserve(recs * 8)) hip_fail("hipMalloc");
-        hipLaunchKernelGGL(sweep_records_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, be.s, pool.d_brec.as<BRec>(),
+        hipLaunchKernelGGL(sweep_records_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, be.s, sl.d_brec.as<BRec>(),
                            pool.d_recs.as<BlockOut>(), nblk);
         std::vector<BlockOut> hr(recs);
         if (!hip_ok(hipMemcpyAsync(hr.data(), pool.d_recs.ptr, recs * sizeof(BlockOut), hipMemcpyDeviceToHost, be.s), "D2H records") ||
@@ -651,7 +735,7 @@ struct HipSweepLauncher {
         uint64_t* hp = static_cast<uint64_t*>(pool.pinned((size_t)total * 16 + 16));
         if (!hp) hip_fail("pinned");
         if (!hip_ok(hipMemcpyAsync(pool.d_offs.ptr, offs.data(), recs * 8, hipMemcpyHostToDevice, be.s), "H2D offsets")) hip_fail("offsets");
-        hipLaunchKernelGGL(sweep_gather_kernel, dim3((unsigned)nblk), dim3(256), 0, be.s, pool.d_col.as<uint64_t>(), geo.col_stride, geo.win,
+        hipLaunchKernelGGL(sweep_gather_kernel, dim3((unsigned)nblk), dim3(256), 0, be.s, sl.d_col.as<uint64_t>(), sl.geo.col_stride, sl.geo.win,
                            pool.d_recs.as<BlockOut>(), pool.d_offs.as<int64_t>(), pool.d_pack.as<uint64_t>(), nblk);
         if (!hip_ok(hipMemcpyAsync(hp, pool.d_pack.ptr, (size_t)total * 16, hipMemcpyDeviceToHost, be.s), "D2H columns") ||
             !hip_ok(hipStreamSynchronize(be.s), "sync"))
@@ -673,6 +757,10 @@ struct HipSweepLauncher {
         }
     }
 };
+
+// Runs when the library is loaded: more hardware queues for the pipelined passes (no effect if the application has set the
+// variable itself or has started the HIP runtime already).
+__attribute__((constructor)) static void pa_sweep_runtime_hints() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 // The engine's bookkeeping without any kernel work (used where the numbers come from a fused GPU pass).
 struct StatsOnlyBackend {

@@ -71,6 +71,15 @@ struct PassInit {
     int32_t last_strip;                    // strips 0..last_strip start at block 1
 };
 
+// A Launcher provides device memory and the passes of ONE pair, numbered seq = 1, 2, ...:
+//   begin_pair(n, m, nblk, sh table or nullptr, trace)
+//   launch_pass(seq, prev_seq, f_max, sparse_h, init)   start pass seq (asynchronous); it reads pass prev_seq's records while that
+//                                             runs, its merged records afterwards (prev_seq 0: no earlier pass)
+//   wait_pass(seq) -> Status                  block until pass seq is over and merged (passes are waited for in order)
+//   cancel_after(seq)                         give up every launched pass > seq and wait until they are gone
+//   read_merged(seq, k) -> BlockRec           block k's record after pass seq was merged (waited)
+//   read_blocks(seq, blocks)                  the blocks of pass seq for Blocks::trace
+//   pass_waves(f_max), wave_budget()          wavefronts a pass occupies / may be in flight together
 template <class Backend, class Launcher>
 class SweepAligner {
    public:
@@ -84,11 +93,33 @@ class SweepAligner {
     engine::AstarPa2Stats stats;
     bool trace;
     int32_t n, m, nblk;
-    int32_t last_block_idx = 0;  // Blocks::last_block_idx as the previous pass left it (domain.rs:395-404 reads through it)
-    BlockRec rec0;               // the first column as the previous pass left it
-    bool have_rec0 = false;
-    int64_t blocks_len = 0;      // Blocks::blocks.len()
     std::optional<engine::Cigar> cigar;
+
+    // What the reference keeps between align_for_bounded_dist calls, as far as the first column and block 1 look at it.
+    struct Carry {
+        int32_t last_block_idx = 0;  // Blocks::last_block_idx as the previous pass left it (domain.rs:395-404 reads through it)
+        int64_t blocks_len = 0;      // Blocks::blocks.len()
+        BlockRec rec0;               // the first column as the previous pass left it
+        bool have_rec0 = false;
+        BlockRec old1;               // block 1 as the previous passes left it (js == kNone: none)
+        int seq = 0;                 // the last device pass of the chain (0: none)
+        Carry() { old1.js = kNone; }
+    };
+    Carry carry;
+    int seq_counter = 0;  // device passes launched so far (given up or not)
+
+    // A pass up to its launch: the first column and block 1 need no DP (domain.rs:395-413, blocks.rs:146-179).
+    struct Prepared {
+        Cost f_max = 0;
+        bool early_none = false;  // no path for this bound before any block is computed
+        bool rec0_set = false;    // the first column was (re)initialised before the pass gave up
+        BlockRec r0;
+        PassInit init;
+        NextDecision nd;
+        int seq = 0;
+        double t0 = 0;
+        Carry after_launch;       // the carry the NEXT pass is prepared from while this one still runs (see speculate())
+    };
 
     SweepAligner(const engine::AstarPa2Params& p, Backend& backend, Launcher& launcher, bool trace_)
         : params(p), be(backend), dev(launcher), trace(trace_) {
@@ -111,89 +142,219 @@ class SweepAligner {
 
     Cost h0() const { return heur_h(hp, 0, 0); }
 
-    // One pass.  nullopt = no path for this bound (domain.rs returns None).
-    std::optional<std::pair<Cost, std::optional<engine::Cigar>>> pass(Cost f_max) {
-        stats.f_max_tries += 1;
+    // The host part of a pass before the launch, from the carry `c` (the real one, or the one assumed while the previous pass
+    // still runs).  `stale` = the block after the previous pass's last one, as `blocks.next_block_j_range()` sees it before init().
+    Prepared prepare(Cost f_max, const Carry& c, const BlockRec& stale) const {
+        Prepared p;
+        p.f_max = f_max;
         if (f_max < 0) engine::engine_panic("f_max >= 0");
-        // ---- first column (domain.rs:395-413, blocks.rs:146-179) ----
-        BlockRec stale;  // `blocks.next_block_j_range()` before init(): the block after the previous pass's last one
-        stale.js = kNone;
-        if ((int64_t)last_block_idx + 1 < blocks_len) stale = dev.read_old(last_block_idx + 1);
         JRangeOut jr0;
-        if (!next_j_range(hp, -1, 0, -1, -1, 0, f_max, params.sparse_h ? 1 : 0, stale.js, stale.je, &jr0) || jr0.ojs > 0) return std::nullopt;
+        if (!next_j_range(hp, -1, 0, -1, -1, 0, f_max, params.sparse_h ? 1 : 0, stale.js, stale.je, &jr0) || jr0.ojs > 0) {
+            p.early_none = true;
+            return p;
+        }
         BlockRec r0;
         r0.ojs = jr0.ojs;
         r0.oje = jr0.oje;
         r0.js = 0;
         r0.je = jr0.je;
-        if (have_rec0 && rec0.je > r0.je) r0.je = rec0.je;  // initial_j_range.union(blocks[0].j_range), rounded
+        if (c.have_rec0 && c.rec0.je > r0.je) r0.je = c.rec0.je;  // initial_j_range.union(blocks[0].j_range), rounded
         r0.fs = jr0.ojs;
         r0.fe = jr0.oje;
         r0.top_val = 0;
         r0.bot_val = r0.je;
-        rec0 = r0;
-        have_rec0 = true;
-        if (blocks_len < 1) blocks_len = 1;
-        last_block_idx = 0;
-        dev.write_old(0, r0);
+        p.r0 = r0;
+        p.rec0_set = true;
         // ---- block 1 from the first column: index_0(j) = j ----
         BlockRec old1;
         old1.js = kNone;
-        if (blocks_len > 1) old1 = dev.read_old(1);
-        const NextDecision nd = decide_next(hp, f_max, params.sparse_h ? 1 : 0, 0, n < kBlockW ? n : kBlockW, r0.fs, r0.fe, r0.fe, old1, true);
-        if (!nd.ok) {
+        if (c.blocks_len > 1) old1 = c.old1;
+        p.nd = decide_next(hp, f_max, params.sparse_h ? 1 : 0, 0, n < kBlockW ? n : kBlockW, r0.fs, r0.fe, r0.fe, old1, true);
+        if (!p.nd.ok) {
             if (old1.js != kNone) engine::engine_panic("empty j_range with existing next block");
-            return std::nullopt;
+            p.early_none = true;
+            return p;
         }
-        stats.block_stats.num_blocks += nd.d_num_blocks;
-        stats.block_stats.unique_lanes += nd.d_unique_add - nd.d_unique_sub;
-        stats.block_stats.computed_lanes += nd.d_computed;
-        stats.block_stats.num_incremental_blocks += nd.d_incremental;
-        PassInit init;
-        init.js1 = nd.jr.js;
-        init.je1 = nd.jr.je;
-        init.ojs1 = nd.jr.ojs;
-        init.oje1 = nd.jr.oje;
-        init.flags1 = nd.flags;
-        init.top1 = nd.jr.js + (n < kBlockW ? n : kBlockW);
-        init.fs0 = r0.fs;
+        p.init.js1 = p.nd.jr.js;
+        p.init.je1 = p.nd.jr.je;
+        p.init.ojs1 = p.nd.jr.ojs;
+        p.init.oje1 = p.nd.jr.oje;
+        p.init.flags1 = p.nd.flags;
+        p.init.top1 = p.nd.jr.js + (n < kBlockW ? n : kBlockW);
+        p.init.fs0 = r0.fs;
         const int32_t mrows = ((m + 63) / 64) * 64;
-        init.last_strip = ((nd.jr.je < mrows ? nd.jr.je : mrows) - 1) / kStripRows;
-        if (init.last_strip < 0) init.last_strip = 0;
-        // ---- the pass ----
-        const double t0 = engine::now_s();
-        const Status st = dev.run_pass(f_max, params.sparse_h ? 1 : 0, init);
-        stats.block_stats.t_compute += engine::now_s() - t0;
+        p.init.last_strip = ((p.nd.jr.je < mrows ? p.nd.jr.je : mrows) - 1) / kStripRows;
+        if (p.init.last_strip < 0) p.init.last_strip = 0;
+        return p;
+    }
+    BlockRec stale_of(const Carry& c) {  // needs the previous pass merged
+        BlockRec stale;
+        stale.js = kNone;
+        if ((int64_t)c.last_block_idx + 1 < c.blocks_len) stale = c.last_block_idx + 1 == 1 ? c.old1 : dev.read_merged(c.seq, c.last_block_idx + 1);
+        return stale;
+    }
+    // The carry after `p` as far as it is known at launch time.
+    void apply_prepared(Carry& c, const Prepared& p) const {
+        if (p.rec0_set) {
+            c.rec0 = p.r0;
+            c.have_rec0 = true;
+            if (c.blocks_len < 1) c.blocks_len = 1;
+            c.last_block_idx = 0;
+        }
+    }
+    void launch(Prepared& p, int prev_seq) {
+        seq_counter += 1;
+        p.seq = seq_counter;
+        p.t0 = engine::now_s();
+        dev.launch_pass(p.seq, prev_seq, p.f_max, params.sparse_h ? 1 : 0, p.init);
+    }
+    // The rest of the pass once its status is known (in pass order).  nullopt = no path for this bound (domain.rs returns None).
+    std::optional<std::pair<Cost, std::optional<engine::Cigar>>> complete(const Prepared& p, const Status& st) {
+        stats.block_stats.num_blocks += p.nd.d_num_blocks;
+        stats.block_stats.unique_lanes += p.nd.d_unique_add - p.nd.d_unique_sub;
+        stats.block_stats.computed_lanes += p.nd.d_computed;
+        stats.block_stats.num_incremental_blocks += p.nd.d_incremental;
+        stats.block_stats.t_compute += engine::now_s() - p.t0;
         if (st.state == kStAbort || st.state == kStTimeout || st.state == kStRunning)
             throw SweepFallback(st.state == kStAbort ? "sweep pass aborted" : "sweep pass timed out", st.state == kStAbort ? st.value : -1);
         stats.block_stats.num_blocks += st.stats.num_blocks;
         stats.block_stats.unique_lanes += st.stats.unique_lanes;
         stats.block_stats.computed_lanes += st.stats.computed_lanes;
         stats.block_stats.num_incremental_blocks += st.stats.num_incremental_blocks;
-        dev.commit(st.k_end, st.k_fixed);
-        last_block_idx = st.k_end;
-        if ((int64_t)st.k_end + 1 > blocks_len) blocks_len = (int64_t)st.k_end + 1;
+        carry.seq = p.seq;
+        carry.last_block_idx = st.k_end;
+        if ((int64_t)st.k_end + 1 > carry.blocks_len) carry.blocks_len = (int64_t)st.k_end + 1;
+        if (st.k_end >= 1) {  // block 1's merged record, as the host needs it next pass
+            carry.old1.js = p.init.js1;
+            carry.old1.je = p.init.je1;
+            carry.old1.ojs = p.init.ojs1;
+            carry.old1.oje = p.init.oje1;
+        }
         if (st.state == kStNoPath) return std::nullopt;
         const Cost dist = st.value;
-        if (trace && dist <= f_max) {
-            cigar = do_trace(r0);
+        if (trace && dist <= p.f_max) {
+            cigar = do_trace(p);
             return std::make_pair(dist, std::optional<engine::Cigar>(*cigar));
         }
         return std::make_pair(dist, std::optional<engine::Cigar>());
     }
 
     // Blocks::trace (blocks/trace.rs:21-135) over the blocks of the pass that just succeeded.
-    engine::Cigar do_trace(const BlockRec& r0) {
+    engine::Cigar do_trace(const Prepared& p) {
         using namespace engine;
         Blocks<Backend> blocks(params.front, true, be);
         blocks.blocks.resize((size_t)nblk + 1);
-        blocks.blocks[0] = Block::first_col(JRange{r0.ojs, r0.oje}, JRange{r0.js, r0.je});
-        dev.read_blocks(blocks.blocks);
+        blocks.blocks[0] = Block::first_col(JRange{p.r0.ojs, p.r0.oje}, JRange{p.r0.js, p.r0.je});
+        dev.read_blocks(p.seq, blocks.blocks);
         blocks.last_block_idx = (size_t)nblk;
         blocks.i_range = IRange{-1, n};
         auto [cg, ts] = blocks.trace(0, 0, n, m);
         stats.trace_stats = ts;
         return cg;
+    }
+
+    // The band search (band.rs:100-182, engine.hpp band_search) with the passes PIPELINED: while the pass for bound s runs, the
+    // passes for next_s(s), next_s(next_s(s)), ... are prepared and launched under the assumptions that (a) the pass before
+    // them finds no path or a cost above its bound that does not cap the next bound, and (b) it gets at least as far as every
+    // pass before it, so that no stale block record reaches the first column (the quirk of domain.rs:395-404).  Both hold for
+    // a band that grows with the bound; when the finished pass says otherwise the passes launched after it are given up and
+    // the search goes on from the real state.  A pass that succeeds likewise gives up the ones behind it.
+    struct InFlight {
+        Prepared p;
+        int waves;
+    };
+    std::pair<Cost, std::optional<engine::Cigar>> search(Cost first_s, const std::function<Cost(Cost)>& next_s) {
+        static const bool no_pipe = std::getenv("PA_SWEEP_NO_PIPELINE") != nullptr;
+        std::vector<InFlight> fl;  // launched, oldest first
+        size_t head = 0;
+        int waves_in_flight = 0;
+        Carry spec;                // the carry after the newest launched pass, as assumed
+        Cost last_s = -1, s = first_s, maxs = engine::COST_MAX;
+        auto give_up = [&]() {  // every launched pass behind the head's predecessor
+            if (head < fl.size()) dev.cancel_after(fl[head].p.seq - 1);
+            fl.resize(head);
+            waves_in_flight = 0;
+        };
+        for (;;) {
+            std::optional<std::pair<Cost, std::optional<engine::Cigar>>> r;
+            stats.f_max_tries += 1;
+            if (head == fl.size()) {  // nothing launched for this bound: prepare it from the real state
+                Prepared p = prepare(s, carry, stale_of(carry));
+                apply_prepared(carry, p);
+                if (!p.early_none) {
+                    launch(p, carry.seq);
+                    fl.push_back(InFlight{p, dev.pass_waves(s)});
+                    waves_in_flight = fl.back().waves;
+                    spec = carry;
+                    spec.blocks_len = spec.blocks_len < 2 ? 2 : spec.blocks_len;  // the pass reaches block 1 at least
+                    spec.old1.js = p.init.js1;
+                    spec.old1.je = p.init.je1;
+                    spec.old1.ojs = p.init.ojs1;
+                    spec.old1.oje = p.init.oje1;
+                    spec.seq = p.seq;
+                }
+            }
+            if (head < fl.size()) {
+                // look ahead while there is room on the chip
+                if (!no_pipe) {
+                    Cost sa = fl.back().p.f_max;
+                    while ((int)(fl.size() - head) < dev.max_in_flight()) {
+                        const Cost sn = next_s(sa);
+                        if (sn <= sa) break;
+                        const int w = dev.pass_waves(sn);
+                        if (waves_in_flight + w > dev.wave_budget()) break;
+                        BlockRec none;
+                        none.js = kNone;
+                        Prepared q = prepare(sn, spec, none);  // assumption (b): nothing stale
+                        if (q.early_none) break;               // (decided again from the real state when its turn comes)
+                        apply_prepared(spec, q);
+                        launch(q, spec.seq);
+                        fl.push_back(InFlight{q, w});
+                        waves_in_flight += w;
+                        spec.old1.js = q.init.js1;
+                        spec.old1.je = q.init.je1;
+                        spec.old1.ojs = q.init.ojs1;
+                        spec.old1.oje = q.init.oje1;
+                        spec.seq = q.seq;
+                        sa = sn;
+                    }
+                }
+                const InFlight cur = fl[head];
+                head += 1;
+                const int64_t len_before = carry.blocks_len;
+                apply_prepared(carry, cur.p);
+                Status st;
+                try {
+                    st = dev.wait_pass(cur.p.seq);
+                    if (st.state == kStDone && st.value <= cur.p.f_max) give_up();  // found: the passes behind it are not needed
+                    r = complete(cur.p, st);
+                } catch (...) {
+                    give_up();
+                    throw;
+                }
+                waves_in_flight -= cur.waves;
+                // assumption (b) for the passes launched behind this one
+                if (head < fl.size() && (int64_t)st.k_end + 1 < (len_before > 2 ? len_before : 2)) give_up();
+            }
+            // ---- band.rs:100-182 ----
+            if (r) {
+                const Cost cost = r->first;
+                if (cost > maxs) stats.sanity_violations += 1;  // band.rs:118-121
+                if (cost <= s) {
+                    if (cost <= last_s) stats.sanity_violations += 1;  // band.rs:123-126
+                    give_up();
+                    return *r;
+                }
+                maxs = std::min(maxs, cost);
+            } else if (maxs != engine::COST_MAX) {
+                stats.sanity_violations += 1;  // band.rs:132-135
+            }
+            const Cost prev = s;
+            last_s = s;
+            s = std::min(next_s(s), maxs);
+            if (s <= prev) s = next_s(prev);  // never stall (the reference's "potential infinite loop" TODO, band.rs:110)
+            if (head < fl.size() && fl[head].p.f_max != s) give_up();  // assumption (a)
+        }
     }
 
     // lib.rs:122-175
@@ -208,18 +369,15 @@ class SweepAligner {
             start_f = h_0;
             start_inc = 1;
         }
-        auto f = [&](Cost s) { return pass(s); };
         std::pair<Cost, std::optional<Cigar>> r;
         if (params.doubling == DoublingKind::LinearSearch) {
             const Cost delta = (Cost)params.delta;
-            r = band_search(start_f, [delta](Cost s) { return s + delta; }, f, &stats.sanity_violations);
+            r = search(start_f, [delta](Cost s) { return s + delta; });
         } else {
             start_inc = std::max(start_inc, params.block_width);  // lib.rs:142
             const float factor = params.factor;
             const Cost offset = start_f;
-            r = band_search(offset + start_inc,
-                            [factor, offset](Cost s) { return std::max((Cost)std::ceil(factor * (float)(s - offset)), 1) + offset; }, f,
-                            &stats.sanity_violations);
+            r = search(offset + start_inc, [factor, offset](Cost s) { return std::max((Cost)std::ceil(factor * (float)(s - offset)), 1) + offset; });
         }
         PA_ASSERT(h_0 <= r.first, "Heuristic at start > final cost");
         out.cost = r.first;

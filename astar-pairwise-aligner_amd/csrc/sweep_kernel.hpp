@@ -109,9 +109,11 @@ struct DeviceWave {
         lo = (uint32_t)w;
         hi = (uint32_t)(w >> 32);
     }
-    static __device__ __forceinline__ void load_i32s(const int32_t* p, int n, vec& v) {  // read-only data of earlier launches
+    // the merged records: written by the merge kernel of the previous pass, possibly while this launch is already running
+    // (pipelined passes) -- agent-scope loads, never the CU's L1
+    static __device__ __forceinline__ void load_i32s(const int32_t* p, int n, vec& v) {
         const uint32_t l = threadIdx.x & 63u;
-        v = (uint32_t)((const PA_GLOBAL int32_t*)p)[l < (uint32_t)n ? l : (uint32_t)(n - 1)];
+        v = (uint32_t)__hip_atomic_load((const PA_GLOBAL int32_t*)p + (l < (uint32_t)n ? l : (uint32_t)(n - 1)), PA_RLX_AGENT);
     }
     static __device__ __forceinline__ void load_codes2(const uint32_t* codes, int32_t q, uint32_t& lo, uint32_t& hi) {
         typedef const __attribute__((address_space(4))) uint32_t* ccu32;  // scalar loads (s_load, lgkmcnt)
@@ -229,9 +231,12 @@ struct DeviceWave {
                                                               int32_t j1) {
         uint32_t k40 = 0x40000000u, k80 = 0x80000000u;
         asm volatile("" : "+v"(k40), "+v"(k80));
-        const uint32_t rel = lane - (uint32_t)cl0;
-        const uint32_t relr = resetm != 0 ? rel : 0xFFFFFFFFu;
-        const uint32_t relf = fpend != 0 ? rel : 0xFFFFFFFFu;
+        uint32_t rel = lane - (uint32_t)cl0;
+        uint32_t relr = resetm != 0 ? rel : 0xFFFFFFFFu;
+        uint32_t relf = fpend != 0 ? rel : 0xFFFFFFFFu;
+        // opaque: else the 96 lane compares below are hoisted out of the caller's loop as loop invariants -- 192 scalar registers
+        // of masks, spilled lane by lane at every entry
+        asm volatile("" : "+v"(rel), "+v"(relr), "+v"(relf));
 #define PA_XSTEP(J)                                                                                                  \
     case J: {                                                                                                        \
         if (J >= j1) break;                                                                                          \
@@ -299,26 +304,31 @@ __global__ __launch_bounds__(64) void sweep_init_kernel(InitArgs a) {
 
 __global__ __launch_bounds__(64) void sweep_kernel(Ctx c) { wave_main<DeviceWave>(c); }
 
-// After a pass: the block records of the blocks the pass reached become the "older pass" records of the next one
-// (Blocks::blocks persists across align_for_bounded_dist calls, lib.rs:140-158; a failed block keeps its old fixed range).
-__global__ void sweep_commit_kernel(const BRec* brec, BlockRec* d_old, const Status* status, int32_t nblk) {
-    const int32_t k = 1 + (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
-    const int32_t k_end = status->k_end, k_fixed = status->k_fixed;
-    if (status->state != kStDone && status->state != kStNoPath) return;
-    if (k > nblk || k > k_end) return;
-    const BRec& s = brec[k];
-    BlockRec& d = d_old[k];
-    d.js = tw_val(s.js);
-    d.je = tw_val(s.je);
-    d.ojs = tw_val(s.ojs);
-    d.oje = tw_val(s.oje);
-    if (k <= k_fixed) {
-        d.fs = tw_val(s.fs);
-        d.fe = tw_val(s.fe);
-        d.top_val = tw_val(s.top_val);
-        d.bot_val = tw_val(s.bot_val);
+// After a pass: merged_new = the older passes' records with this pass's on top (Blocks::blocks persists across
+// align_for_bounded_dist calls, lib.rs:140-158; a block the pass did not reach, or did not fix, keeps its older record).  A pass
+// that did not end by itself (aborted, cancelled) merges nothing.  The two merged arrays alternate from pass to pass.
+__global__ void sweep_merge_kernel(const BRec* brec, const BlockRec* merged_old, BlockRec* merged_new, const Status* status, int32_t nblk) {
+    const int32_t k = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (k > nblk + 1) return;
+    BlockRec d = merged_old[k];
+    const bool ended = status->state == kStDone || status->state == kStNoPath;
+    if (ended && k >= 1 && k <= nblk && k <= status->k_end) {
+        const BRec& s = brec[k];
+        d.js = tw_val(s.js);
+        d.je = tw_val(s.je);
+        d.ojs = tw_val(s.ojs);
+        d.oje = tw_val(s.oje);
+        if (k <= status->k_fixed) {
+            d.fs = tw_val(s.fs);
+            d.fe = tw_val(s.fe);
+            d.top_val = tw_val(s.top_val);
+            d.bot_val = tw_val(s.bot_val);
+        }
     }
+    merged_new[k] = d;
 }
+// ... and only then (stream order) the word the next pass polls
+__global__ void sweep_done_kernel(uint64_t* done, uint32_t pass) { *done = pass; }
 
 // Traceback: gather the blocks' columns (window-addressed, see col_base_word) into one packed buffer, and the fields of
 // the block records the host needs.

@@ -68,7 +68,15 @@ struct Ctx {
     const int32_t* sh_h;
     int32_t store_cols;       // 1: keep every block's column (traceback); 0: ring of col_ring blocks
     // state
-    const BlockRec* d_old;    // [nblk + 2], merged result of the earlier passes
+    const BlockRec* d_old;    // [nblk + 2], merged result of the earlier passes (valid once the previous pass is over: *prev_done)
+    // Passes of one band search run PIPELINED: the pass with the next f_max is launched while this one runs and follows one or two
+    // blocks behind.  What a pass needs from its predecessor is tiny -- the fixed range of block kc and the range of block kc + 1
+    // (the unions of domain.rs:181-183, 332-341; blocks.rs:190-197) -- and the predecessor's bottom-edge records ARE that, as
+    // self-validating words: read them while the predecessor runs, the merged array once it is over.
+    const BRec* prev_brec;    // the previous pass's records (nullptr: no previous pass, or it is over: use d_old)
+    uint32_t prev_pass;       // its pass id (tags)
+    const uint64_t* prev_done;  // *prev_done == prev_pass once it is over and d_old holds its merged records
+    const uint64_t* cancel;   // *cancel == pass: the host gave this pass up (a pass before it succeeded)
     BRec* brec;               // [nblk + 2]
     TRec* trec;               // [nblk + 2]
     uint64_t* bprog;          // one word: {tag(pass, k) | oje_k} of the last decided block
@@ -159,7 +167,7 @@ struct StripProg {
     }
 
     // ---- status ------------------------------------------------------------------------------------------------------
-    PA_HD bool pass_over() { return W::load_u32(&c.status->state) != kStRunning; }
+    PA_HD bool pass_over() { return W::load_u32(&c.status->state) != kStRunning || W::load_u64(c.cancel) == (uint64_t)c.pass; }
     // The end of the pass as this strip sees it: recorded here, written to the status block once, by wave_main (this is
     // inlined at every wait and every consistency check: it must be a handful of scalar moves, the kernel has to fit the
     // instruction cache).
@@ -400,6 +408,10 @@ struct StripProg {
     // there yet.
     vec brv_lo, brv_hi;  // BRec[kc], lane l = word l (kept for the bottom-edge logic)
     vec oldv;            // d_old[kc], d_old[kc + 1] as 16 ints
+    vec pbv_lo, pbv_hi, pnv_lo, pnv_hi, pdn_lo, pdn_hi;  // the previous pass's BRec[kc], BRec[kc + 1] and its done word
+    flag_t prev_over;    // the older records come from d_old (no previous pass, or it is over and merged)
+    flag_t old_prev;     // this boundary's older records are the previous pass's own (pbv / pnv)
+    flag_t pfo_valid;    // pbv / pnv / pdn (or oldv) were fetched a chunk ahead
     vec pfb_st, pfb_bp_lo, pfb_bp_hi, pfb_tr_lo, pfb_tr_hi;  // the same loads issued one chunk ahead of the boundary (in flight
     flag_t pfb_valid;                                        // during the chunk; the boundary only waits if something is missing)
     vec pfp_lo, pfp_hi;  // the strip above's prefix word of block kc, issued one chunk ahead of boundary_end
@@ -407,19 +419,73 @@ struct StripProg {
 
     PA_HD void boundary_loads(vec& st_lo, vec& bp_lo, vec& bp_hi, vec& tr_lo, vec& tr_hi) {
         vec dummy;
-        W::load_words(reinterpret_cast<const uint64_t*>(c.status), 1, st_lo, dummy);
+        W::load_words(reinterpret_cast<const uint64_t*>(c.status) - 1, 2, st_lo, dummy);  // [cancel word | {state, value}]: adjacent
         W::load_words(c.bprog, 1, bp_lo, bp_hi);
         W::load_words(reinterpret_cast<const uint64_t*>(c.brec + kc), 11, brv_lo, brv_hi);
         W::load_words(reinterpret_cast<const uint64_t*>(c.trec + (kc + 1)), 7, tr_lo, tr_hi);
     }
+    PA_HD void older_loads() {
+        if (prev_over) {
+            W::load_i32s(reinterpret_cast<const int32_t*>(c.d_old + kc), kc + 1 <= c.nblk ? 16 : 8, oldv);
+        } else {
+            W::load_words(reinterpret_cast<const uint64_t*>(c.prev_brec + kc), 7, pbv_lo, pbv_hi);
+            W::load_words(reinterpret_cast<const uint64_t*>(c.prev_brec + (kc + 1 <= c.nblk ? kc + 1 : kc)), 4, pnv_lo, pnv_hi);
+            W::load_words(c.prev_done, 1, pdn_lo, pdn_hi);
+        }
+    }
     PA_HD void prefetch_boundary() {  // at the start of the last chunk of block kc
-        W::load_i32s(reinterpret_cast<const int32_t*>(c.d_old + kc), kc + 1 <= c.nblk ? 16 : 8, oldv);
+        older_loads();
+        pfo_valid = true;
         boundary_loads(pfb_st, pfb_bp_lo, pfb_bp_hi, pfb_tr_lo, pfb_tr_hi);
         pfb_valid = true;
     }
+    // The older passes' records of blocks kc and kc + 1.  While the previous pass runs they are its own bottom-edge records
+    // (final as soon as their tags are there: it decides block kc + 1's range right after block kc's fixed range); a record it
+    // never writes (the pass ended before) is waited for until the pass is over, then everything comes from the merged array.
+    PA_HD bool resolve_older() {
+        if (!pfo_valid) older_loads();
+        pfo_valid = false;
+        old_prev = false;
+        if (prev_over) return true;
+        const uint32_t pt = blk_tag(c.prev_pass, kc), ptn = blk_tag(c.prev_pass, kc + 1);
+        uint32_t spins = 0;
+        for (;;) {
+            const bool fixed_ok = W::readlane(pbv_hi, kBfs) == pt && W::readlane(pbv_hi, kBfe) == pt;
+            const bool range_ok = kc + 1 > c.nblk || (W::readlane(pnv_hi, kBjs) == ptn && W::readlane(pnv_hi, kBje) == ptn &&
+                                                      W::readlane(pnv_hi, kBojs) == ptn && W::readlane(pnv_hi, kBoje) == ptn);
+            if (fixed_ok && range_ok) {
+                old_prev = true;
+                return true;
+            }
+            if (W::readlane(pdn_lo, 0) == c.prev_pass) {  // over and merged: d_old from here on
+                prev_over = true;
+                older_loads();
+                return true;
+            }
+            W::nap(spins);
+            if ((++spins & 63u) == 0) {
+                if (pass_over()) {
+                    alive = false;
+                    return false;
+                }
+                if (spins > c.spin_limit) {
+                    finish(kStTimeout, 4, 0, 0);
+                    return false;
+                }
+            }
+            older_loads();
+        }
+    }
     enum { kBjs = 0, kBje = 1, kBojs = 2, kBoje = 3, kBflags = 4, kBfs = 5, kBfe = 6, kBbot = 7, kBtop = 8, kBsmax = 9, kBspec = 10 };
     enum { kTstate = 0, kTjs = 1, kTtop = 2, kTfs = 3, kTlim = 4, kTfound = 5, kTcont = 6 };
-    PA_HD int32_t old_field(int rec, int f) const { return W::readlane_i(oldv, rec * 8 + f); }  // BlockRec field order
+    // field f of the older record of block kc (rec 0: fs = 4, fe = 5) / kc + 1 (rec 1: js, je, ojs, oje = 0..3), BlockRec order
+    PA_HD int32_t old_field(int rec, int f) const {
+        if (old_prev) {  // the previous pass's BRec: fs, fe are words 5, 6; the range words are 0..3 in both layouts
+            const int32_t v = rec == 0 ? W::readlane_i(pbv_lo, f + 1) : W::readlane_i(pnv_lo, f);
+            return (rec == 1 && kc + 1 > c.nblk) ? kNone : v;
+        }
+        return W::readlane_i(oldv, rec * 8 + f);
+    }
 
     PA_HD bool boundary_begin() {
         PA_TRACE("pass %u strip %d boundary_begin block %d js=%d fsprev=%d\n", c.pass, r, kc, js_c, fsprev_c);
@@ -432,7 +498,6 @@ struct StripProg {
         const bool need_t = !scan_owner && !dead;
         bool bot_done = false, t_done = !need_t;
         const uint32_t tk = btag(kc), tn = btag(kc + 1);
-        if (!pfb_valid) W::load_i32s(reinterpret_cast<const int32_t*>(c.d_old + kc), kc + 1 <= c.nblk ? 16 : 8, oldv);
         uint32_t spins = 0;
         for (;;) {
             vec st_lo, bp_lo, bp_hi, tr_lo, tr_hi;
@@ -446,7 +511,7 @@ struct StripProg {
             } else {
                 boundary_loads(st_lo, bp_lo, bp_hi, tr_lo, tr_hi);
             }
-            if (W::readlane(st_lo, 0) != kStRunning) {
+            if (W::readlane(st_lo, 1) != kStRunning || W::readlane(st_lo, 0) == c.pass) {  // over, or given up by the host
                 alive = false;
                 return false;
             }
@@ -503,6 +568,7 @@ struct StripProg {
                 return false;
             }
         }
+        if (!resolve_older()) return false;
         old_fs_c = old_field(0, 4);
         old_js_n = kc + 1 <= c.nblk ? old_field(1, 0) : kNone;
         if (scan_owner) {  // the top-down scan of block kc starts in my rows
@@ -727,8 +793,7 @@ struct StripProg {
         old_next.je = old_field(1, 1);
         old_next.ojs = old_field(1, 2);
         old_next.oje = old_field(1, 3);
-        old_next.fs = old_field(1, 4);
-        old_next.fe = old_field(1, 5);
+        old_next.fs = old_next.fe = kNone;  // (not looked at: decide_next only needs the range)
         old_next.top_val = old_next.bot_val = 0;
         const NextDecision nd = decide_next(hp, c.f_max, c.sparse_h, ie, blk_end(c, kn), fs_final, fe_final, gu, old_next, (flags_c & 2) != 0);
         if (!nd.ok) {
@@ -887,6 +952,9 @@ struct StripProg {
         fpend = W::splat(0u);
         pfb_valid = false;
         pfp_valid = false;
+        pfo_valid = false;
+        old_prev = false;
+        prev_over = c.prev_brec == nullptr;
         if (is_top && js_c > row0) {  // the band's first row is inside my strip: that lane forces +1 from the start
             const typename W::mask first = W::eq_u(lrow0, (uint32_t)js_c);
             andm = W::select(first, W::splat(3u), andm);
@@ -1024,6 +1092,24 @@ struct StripProg {
                 }
                 block_done = crossing && t0 + 31 >= cx + 63;  // every lane has left block kc
             }
+            // ---- the plain stretch: chunks with no lane crossing and no boundary work ahead run in a loop of their own, so that
+            //      the register allocator keeps only what THEY need in registers (the block state lives in spill lanes meanwhile)
+            if (!crossing && !block_done && !fin) {
+                // chunks q + 1 .. qs - 1: before the chunk that prefetches the next boundary's records, left of the last column
+                int32_t qs = (blk_end(c, kc) >> 5) - 1;
+                if (kc == c.nblk) qs = c.n >> 5;  // (chunks from there on hold columns past the end: the general loop)
+                int32_t qq = q + 1;
+                PA_NOUNROLL
+                while (qq < qs && qq - q_first >= 2) {
+                    vec XS;
+                    if (!decode_inputs(qq, XS)) return;
+                    if (qq - q_first >= 3 && has_below) publish_granule(qq - 3);
+                    prefetch_inputs(qq + 1);
+                    W::template chunk<true>(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm);
+                    ++qq;
+                }
+                q = qq - 1;
+            }
             if (block_done) {
                 const uint64_t te0 = PA_CLK(W);
                 boundary_end();
@@ -1083,7 +1169,7 @@ PA_HD void wave_main(const Ctx& c) {
             W::add_u64(c.timing + 5, prog.t_wait_gran);
             W::add_u64(c.timing + 6, prog.t_cross2);
         }
-        if (W::load_u32(&c.status->state) != kStRunning) return;
+        if (W::load_u32(&c.status->state) != kStRunning || W::load_u64(c.cancel) == (uint64_t)c.pass) return;
     }
 }
 

@@ -29,6 +29,9 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+# the pipelined A*PA2 passes of pa_align run on their own streams: ask the HIP runtime for enough hardware queues BEFORE it starts
+# (torch initialises it ahead of the library's own load-time hint)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # The kernel's real bound is VALU issue: 256 CUs x 4 SIMDs x 2.4 GHz, one wave64 instruction per 2 clocks at best.

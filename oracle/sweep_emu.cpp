@@ -24,23 +24,47 @@ using pa_oracle_cpu::CpuBackend;
 namespace {
 
 struct HostLauncher {
+    static constexpr int kSlots = 4;
     const uint8_t *a, *b;
     int32_t n = 0, m = 0, nblk = 0;
     const int32_t* sh_h = nullptr;
     bool trace = false;
     int nwaves = 4;
+    int in_flight = 3;  // passes launched together at most (PA_SWEEP_EMU_DEPTH)
     uint32_t pass_id = 0;
     uint32_t spin_limit = 1u << 24;
+    int32_t heur_kind = kHeurGap;
     std::vector<uint32_t> codes, prof;
-    std::vector<BlockRec> d_old;
-    std::vector<BRec> brec;
-    std::vector<TRec> trec;
-    std::vector<uint64_t> strip_start, pring, gran, col;
-    uint64_t bprog = 0;
-    Status status;
-    uint32_t ticket = 0;
-    PassGeometry geo;
+    std::vector<BlockRec> merged[2];
+    // One pass in flight: its own records and buffers, its wavefront threads, and a closer thread that merges its records
+    // into the older ones and publishes the done word (what sweep_merge_kernel / sweep_done_kernel do behind the launch).
+    struct Slot {
+        int seq = 0, prev_seq = 0, mbuf = 0;
+        uint32_t pass = 0;
+        std::vector<BRec> brec;
+        std::vector<TRec> trec;
+        std::vector<uint64_t> strip_start, pring, gran, col;
+        uint64_t bprog = 0;
+        struct {
+            uint64_t cancel;  // directly before the status block (the wave program fetches both with one load)
+            Status status;
+        } ctl;
+        uint32_t ticket = 0;
+        uint64_t done = 0;
+        PassGeometry geo;
+        Ctx c;
+        std::vector<std::thread> waves;
+        std::thread closer;
+        bool live = false;
+    };
+    Slot slots[kSlots];
     Status last_status;
+
+    ~HostLauncher() { cancel_after(0); }
+    Slot& slot_of(int seq) { return slots[seq % kSlots]; }
+    int max_in_flight() const { return in_flight; }
+    int pass_waves(int32_t) const { return 1; }
+    int wave_budget() const { return 1 << 20; }
 
     void begin_pair(int32_t n_, int32_t m_, int32_t nblk_, const int32_t* sh, bool tr) {
         n = n_;
@@ -48,6 +72,7 @@ struct HostLauncher {
         nblk = nblk_;
         sh_h = sh;
         trace = tr;
+        if (const char* e = std::getenv("PA_SWEEP_EMU_DEPTH")) in_flight = std::atoi(e) < 1 ? 1 : (std::atoi(e) > kSlots - 1 ? kSlots - 1 : std::atoi(e));
         codes.assign((size_t)(n + 15) / 16 + 16, 0);
         for (int32_t i = 0; i < n; ++i) {
             const uint8_t ch = a[i];
@@ -62,25 +87,37 @@ struct HostLauncher {
         BlockRec none;
         none.js = none.je = none.ojs = none.oje = none.fs = none.fe = kNone;
         none.top_val = none.bot_val = 0;
-        d_old.assign((size_t)nblk + 2, none);
-        brec.assign((size_t)nblk + 2, BRec{});
-        trec.assign((size_t)nblk + 2, TRec{});
+        merged[0].assign((size_t)nblk + 2, none);
+        merged[1].assign((size_t)nblk + 2, none);
+        for (Slot& sl : slots) {
+            sl.ctl.cancel = 0;
+            sl.done = 0;
+            sl.brec.assign((size_t)nblk + 2, BRec{});
+            sl.trec.assign((size_t)nblk + 2, TRec{});
+        }
     }
-    BlockRec read_old(int32_t k) { return d_old[(size_t)k]; }
-    void write_old(int32_t k, const BlockRec& r) { d_old[(size_t)k] = r; }
+    BlockRec read_merged(int seq, int32_t k) { return seq == 0 ? merged[0][(size_t)k] : merged[slot_of(seq).mbuf][(size_t)k]; }
 
-    Status run_pass(int32_t f_max, int32_t sparse_h, const PassInit& init) {
+    void launch_pass(int seq, int prev_seq, int32_t f_max, int32_t sparse_h, const PassInit& init) {
+        Slot& sl = slot_of(seq);
+        if (sl.live) std::abort();  // (the aligner never has more than kSlots - 1 passes in flight)
+        Slot* pv = prev_seq ? &slot_of(prev_seq) : nullptr;
         pass_id += 1;
-        geo = pass_geometry(n, m, f_max);
-        strip_start.resize((size_t)geo.nstrips, 0);
-        pring.resize((size_t)geo.nstrips * geo.pr_stride, 0);
-        gran.assign((size_t)geo.nstrips * geo.gran_stride, 0);
-        const size_t slots = trace ? (size_t)nblk + 1 : (size_t)geo.col_ring;
-        col.assign(slots * (size_t)geo.col_stride * 2, 0);
-        std::memset(&status, 0, sizeof(status));
-        ticket = 0;
-        const uint32_t t1 = blk_tag(pass_id, 1);
-        BRec& b1 = brec[1];
+        sl.seq = seq;
+        sl.prev_seq = prev_seq;
+        sl.pass = pass_id;
+        sl.mbuf = pv ? 1 - pv->mbuf : 1;  // (before any pass the merged records are merged[0])
+        sl.geo = pass_geometry(n, m, f_max);
+        const PassGeometry& geo = sl.geo;
+        sl.strip_start.resize((size_t)geo.nstrips, 0);
+        sl.pring.resize((size_t)geo.nstrips * geo.pr_stride, 0);
+        sl.gran.assign((size_t)geo.nstrips * geo.gran_stride, 0);
+        const size_t nslots = trace ? (size_t)nblk + 1 : (size_t)geo.col_ring;
+        sl.col.assign(nslots * (size_t)geo.col_stride * 2, 0);
+        std::memset(&sl.ctl.status, 0, sizeof(Status));
+        sl.ticket = 0;
+        const uint32_t t1 = blk_tag(sl.pass, 1);
+        BRec& b1 = sl.brec[1];
         b1.js = tw_make(t1, init.js1);
         b1.je = tw_make(t1, init.je1);
         b1.ojs = tw_make(t1, init.ojs1);
@@ -88,17 +125,17 @@ struct HostLauncher {
         b1.flags = tw_make(t1, init.flags1);
         b1.smax = tw_make(t1, init.last_strip);
         b1.specmax = tw_make(t1, 0);
-        TRec& tr1 = trec[1];
+        TRec& tr1 = sl.trec[1];
         tr1.js = tw_make(t1, init.js1);
         tr1.top_val = tw_make(t1, init.top1);
         tr1.fs_prev = tw_make(t1, init.fs0);
         tr1.lim = tw_make(t1, 0);
         tr1.found = tw_make(t1, 0);
         tr1.state = tw_make(t1, kTDesc);
-        for (int32_t r = 0; r <= init.last_strip && r < geo.nstrips; ++r) strip_start[(size_t)r] = tw_make(pass_id, 1);
-        bprog = tw_make(t1, init.oje1);
+        for (int32_t r = 0; r <= init.last_strip && r < geo.nstrips; ++r) sl.strip_start[(size_t)r] = tw_make(sl.pass, 1);
+        sl.bprog = tw_make(t1, init.oje1);
 
-        Ctx c;
+        Ctx& c = sl.c;
         c.a_codes = codes.data();
         c.b_prof = prof.data();
         c.n = n;
@@ -106,67 +143,102 @@ struct HostLauncher {
         c.nblk = nblk;
         c.wtot = geo.wtot;
         c.f_max = f_max;
-        c.pass = pass_id;
+        c.pass = sl.pass;
         c.heur = sh_h ? kHeurSH : heur_kind;
         c.sparse_h = sparse_h;
         c.sh_h = sh_h;
         c.store_cols = trace ? 1 : 0;
-        c.d_old = d_old.data();
-        c.brec = brec.data();
-        c.trec = trec.data();
-        c.bprog = &bprog;
-        c.strip_start = strip_start.data();
-        c.pring = pring.data();
+        c.d_old = merged[1 - sl.mbuf].data();
+        c.prev_brec = pv ? pv->brec.data() : nullptr;
+        c.prev_pass = pv ? pv->pass : 0;
+        c.prev_done = pv ? &pv->done : &sl.done;
+        c.cancel = &sl.ctl.cancel;
+        c.brec = sl.brec.data();
+        c.trec = sl.trec.data();
+        c.bprog = &sl.bprog;
+        c.strip_start = sl.strip_start.data();
+        c.pring = sl.pring.data();
         c.pr_stride = geo.pr_stride;
-        c.gran = gran.data();
+        c.gran = sl.gran.data();
         c.gran_stride = geo.gran_stride;
         c.win = geo.win;
-        c.col = col.data();
+        c.col = sl.col.data();
         c.col_stride = geo.col_stride;
         c.col_ring = geo.col_ring;
-        c.status = &status;
-        c.ticket = &ticket;
+        c.status = &sl.ctl.status;
+        c.ticket = &sl.ticket;
         c.nstrips = geo.nstrips;
         c.nwaves = nwaves < geo.nstrips ? nwaves : geo.nstrips;
         c.spin_limit = spin_limit;
         c.timing = nullptr;
-        std::vector<std::thread> th;
-        for (int w = 0; w < c.nwaves; ++w) th.emplace_back([&c]() { wave_main<HostWave>(c); });
-        for (auto& t : th) t.join();
-        last_status = status;
-        return status;
+        sl.live = true;
+        for (int w = 0; w < c.nwaves; ++w) sl.waves.emplace_back([&c]() { wave_main<HostWave>(c); });
+        // behind the pass: merge (after the previous pass's merge, like the stream-ordered kernels on the device), then the done word
+        const uint64_t prev_pass_id = pv ? pv->pass : 0;
+        sl.closer = std::thread([this, &sl, pv, prev_pass_id]() {
+            for (auto& t : sl.waves) t.join();
+            if (pv)
+                while (__atomic_load_n(&pv->done, __ATOMIC_ACQUIRE) != prev_pass_id) std::this_thread::yield();
+            const Status& st = sl.ctl.status;
+            const std::vector<BlockRec>& mo = merged[1 - sl.mbuf];
+            std::vector<BlockRec>& mn = merged[sl.mbuf];
+            const bool ended = st.state == kStDone || st.state == kStNoPath;
+            for (int32_t k = 0; k <= nblk + 1; ++k) {
+                BlockRec d = mo[(size_t)k];
+                if (ended && k >= 1 && k <= nblk && k <= st.k_end) {
+                    const BRec& s = sl.brec[(size_t)k];
+                    d.js = tw_val(s.js);
+                    d.je = tw_val(s.je);
+                    d.ojs = tw_val(s.ojs);
+                    d.oje = tw_val(s.oje);
+                    if (k <= st.k_fixed) {
+                        d.fs = tw_val(s.fs);
+                        d.fe = tw_val(s.fe);
+                        d.top_val = tw_val(s.top_val);
+                        d.bot_val = tw_val(s.bot_val);
+                    }
+                }
+                mn[(size_t)k] = d;
+            }
+            __atomic_store_n(&sl.done, (uint64_t)sl.pass, __ATOMIC_RELEASE);
+        });
     }
-    int32_t heur_kind = kHeurGap;
-
-    void commit(int32_t k_end, int32_t k_fixed) {
+    Status wait_pass(int seq) {
+        Slot& sl = slot_of(seq);
+        if (sl.closer.joinable()) sl.closer.join();
+        sl.waves.clear();
+        sl.live = false;
+        last_status = sl.ctl.status;
         if (std::getenv("PA_SWEEP_DEBUG")) {
-            std::fprintf(stderr, "pass %u state=%u value=%d k_end=%d k_fixed=%d\n", pass_id, status.state, status.value, k_end, k_fixed);
-            for (int32_t k = 1; k <= k_end && k <= nblk; ++k) {
-                const BRec& s = brec[(size_t)k];
+            const Status& st = sl.ctl.status;
+            std::fprintf(stderr, "pass %u (seq %d after %d) state=%u value=%d k_end=%d k_fixed=%d\n", sl.pass, seq, sl.prev_seq, st.state, st.value, st.k_end, st.k_fixed);
+            for (int32_t k = 1; k <= st.k_end && k <= nblk; ++k) {
+                const BRec& s = sl.brec[(size_t)k];
                 std::fprintf(stderr, "  i=(%d,%d] j_range=[%d,%d] fixed=[%d,%d] top=%d bot=%d\n", (k - 1) * kBlockW, k * kBlockW < n ? k * kBlockW : n,
-                             tw_val(s.ojs), tw_val(s.oje), k <= k_fixed ? tw_val(s.fs) : -9, k <= k_fixed ? tw_val(s.fe) : -9,
-                             k <= k_fixed ? tw_val(s.top_val) : -9, k <= k_fixed ? tw_val(s.bot_val) : -9);
+                             tw_val(s.ojs), tw_val(s.oje), k <= st.k_fixed ? tw_val(s.fs) : -9, k <= st.k_fixed ? tw_val(s.fe) : -9,
+                             k <= st.k_fixed ? tw_val(s.top_val) : -9, k <= st.k_fixed ? tw_val(s.bot_val) : -9);
             }
         }
-        for (int32_t k = 1; k <= k_end && k <= nblk; ++k) {
-            BlockRec& d = d_old[(size_t)k];
-            const BRec& s = brec[(size_t)k];
-            d.js = tw_val(s.js);
-            d.je = tw_val(s.je);
-            d.ojs = tw_val(s.ojs);
-            d.oje = tw_val(s.oje);
-            if (k <= k_fixed) {
-                d.fs = tw_val(s.fs);
-                d.fe = tw_val(s.fe);
-                d.top_val = tw_val(s.top_val);
-                d.bot_val = tw_val(s.bot_val);
-            }
-        }
+        return sl.ctl.status;
     }
-    void read_blocks(std::vector<Block>& blocks) {
+    void cancel_after(int seq) {  // in launch order, so that every closer finds its predecessor's done word
+        for (int pass = 0; pass < 2; ++pass)
+            for (int q = seq + 1; q <= seq + kSlots; ++q) {
+                Slot& sl = slot_of(q);
+                if (!sl.live || sl.seq <= seq) continue;
+                if (pass == 0) __atomic_store_n(&sl.ctl.cancel, (uint64_t)sl.pass, __ATOMIC_RELEASE);
+                else {
+                    if (sl.closer.joinable()) sl.closer.join();
+                    sl.waves.clear();
+                    sl.live = false;
+                }
+            }
+    }
+    void read_blocks(int seq, std::vector<Block>& blocks) {
+        Slot& sl = slot_of(seq);
         for (int32_t k = 1; k <= nblk; ++k) {
             Block& bl = blocks[(size_t)k];
-            const BRec& s = brec[(size_t)k];
+            const BRec& s = sl.brec[(size_t)k];
             const int32_t js = tw_val(s.js), je = tw_val(s.je);
             bl.i_range = IRange{(k - 1) * kBlockW, k * kBlockW < n ? k * kBlockW : n};
             bl.original_j_range = JRange{tw_val(s.ojs), tw_val(s.oje)};
@@ -178,11 +250,11 @@ struct HostLauncher {
             bl.j_h.reset();
             bl.v.resize((size_t)(je - js) / 64);
             Ctx c;
-            c.win = geo.win;
+            c.win = sl.geo.win;
             c.store_cols = 1;
-            c.col_ring = geo.col_ring;
+            c.col_ring = sl.geo.col_ring;
             c.n = n;
-            const uint64_t* colk = col.data() + ((int64_t)k * geo.col_stride - col_base_word(c, k)) * 2;
+            const uint64_t* colk = sl.col.data() + ((int64_t)k * sl.geo.col_stride - col_base_word(c, k)) * 2;
             for (size_t w = 0; w < bl.v.size(); ++w) {
                 bl.v[w].p = colk[2 * ((size_t)js / 64 + w)];
                 bl.v[w].m = colk[2 * ((size_t)js / 64 + w) + 1];

@@ -147,3 +147,26 @@ def test_jr_end_fast_forward_equals_literal_loops(oracle):
         sp = rng.choice([0, 1])
         got = L.pa_sweep_jr_end(kind, n, m, sh.ctypes.data_as(C.c_void_p), is_, ie, fe, gu, f_max, sp)
         assert got == literal(kind, n, m, sh, is_, ie, fe, gu, f_max, sp), (kind, n, m, is_, ie, fe, gu, f_max, sp)
+
+
+def test_pipelined_passes_equal_sequential_passes(oracle, monkeypatch):
+    """The passes of one band search run pipelined (sweep_host.hpp search()): the pass for the next bound is launched while the
+    current one runs and reads its block records as they appear.  Whatever the depth, cost / CIGAR / statistics are those of
+    one pass after the other -- which in turn are the host-driven engine's."""
+    import random
+
+    rng = random.Random(5)
+    vs = variants(oracle)
+    cases = []
+    for _ in range(40):
+        n = rng.choice([rng.randint(300, 3000), rng.randint(3000, 15000)])
+        cases.append((rng.choice(list(vs)), gen_pair(n, rng.choice([0.02, 0.1, 0.25, 0.5]), rng.randint(1, 10**6))))
+    results = {}
+    for depth in ("1", "2", "3"):
+        monkeypatch.setenv("PA_SWEEP_EMU_DEPTH", depth)
+        results[depth] = [oracle.sweep_emu_align(a, b, vs[name], trace=True, nwaves=16)[:4] for name, (a, b) in cases]
+    for (name, (a, b)), r1, r2, r3 in zip(cases, results["1"], results["2"], results["3"]):
+        want = oracle.cpu_align(a, b, vs[name], trace=True)
+        for rc, cost, cigar, stats in (r1, r2, r3):
+            assert rc == 0 and (cost, cigar) == (want[0], want[1])
+            assert {k: stats[k] for k in KEYS} == {k: want[2][k] for k in KEYS}

@@ -5,6 +5,7 @@ There is no CPU fallback: if the library is missing or no GPU is visible, calls 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
@@ -36,6 +37,10 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     if _lib is not None:
         return _lib
     path = _build.LIB_PATH
+    if os.environ.get("PA_LIB_PATH"):  # diagnostics: an alternative build of the same sources (e.g. -DPA_SWEEP_PHASE_TIMERS)
+        from pathlib import Path
+
+        path, build_if_stale = Path(os.environ["PA_LIB_PATH"]).resolve(), False
     if build_if_stale and _build.is_stale():
         try:
             _build.build()

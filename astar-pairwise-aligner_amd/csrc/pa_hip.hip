@@ -334,6 +334,7 @@ bool launch_strips(const StripJob* d_jobs, int njobs, bool fill, uint32_t* d_tic
     if (zero_ticket && !hip_ok(hipMemsetAsync(d_ticket_err, 0, 2 * sizeof(uint32_t), s), "memset ticket")) return false;
     if (block_waves < 1 || block_waves > kStripMaxBlockWaves) block_waves = kStripBlockWaves;
     if (const char* e = getenv("PA_STRIP_BLOCK_WAVES")) block_waves = std::min(std::max(atoi(e), 1), kStripMaxBlockWaves);  // experiments
+    if (k < 4 && block_waves > kStripBlockWaves) block_waves = kStripBlockWaves;  // (the k = 1, 2 kernels are built for 256 threads)
     const int grid = (njobs + block_waves - 1) / block_waves;  // one wave per job; jobs beyond residency queue behind their
                                                                // producers (ticket order)
     const unsigned lds = block_waves >= kStripBlockWaves ? residency_lds_bytes(grid) : 0;

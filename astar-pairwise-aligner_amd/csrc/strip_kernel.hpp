@@ -338,6 +338,30 @@ __device__ __forceinline__ bool resolve_granule(gcu64 g, uint64_t pre, int q, ui
     return l != 0u;
 }
 
+// Rarely taken paths of chained batches, kept OUT of line: inlined, their loads share registers with the chunk loop's and the
+// compiler protects those with an s_waitcnt vmcnt(0) in front of every granule store -- one memory round trip per chunk on the
+// critical path of every chain (measured: one pair 5.45 -> 6.39 ms).
+__device__ __attribute__((noinline)) void pace_top_strip(const uint32_t* counter, int32_t strips, int q) {
+    typedef PA_GLOBAL unsigned long long* gull;
+    const gull ctr = (gull)counter;
+    const int lane = (int)(threadIdx.x & 63);
+    unsigned long long g = 0;
+    if (lane == 0) g = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t glo = rfl((uint32_t)g), ghi = rfl((uint32_t)(g >> 32));
+    const unsigned long long mine = (unsigned long long)(q > kPaceLead ? q - kPaceLead : 0) * (unsigned long long)strips;
+    // ahead of the average by more than kPaceLead chunks: nap (a chunk is ~5 us of work), at most ~8 chunks' worth
+    for (int nap = 0; nap < 16 && (((unsigned long long)ghi << 32) | glo) < mine; ++nap) {
+        __builtin_amdgcn_s_sleep(127);
+        if (lane == 0) g = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        glo = rfl((uint32_t)g);
+        ghi = rfl((uint32_t)(g >> 32));
+    }
+}
+__device__ __attribute__((noinline)) bool wait_granule_ahead(const uint64_t* gran, int q) {
+    uint32_t lo, hi;
+    return resolve_granule<false>((gcu64)gran, 0, q, lo, hi);
+}
+
 // Process one strip.  On a spin timeout the error word is set and the strip stops early.
 // K = 32-row subwords per lane: the strip covers 64*K subwords = 32*K reference words.
 // LOCAL: the granules are produced and consumed by the SAME wavefront (pair_kernel, trace_kernel): workgroup-scope
@@ -477,6 +501,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
     };
 
     if (!LOCAL && ((job.flags & kJobPrioMask) >> 1) >= 2 && !has_gran) __builtin_amdgcn_s_setprio(3);
+    const bool extras = (job.flags & (kJobPrioMask | kJobLag | kJobPace | kJobLog)) != 0;
     const uint32_t prio_slot = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 4);  // HW_ID.wave_id: the slot on this SIMD
     const uint64_t log_t0 = (!FILL && (job.flags & kJobLog)) ? wall_clock64() : 0;
     uint32_t log_polled = 0;
@@ -519,23 +544,24 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
         uint32_t hin2 = has_hin ? (((hinb_next & 1u) << 31) | ((hinb_next & 2u) << 29)) : 0x80000000u;
         if (q < C && has_gran && (job.hin_n == 0 || q * 32 < job.hin_n)) {
             uint32_t glo, ghi;
-            if (!LOCAL && (job.flags & kJobPrioMask) && (job.flags & kJobPrioMask) != kJobPrioMask) {
-                if (rfl((uint32_t)gran_next) == 0u) __builtin_amdgcn_s_setprio(0);
-                else __builtin_amdgcn_s_setprio(2);
-            }
-            if (!FILL && rfl((uint32_t)gran_next) == 0u) ++log_polled;
-            if (!LOCAL && (job.flags & kJobLag) && rfl((uint32_t)gran_next) == 0u) {
-                const int lastg = (job.hin_n == 0 || job.hin_n >= n ? C : job.hin_n / 32) - 1;
-                const int qa = q + 4 < lastg ? q + 4 : lastg;
-                uint32_t dl, dh;
-                if (qa > q) alive = resolve_granule<LOCAL>(g_gran, 0, qa, dl, dh);
+            if (!LOCAL && !FILL && extras) {  // (one test on the common path: none of this is on for a batch within one wavefront per SIMD)
+                if ((job.flags & kJobPrioMask) && (job.flags & kJobPrioMask) != kJobPrioMask) {
+                    if (rfl((uint32_t)gran_next) == 0u) __builtin_amdgcn_s_setprio(0);
+                    else __builtin_amdgcn_s_setprio(2);
+                }
+                if (rfl((uint32_t)gran_next) == 0u) ++log_polled;
+                if ((job.flags & kJobLag) && rfl((uint32_t)gran_next) == 0u) {
+                    const int lastg = (job.hin_n == 0 || job.hin_n >= n ? C : job.hin_n / 32) - 1;
+                    const int qa = q + 4 < lastg ? q + 4 : lastg;
+                    if (qa > q) alive = wait_granule_ahead(job.hin_gran, qa);
+                }
             }
             if (alive) alive = resolve_granule<LOCAL>(g_gran, gran_next, q, glo, ghi);
             hin2 = ((upper ? ghi : glo) << sh) & 0xC0000000u;
             // every granule has exactly one consumer: hand it back zeroed, so the buffer needs clearing only once
             if (lane == 0) __hip_atomic_store((gu64)job.hin_gran + q, (uint64_t)0, __ATOMIC_RELAXED, kGranScope);
         }
-        if (!LOCAL && (job.flags & kJobPrioMask) == kJobPrioMask) {
+        if (!LOCAL && !FILL && extras && (job.flags & kJobPrioMask) == kJobPrioMask) {
             // rotate the issue priority chunk by chunk, with a phase per wave slot: the SIMD serves the highest priority
             // first and the OLDEST wavefront among equals, which starves the younger wavefronts of a shared SIMD -- and a
             // chain advances at the pace of its most starved strip
@@ -545,21 +571,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
             else if (ph == 2) __builtin_amdgcn_s_setprio(2);
             else __builtin_amdgcn_s_setprio(3);
         }
-        if (!LOCAL && !CKPT && !FILL && (job.flags & kJobPace) && q < C) {
-            typedef PA_GLOBAL unsigned long long* gull;
-            const gull ctr = (gull)job.ckpt;
-            unsigned long long g = 0;
-            if (lane == 0) g = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t glo_ = rfl((uint32_t)g), ghi_ = rfl((uint32_t)(g >> 32));
-            const unsigned long long mine = (unsigned long long)(q > kPaceLead ? q - kPaceLead : 0) * (unsigned long long)job.ckpt_stride;
-            // ahead of the average by more than kPaceLead chunks: nap (a chunk is ~5 us of work), at most ~8 chunks' worth
-            for (int nap = 0; nap < 16 && (((unsigned long long)ghi_ << 32) | glo_) < mine; ++nap) {
-                __builtin_amdgcn_s_sleep(127);
-                if (lane == 0) g = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                glo_ = rfl((uint32_t)g);
-                ghi_ = rfl((uint32_t)(g >> 32));
-            }
-        }
+        if (!LOCAL && !CKPT && !FILL && extras && (job.flags & kJobPace) && q < C) pace_top_strip(job.ckpt, job.ckpt_stride, q);
         const uint32_t XS = code | hin2;
         // ---- publish the granule completed by the previous chunk (q-1) ----
         if (q >= 3) publish(q - 3);
@@ -671,10 +683,11 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
 // crowded SIMD, so balance is worth more than anything else at 1-4 wavefronts per SIMD.
 // `ticket` and `err` must be zeroed (and every hin/hout granule buffer cleared) before the launch.
 constexpr int kStripBlockWaves = 4;
-constexpr int kStripMaxBlockWaves = 16;  // chained batches beyond one wavefront per SIMD: one workgroup per CU (<= 128 VGPRs)
+constexpr int kStripMaxBlockWaves = 16;  // chained batches of tall strips (k >= 4) beyond one wavefront per SIMD: one workgroup
+                                         // per CU (<= 128 VGPRs); k = 1, 2 kernels keep 4-wavefront workgroups
 // LDSEQ (K >= 4, cost-only): eq words from LDS, see LdsEq; the launch provides one slice per wavefront of the block.
 template <int K, bool FILL, bool SCATTER = false, bool CKPT = false, bool LDSEQ = false>
-__global__ __launch_bounds__(64 * kStripMaxBlockWaves) void strip_kernel(const StripJob* __restrict__ jobs, int njobs,
+__global__ __launch_bounds__(64 * (K >= 4 ? kStripMaxBlockWaves : kStripBlockWaves)) void strip_kernel(const StripJob* __restrict__ jobs, int njobs,
                                                    uint32_t* ticket, uint32_t* err) {
     uint32_t t = 0;
     if ((threadIdx.x & 63) == 0) t = atomicAdd(ticket, 1u);

@@ -149,7 +149,7 @@ struct StripProg {
     flag_t alive;                        // false: stop (pass over, abort, timeout)
     // deferred flag publications (after the payload stores have drained)
     uint64_t st_num_blocks = 0, st_unique = 0, st_computed = 0, st_incremental = 0;  // my share of the pass's BlockStats
-    uint64_t t_cross2 = 0;
+    uint64_t t_cross2 = 0, t_probe = 0;
     uint64_t t_begin = 0, t_cross = 0, t_end = 0, t_bottom = 0, t_plain = 0, t_wait_gran = 0;  // phase clocks (W::clock ticks)
     int32_t pend_k, pend_p, pend_cont_j;  // deferred publications (see flush_deferred)
     flag_t pend_cont;
@@ -1075,7 +1075,9 @@ struct StripProg {
                             if (sc_active) {
                                 const int32_t jh = lane_of(sc_j) - cl0;  // the step in which the scanned row's lane crosses
                                 if (jh == j) {
+                                    const uint64_t tp0 = PA_CLK(W);
                                     scan_probe(cl0 + j);
+                                    PA_CLK_ADD(t_probe, W::clock() - tp0);
                                     if (!alive) return;
                                     continue;
                                 }
@@ -1102,10 +1104,14 @@ struct StripProg {
                 PA_NOUNROLL
                 while (qq < qs && qq - q_first >= 2) {
                     vec XS;
+                    const uint64_t tg0 = PA_CLK(W);
                     if (!decode_inputs(qq, XS)) return;
+                    const uint64_t tg1 = PA_CLK(W);
+                    PA_CLK_ADD(t_wait_gran, tg1 - tg0);
                     if (qq - q_first >= 3 && has_below) publish_granule(qq - 3);
                     prefetch_inputs(qq + 1);
                     W::template chunk<true>(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm);
+                    PA_CLK_ADD(t_plain, W::clock() - tg1);
                     ++qq;
                 }
                 q = qq - 1;
@@ -1168,6 +1174,7 @@ PA_HD void wave_main(const Ctx& c) {
             W::add_u64(c.timing + 4, prog.t_plain);
             W::add_u64(c.timing + 5, prog.t_wait_gran);
             W::add_u64(c.timing + 6, prog.t_cross2);
+            W::add_u64(c.timing + 7, prog.t_probe);
         }
         if (W::load_u32(&c.status->state) != kStRunning || W::load_u64(c.cancel) == (uint64_t)c.pass) return;
     }

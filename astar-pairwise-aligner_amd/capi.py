@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "pa_batch_create", "pa_batch_run", "pa_batch_stats", "pa_batch_shape", "pa_batch_destroy",
     "pa_batch_create_banded", "pa_batch_create_trace", "pa_batch_align", "pa_batch_trace_fallbacks", "pa_params_batch_align",
     "pa_pairs_read", "pa_pairs_count", "pa_pairs_get", "pa_pairs_free", "pa_write_results_csv", "pa_align_file",
-    "pa_align", "pa_batch_align_multi",
+    "pa_align", "pa_batch_align_multi", "pa_batch_create_trace_params",
 ]
 
 _lib = None
@@ -75,6 +75,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_batch_create_banded.restype = vp
     L.pa_batch_create_trace.argtypes = [vp, vp, vp, vp, sz]
     L.pa_batch_create_trace.restype = vp
+    L.pa_batch_create_trace_params.argtypes = [vp, vp, vp, vp, sz, vp]
+    L.pa_batch_create_trace_params.restype = vp
     L.pa_batch_align.argtypes = [vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.pa_batch_align.restype = C.c_int
     L.pa_batch_trace_fallbacks.argtypes = [vp]
@@ -243,8 +245,9 @@ def align_multi(pairs: list[tuple[bytes, bytes]], devices: list[int], trace: boo
 class Batch:
     """Device-resident batch of independent pairs; run() = full-DP edit distance of every pair."""
 
-    def __init__(self, pairs: list[tuple[bytes, bytes]], trace: bool = False, band: float | None = None):
-        """band: expected edit rate (e.g. 0.05) -> diagonal-band DP, re-run wider where it was too narrow (still exact)."""
+    def __init__(self, pairs: list[tuple[bytes, bytes]], trace: bool = False, band: float | None = None, trace_params=None):
+        """band: expected edit rate (e.g. 0.05) -> diagonal-band DP, re-run wider where it was too narrow (still exact).
+        trace_params: an AstarPa2Params whose `front` (dt_trace, max_g, fr_drop) the batched traceback follows."""
         L = load()
         self._keep = pairs
         self.trace = trace
@@ -257,6 +260,9 @@ class Batch:
             raise ValueError("banded batches are cost-only")
         if band is not None:
             self._h = L.pa_batch_create_banded(ap, al, bp, bl, n, C.c_float(band))
+        elif trace and trace_params is not None:
+            cp = trace_params._to_c()
+            self._h = L.pa_batch_create_trace_params(ap, al, bp, bl, n, C.byref(cp))
         else:
             self._h = (L.pa_batch_create_trace if trace else L.pa_batch_create)(ap, al, bp, bl, n)
         if not self._h:

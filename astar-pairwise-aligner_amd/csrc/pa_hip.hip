@@ -964,6 +964,7 @@ struct pa_batch {
     DeviceBuf d_rjobs, d_rfirst;  // retry sub-batches
     // traceback mode (pa_batch_create_trace / pa_batch_align)
     bool trace = false;
+    int dt_max_g = 0, dt_fr_drop = 0;  // DT-trace options of the batched traceback (0: re-fill only)
     size_t trace_fallbacks = 0;  // pairs whose traceback was redone by the host engine
     std::vector<size_t> ckpt_off, cigar_off, word_off;  // per pair, in u32 (ckpt) / elements (cigar) / words of b before this pair
     DeviceBuf d_scratch_gran;
@@ -1162,11 +1163,13 @@ static void choose_band_shape(pa_batch* p) {
 }
 
 static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len, size_t pairs,
-                              bool trace, float band_hint = -1.f) {
+                              bool trace, float band_hint = -1.f, int dt_max_g = 0, int dt_fr_drop = 0) {
     if (!ensure_device()) return nullptr;
     auto p = std::make_unique<pa_batch>();
     p->pairs = pairs;
     p->trace = trace;
+    p->dt_max_g = dt_max_g;
+    p->dt_fr_drop = dt_fr_drop;
     p->banded = band_hint >= 0.f;
     if (p->banded) {
         for (size_t i = 0; i < pairs; ++i) {
@@ -1366,6 +1369,8 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             t.m = (int32_t)b_len[i];
             t.w = (int32_t)((b_len[i] + 63) / 64);
             t.cigar_cap = (uint32_t)std::min<size_t>(a_len[i] + b_len[i] + 2, 0xFFFFFFF0u);
+            t.dt_max_g = dt_max_g;
+            t.dt_fr_drop = dt_fr_drop;
             src_off[i] = p->cigar_off[i];
         }
         if (!hip_ok(hipMemsetAsync(p->d_scratch_gran.ptr, 0, pairs * 16 * 8, p->stream), "memset trace granules") ||
@@ -1430,6 +1435,23 @@ extern "C" pa_batch* pa_batch_create_banded(const uint8_t* const* a, const size_
 extern "C" pa_batch* pa_batch_create_trace(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b,
                                            const size_t* b_len, size_t pairs) {
     return batch_create(a, a_len, b, b_len, pairs, true);
+}
+
+// ... with the traceback options of `trace_params->front` (dt_trace, max_g, fr_drop): DT-trace through every block first, the
+// re-fill only where it gives up (blocks/trace.rs:51-125), e.g. the `simple` preset's { dt_trace: true, max_g: 40, fr_drop: 10 }.
+extern "C" pa_batch* pa_batch_create_trace_params(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b,
+                                                  const size_t* b_len, size_t pairs, const pa_astarpa2_params* trace_params) {
+    if (!trace_params) return batch_create(a, a_len, b, b_len, pairs, true);
+    const engine::AstarPa2Params tp = engine::params_from_c(*trace_params);
+    if (!tp.front.sparse || tp.block_width != 256) {
+        set_error("pa_batch_create_trace_params: the batched traceback walks sparse 256-column blocks");
+        return nullptr;
+    }
+    if (tp.front.dt_trace && (tp.front.max_g < 1 || tp.front.max_g > kDtMaxG)) {
+        set_error("pa_batch_create_trace_params: max_g must be in 1..%d", kDtMaxG);
+        return nullptr;
+    }
+    return batch_create(a, a_len, b, b_len, pairs, true, -1.f, tp.front.dt_trace ? (int)tp.front.max_g : 0, tp.front.dt_trace ? (int)tp.front.fr_drop : 0);
 }
 
 // Profiles -> (granule clear) -> DP kernel, all queued on the batch's stream; ev0/ev1 bracket the DP kernel.
@@ -1633,7 +1655,11 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
     // traceback: one wavefront per pair
     if (P) {
         const int grid = (int)((P + kStripBlockWaves - 1) / kStripBlockWaves);
-        hipLaunchKernelGGL(trace_kernel, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, p->d_tjobs.as<TraceJob>(), (int)P, p->d_misc.as<uint32_t>() + 1);
+        if (p->dt_max_g > 0)
+            hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(64 * kStripBlockWaves), kStripBlockWaves * sizeof(DtLds), s, p->d_tjobs.as<TraceJob>(), (int)P,
+                               p->d_misc.as<uint32_t>() + 1);
+        else
+            hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, p->d_tjobs.as<TraceJob>(), (int)P, p->d_misc.as<uint32_t>() + 1);
         if (!hip_ok(hipGetLastError(), "trace_kernel launch")) return PA_E_HIP;
     }
     if (!hip_ok(hipEventRecord(p->ev2, s), "event")) return PA_E_HIP;
@@ -1697,7 +1723,12 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
         }
     }
     mark("pack kernel + text D2H");
-    const pa_astarpa2_params fallback = traced_batch_params();
+    pa_astarpa2_params fallback = traced_batch_params();
+    if (p->dt_max_g > 0) {
+        fallback.front.dt_trace = 1;
+        fallback.front.max_g = p->dt_max_g;
+        fallback.front.fr_drop = p->dt_fr_drop;
+    }
     // a failure after the first string has been handed out: free them all again, the caller owns outputs only on success
     auto fail_out = [&](size_t produced, int code) {
         if (cigar_out)

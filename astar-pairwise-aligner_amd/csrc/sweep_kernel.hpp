@@ -96,6 +96,7 @@ struct DeviceWave {
         for (uint32_t k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(8);
     }
     static __device__ __forceinline__ uint64_t clock() { return wall_clock64(); }  // 100 MHz
+    static __device__ __forceinline__ void stretch_marker() { asm volatile("; plain stretch"); }
     static __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     static __device__ __forceinline__ uint32_t ticket(uint32_t* p) {
         return rfl32(atomicAdd(p, (threadIdx.x & 63u) == 0 ? 1u : 0u));  // lane 0's view: the tickets taken before mine

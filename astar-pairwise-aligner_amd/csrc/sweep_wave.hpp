@@ -1110,6 +1110,7 @@ struct StripProg {
                     PA_CLK_ADD(t_wait_gran, tg1 - tg0);
                     if (qq - q_first >= 3 && has_below) publish_granule(qq - 3);
                     prefetch_inputs(qq + 1);
+                    W::stretch_marker();  // (keeps this copy of the chunk from being merged back into the general loop's)
                     W::template chunk<true>(XS, X, vp, vm, nb0, nb1, acc_lo, acc_hi, andm, orm);
                     PA_CLK_ADD(t_plain, W::clock() - tg1);
                     ++qq;

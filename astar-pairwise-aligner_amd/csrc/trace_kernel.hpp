@@ -36,6 +36,7 @@ struct TraceJob {
     uint64_t* scratch_gran;    // 2 rows x 8 granules, zero between uses (multi-strip re-fills hand their bottom row down)
     int32_t n, m, w;           // |a|, |b|, words of b
     uint32_t cigar_cap;
+    int32_t dt_max_g, dt_fr_drop;  // DT-trace (trace.rs:231-416) before every re-fill: max_g (0 = off, <= kDtMaxG), fr_drop
 };
 enum : uint32_t { kTraceFailed = 0xFFFFFFFFu };
 // Re-fills of up to 128 words (8192 rows, four strips) stay on the GPU; a pair with a taller one (an indel of more than
@@ -74,11 +75,31 @@ __device__ __forceinline__ int32_t column_diff(gcu32 col, int r) {
     return (int32_t)((p >> (r & 31)) & 1u) - (int32_t)((m >> (r & 31)) & 1u);
 }
 
+// ---- DT-trace (blocks/trace.rs:231-416; engine.hpp dt_trace_block) -------------------------------------------------------
+// Before a block is re-filled, a diagonal-transition search runs backwards from `to` through the block: level g holds, per
+// diagonal d, the smallest column reachable with g edits (then extended left along matches); a diagonal that reaches the
+// block's checkpoint column with the right value ends the block.  One lane per diagonal; the furthest-reaching columns of the
+// current and the next level, the (extension, parent) table for the walk back, and the block's slices of a and b live in the
+// wavefront's LDS slice.  Every decision follows the host code's order: candidates from d - 1, d, d + 1 with strict `<`,
+// success at the lowest d, the midpoint and max_g early-outs, fr_drop pruning from both ends.
+constexpr int kDtMaxG = 40;
+struct DtLds {
+    int32_t cur[2 * kDtMaxG + 8], nxt[2 * kDtMaxG + 8];  // column per diagonal, index d + kDtMaxG + 2
+    uint16_t tbl[(kDtMaxG + 1) * (kDtMaxG + 1) + 3];       // ext | (parent_d + 1) << 12 at g*g + g + d
+    int32_t chain[kDtMaxG + 2];
+    uint32_t aw[(8 + 256 + 8) / 4];                        // 8 bytes of headroom, then a[i0 .. st_i)
+    uint32_t bw[(8 + 256 + kDtMaxG + 24) / 4];             // 8 bytes of headroom, then b[b_lo .. st_j)
+};
+constexpr int32_t kDtInf = 0x7FFFFFFF;
+
+template <bool DT>
 __global__ __launch_bounds__(64 * kStripBlockWaves) void trace_kernel(const TraceJob* __restrict__ jobs, int npairs, uint32_t* err) {
     const int pair = (int)rfl((uint32_t)(blockIdx.x * kStripBlockWaves + (threadIdx.x >> 6)));
     if (pair >= npairs) return;
     const int lane = (int)(threadIdx.x & 63);
     const TraceJob tj = jobs[pair];
+    extern __shared__ unsigned char pa_trace_lds[];
+    DtLds& L = *reinterpret_cast<DtLds*>(pa_trace_lds + (size_t)(threadIdx.x >> 6) * sizeof(DtLds));
     const gcu8 a = (gcu8)tj.a;
     const gcu8 b = (gcu8)tj.b;
     const gu32 cig = (gu32)tj.cigar;
@@ -130,6 +151,191 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void trace_kernel(const Trac
             g -= to_i;
             to_i = 0;
             break;
+        }
+        // ---- DT-trace through the block, when it has more than one column left (trace.rs:51-75) ----
+        if (DT && tj.dt_max_g > 0 && !(f_i0 < to_i && to_i <= f_i1)) {
+            const int i0 = ((to_i - 1) >> 8) << 8;
+            if (i0 < to_i - 1) {
+                const int G = tj.dt_max_g, drop = tj.dt_fr_drop;
+                const int st_i = to_i, st_j = to_j, cols = st_i - i0;
+                const gcu32 ck = ckpt_col(i0);
+                const int b_lo = st_j - cols - G - 1 > 0 ? st_j - cols - G - 1 : 0;
+                {
+                    uint8_t* awb = reinterpret_cast<uint8_t*>(L.aw) + 8;
+                    uint8_t* bwb = reinterpret_cast<uint8_t*>(L.bw) + 8;
+                    for (int k = lane; k < cols; k += 64) awb[k] = a[i0 + k];
+                    for (int k = lane; k < st_j - b_lo; k += 64) bwb[k] = b[b_lo + k];
+                }
+                __builtin_amdgcn_wave_barrier();
+                // extension to the left along matches (trace.rs:443-500), all lanes at once, four characters per round: the dword
+                // that ENDS at the current character (two aligned LDS words and a byte funnel shift), most significant byte first
+                auto extend = [&](int& i, int& j, bool on) -> int {
+                    int cnt = 0;
+                    bool go = on && i > i0 && j > 0;
+                    while (__ballot(go) != 0) {
+                        if (go) {
+                            const int qa = i - 1 - i0 + 8 - 3, qb = j - 1 - b_lo + 8 - 3;  // byte offsets of the dwords (>= 5: headroom)
+                            const uint32_t va = __builtin_amdgcn_alignbyte(L.aw[(qa >> 2) + 1], L.aw[qa >> 2], (uint32_t)(qa & 3));
+                            const uint32_t vb = __builtin_amdgcn_alignbyte(L.bw[(qb >> 2) + 1], L.bw[qb >> 2], (uint32_t)(qb & 3));
+                            const uint32_t x = va ^ vb;
+                            int run = x ? (__builtin_clz(x) >> 3) : 4;
+                            const int room = i - i0 < j ? i - i0 : j;
+                            run = run < room ? run : room;
+                            i -= run;
+                            j -= run;
+                            cnt += run;
+                            go = run == 4 && i > i0 && j > 0;
+                        }
+                    }
+                    return cnt;
+                };
+                // prev_block.index(j) = value at (i0, j): one prefix over the whole column per block (as the re-fill needs for its
+                // top-left value), then only the words between
+                const int vj0 = (st_j - cols - G > 0 ? st_j - cols - G : 0) & ~63;
+                int32_t vbase = 0;
+                bool vbase_ok = false;
+                auto value_at = [&](int j) -> int32_t {
+                    if (ck == nullptr) return i0 + j;
+                    if (!vbase_ok) {
+                        vbase = i0 + column_prefix(ck, vj0, lane);
+                        vbase_ok = true;
+                    }
+                    return vbase + column_prefix(ck + (size_t)(vj0 >> 6) * 4, j - vj0, lane);
+                };
+                int found_g = -1, found_d = 0;
+                // level 0
+                {
+                    int i = st_i, j = st_j;
+                    const int cnt = extend(i, j, lane == 0);
+                    if (lane == 0) {
+                        L.cur[G + 2] = i;
+                        L.tbl[0] = (uint16_t)(cnt | (1 << 12));
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const int i_f = (int)rfl((uint32_t)i), j_f = (int)rfl((uint32_t)j);
+                    if (i_f == i0 && j_f >= 0 && value_at(j_f) == g) found_g = 0;
+                }
+                int lvl = 0, d_lo = 0, d_hi = 0;
+                bool dt_fail = false;
+                int32_t* cur = L.cur;  // furthest-reaching columns of level lvl / lvl + 1, swapped after every level
+                int32_t* nxt = L.nxt;
+                while (found_g < 0 && !dt_fail) {
+                    __builtin_amdgcn_wave_barrier();
+                    const int ng = lvl + 1, nlo = d_lo - 1, nhi = d_hi + 1;
+                    int32_t min_fr = kDtInf, min_i = kDtInf;
+                    for (int base = nlo; base <= nhi && found_g < 0; base += 64) {
+                        const int e = base + lane;
+                        const bool mine = e <= nhi;
+                        // expand (trace.rs:351-364): candidates in the host's order, strict `<`
+                        int32_t bi = kDtInf, bpd = 0;
+                        if (mine) {
+                            if (e - 1 >= d_lo && e - 1 <= d_hi) {
+                                const int32_t y = cur[e - 1 + G + 2];
+                                if (y < bi) {
+                                    bi = y;
+                                    bpd = -1;
+                                }
+                            }
+                            if (e >= d_lo && e <= d_hi) {
+                                const int32_t y = cur[e + G + 2] - 1;
+                                if (y < bi) {
+                                    bi = y;
+                                    bpd = 0;
+                                }
+                            }
+                            if (e + 1 >= d_lo && e + 1 <= d_hi) {
+                                const int32_t y = cur[e + 1 + G + 2] - 1;
+                                if (y < bi) {
+                                    bi = y;
+                                    bpd = 1;
+                                }
+                            }
+                        }
+                        // extend (trace.rs:370-385)
+                        const bool reach = mine && bi < kDtInf - 4 * kDtMaxG;
+                        int i = bi, j = reach ? st_j - (st_i - bi) - e : 0;
+                        const int cnt = extend(i, j, reach);
+                        if (mine) {
+                            nxt[e + G + 2] = reach ? i : bi;
+                            L.tbl[ng * ng + ng + e] = (uint16_t)((reach ? cnt : 0) | ((bpd + 1) << 12));
+                        }
+                        // a diagonal at the checkpoint column with the right value ends the block: the lowest d first
+                        uint64_t cand = __ballot(reach && i == i0 && j >= 0);
+                        while (cand) {
+                            const int l = __builtin_ctzll(cand);
+                            cand &= cand - 1;
+                            const int jl = __shfl(j, l, 64);
+                            if (value_at(jl) == g - ng) {
+                                found_g = ng;
+                                found_d = base + l;
+                                break;
+                            }
+                        }
+                        if (reach) {
+                            min_fr = 2 * i - e < min_fr ? 2 * i - e : min_fr;
+                            min_i = i < min_i ? i : min_i;
+                        }
+                    }
+                    if (found_g >= 0) break;
+                    lvl = ng;
+                    d_lo = nlo;
+                    d_hi = nhi;
+                    {
+                        int32_t* t = cur;
+                        cur = nxt;
+                        nxt = t;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lvl == G / 2) {  // trace.rs:388-391
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const int32_t a2 = __shfl_xor(min_i, o, 64);
+                            min_i = a2 < min_i ? a2 : min_i;
+                        }
+                        if (min_i > (i0 + st_i) / 2) dt_fail = true;
+                    }
+                    if (lvl == G) dt_fail = true;
+                    if (!dt_fail && drop > 0) {
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const int32_t a1 = __shfl_xor(min_fr, o, 64);
+                            min_fr = a1 < min_fr ? a1 : min_fr;
+                        }
+                    }
+                    if (!dt_fail && drop > 0) {  // trace.rs:396-413
+                        auto bad = [&](int d) -> bool {
+                            const int32_t fi = cur[d + G + 2];
+                            return fi <= i0 || (int64_t)2 * fi - d > (int64_t)min_fr + drop;
+                        };
+                        while (d_lo < d_hi && bad(d_lo)) d_lo += 1;  // (uniform: every lane reads the same LDS words)
+                        while (d_lo < d_hi && bad(d_hi)) d_hi -= 1;
+                        if (d_lo > d_hi) dt_fail = true;
+                    }
+                }
+                if (found_g >= 0) {
+                    // walk back through the table (trace.rs:274-314); the elements go out from the END of the alignment
+                    int dk = found_d;
+                    for (int k = found_g; k >= 0; --k) {
+                        if (lane == 0) L.chain[k] = dk;
+                        dk += (int)(L.tbl[k * k + k + dk] >> 12) - 1;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    for (int k = 0; k <= found_g; ++k) {
+                        const int d = L.chain[k];
+                        const uint32_t ext = L.tbl[k * k + k + d] & 0xFFFu;
+                        if (ext > 0) emit(kOpMatch, ext);
+                        if (k < found_g) {
+                            const int dn = L.chain[k + 1];
+                            const int pd = (int)(L.tbl[(k + 1) * (k + 1) + (k + 1) + dn] >> 12) - 1;
+                            emit(pd == -1 ? kOpIns : (pd == 0 ? kOpSub : kOpDel), 1);
+                        }
+                    }
+                    g -= found_g;
+                    to_i = i0;
+                    to_j = st_j - cols - found_d;
+                    continue;
+                }
+            }
         }
         // ---- re-fill when the walk has left the filled columns (trace.rs:83-125) ----
         if (!(f_i0 < to_i && to_i <= f_i1) && to_i == n && ((n - 1) & 255) == 0) {

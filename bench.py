@@ -6,8 +6,8 @@ divergence, full bit-parallel DP, cost only (configs[1], "C2").
 
 A *step* is one pass of the hot path over one batch of synthetic pairs that is already resident in HBM
 as ASCII: BitProfile build kernels -> clear hand-off granules -> the strip kernel (every 64-lane strip
-of every pair) -> read the edit distances back.  `--pairs P` sets the batch per GPU (default 4096 =
-four pairs per SIMD, where one wavefront runs a whole pair; P=1 is the literal single-pair C2 case, which
+of every pair) -> read the edit distances back.  `--pairs P` sets the batch per GPU (default 8192 =
+eight pairs per SIMD, four of them resident at a time, where one wavefront runs a whole pair; P=1 is the literal single-pair C2 case, which
 is latency bound on ~49 chained wavefronts and is reported next to the batch number as `single_pair`).
 
     python bench.py --gpus 1 --steps K --warmup W
@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=4096, help="independent pairs per GPU per step")
+    ap.add_argument("--pairs", type=int, default=8192, help="independent pairs per GPU per step")
     ap.add_argument("--seq-len", dest="n", type=int, default=100_000, help="sequence length (bp)")
     ap.add_argument("--div", type=float, default=0.05, help="divergence (edit rate)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -289,6 +289,16 @@ def main():
             "host_engine_fallbacks": bt.trace_fallbacks(),
         }
         bt.close()
+        # the same batch with the `simple` preset's traceback options (DT-trace through every block, re-fill where it gives up)
+        tp = pa.AstarPa2Params.simple()
+        tp.domain, tp.doubling = "full", "none"
+        try:
+            bd = pa.Batch(c4, trace=True, trace_params=tp)
+            bd.align()
+            out["c4_batch_align"]["dt_trace_kernel_ms"] = round(min(bd.align()[3] for _ in range(3)), 3)
+            bd.close()
+        except Exception as e:  # (reporting only)
+            out["c4_batch_align"]["dt_trace_kernel_ms"] = f"failed: {e}"
 
     # ---- PCIe-inclusive rate of the headline workload: host buffers -> device layout -> one pass (never `value`) ----
     if world == 1:

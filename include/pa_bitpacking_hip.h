@@ -112,6 +112,13 @@ void pa_batch_destroy(pa_batch* plan);
  * reaches a state the reference itself would panic on, is redone by the host engine transparently. */
 pa_batch* pa_batch_create_trace(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b,
                                 const size_t* b_len, size_t pairs);
+/* The same with the traceback options of trace_params->front (struct pa_astarpa2_params, pa_astarpa2.h): with dt_trace set,
+ * every block is first tried with the diagonal-transition trace (blocks/trace.rs:231-416; max_g <= 40, fr_drop) and re-filled
+ * only where that gives up -- the result is what pa_align(.., params, trace = 1, ..) returns for Full-domain params with that
+ * `front`, e.g. the `simple` preset's { sparse, dt_trace, max_g = 40, fr_drop = 10 }.  NULL = pa_batch_create_trace. */
+struct pa_astarpa2_params;
+pa_batch* pa_batch_create_trace_params(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len,
+                                       size_t pairs, const struct pa_astarpa2_params* trace_params);
 int pa_batch_align(pa_batch* plan, int32_t* cost_out, char** cigar_out, float* forward_ms, float* trace_ms);
 /* Pairs (summed over all pa_batch_align calls of this plan) whose traceback was redone by the host engine. */
 size_t pa_batch_trace_fallbacks(const pa_batch* plan);

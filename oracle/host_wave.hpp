@@ -122,6 +122,7 @@ struct HostWave {
     static void add_u64(uint64_t* p, uint64_t v) { __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
     static void nap(uint32_t) { std::this_thread::yield(); }
     static uint64_t clock() { return 0; }
+    static void stretch_marker() {}
     static void drain_stores() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
     static uint32_t ticket(uint32_t* p) { return __atomic_fetch_add(p, 1u, __ATOMIC_ACQ_REL); }
 

@@ -185,3 +185,45 @@ def test_concurrent_host_threads_through_the_c_abi(pa, oracle):
     assert all(c == want_costs for c in out["batch"])
     assert all(c.tolist() == want_costs for c, _ in out["trace"])
     assert all(oracle.cigar_verify(g, x, y) == w for _, gs in out["trace"] for g, (x, y), w in zip(gs, pairs, want_costs))
+
+
+def dt_params(oracle):
+    """Full-domain forward pass, the `simple` preset's traceback options (params.rs:70-96: dt_trace, max_g 40, fr_drop 10)."""
+    return oracle.make_params(domain="full", heuristic="none", doubling="none", block_width=256, sparse=True,
+                              incremental_doubling=False, dt_trace=True)
+
+
+def check_dt(pa, oracle, pairs):
+    from tests.test_gpu_engine import gpu_params
+
+    prm = dt_params(oracle)
+    batch = pa.Batch(pairs, trace=True, trace_params=gpu_params(pa, prm))
+    costs, cigars, _, trace_ms = batch.align()
+    for (a, b), c, cg in zip(pairs, costs, cigars):
+        want_cost, want_cigar, _ = oracle.cpu_align(a, b, prm)
+        assert c == want_cost, (len(a), len(b))
+        assert cg == want_cigar, (len(a), len(b), cg[:80], want_cigar[:80])
+    assert batch.trace_fallbacks() == 0
+    batch.close()
+    return trace_ms
+
+
+def test_dt_trace_small_and_boundaries(pa, oracle):
+    """Device-side DT-trace (blocks/trace.rs:231-416) in the batched traceback: cost and CIGAR string equal the engine over the
+    CPU oracle kernels with the same `front` -- which takes the diagonal-transition path wherever it succeeds and re-fills the
+    block where it gives up (max_g, the midpoint early-out, fr_drop)."""
+    pairs = list(PA_TEST_PAIRS)
+    for n in (1, 2, 63, 64, 65, 255, 256, 257, 258, 511, 512, 513, 769, 1000, 1025, 2049):
+        for e in (0.0, 0.05, 0.2):
+            pairs.append(gen_pair(n, e, seed=n * 13 + int(100 * e)))
+    pairs += [(b"", b""), (b"ACGT", b""), (b"", b"ACGTA"), (b"A", b"A"), (b"A", b"C")]
+    check_dt(pa, oracle, pairs)
+
+
+def test_dt_trace_divergence_mix_and_indels(pa, oracle):
+    a = rand_seq(3000, seed=5)
+    pairs = [gen_pair(10_000, e, seed=300 + i) for i, e in enumerate((0.01, 0.03, 0.05, 0.08, 0.10, 0.12, 0.15, 0.25, 0.4))]
+    pairs += [(a, a[:1000] + a[1400:]), (a[:1000] + a[1400:], a), (a, a[:700] + rand_seq(300, seed=6) + a[700:]),
+              (rand_seq(700, seed=1), rand_seq(2300, seed=2)), (rand_seq(2300, seed=3), rand_seq(70, seed=4)), (a, a)]
+    pairs += [gen_pair(n, e, seed=n + 7) for n in (5000, 20_000, 40_000) for e in (0.02, 0.1)]
+    check_dt(pa, oracle, pairs)

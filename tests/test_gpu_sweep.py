@@ -27,10 +27,16 @@ def both(pa, oracle, a, b, oc, trace=True):
 
     want = oracle.cpu_align(a, b, oc, trace=trace)
     cost, cigar, stats = gpu_params(pa, oc).make_aligner(trace).align_with_stats(a, b)
-    assert cost == want[0]
-    assert cigar == want[1]
-    if trace:  # (the reference's cost-only path keeps ONE block whose fixed range only grows; the sweep runs the traced band)
+    if trace:
+        assert cost == want[0]
+        assert cigar == want[1]
         assert {k: stats[k] for k in KEYS} == {k: want[2][k] for k in KEYS}
+    else:
+        # The reference's cost-only path keeps ONE block whose fixed range only grows (blocks.rs:245-270) and can end on an upper
+        # bound (tests/tools/fuzz_sweep.py found SH returning 11353 for a distance of 11325); the sweep always runs the traced
+        # band: its cost-only answer is the distance itself.
+        assert cigar is None
+        assert cost == oracle.nw_cost(a, b, True) <= want[0]
     return cost, cigar, stats
 
 

@@ -32,10 +32,15 @@ def both(o, a, b, prm, trace=True, nwaves=16):
     want = o.cpu_align(a, b, prm, trace=trace)
     rc, cost, cigar, stats, info = o.sweep_emu_align(a, b, prm, trace=trace, nwaves=nwaves)
     assert rc == 0, info
-    assert cost == want[0]
-    assert cigar == want[1]
-    if trace:  # (the reference's cost-only path keeps ONE block whose fixed range only grows; the sweep runs the traced band)
+    if trace:
+        assert cost == want[0]
+        assert cigar == want[1]
         assert {k: stats[k] for k in KEYS} == {k: want[2][k] for k in KEYS}
+    else:
+        # The reference's cost-only path keeps ONE block whose fixed range only grows (blocks.rs:245-270) and can end on an upper
+        # bound (seen with SH: 11353 for a distance of 11325); the sweep always runs the traced band and returns the distance.
+        assert cigar is None or cigar == ""
+        assert cost == o.nw_cost(a, b, True) <= want[0]
     return cost
 
 

@@ -444,6 +444,18 @@ struct SweepPool {
     static constexpr int kSlots = 6;
     SweepSlot slots[kSlots];
     DeviceBuf d_merged[2], d_sh, d_recs, d_offs, d_pack;
+    // hipFree waits for the whole device -- with passes in flight that serialises them (C5 cold: 2.7 s instead of 1.x).  A slot
+    // buffer that has to grow while other passes run is therefore replaced, and the old allocation freed when nothing is in flight.
+    std::vector<void*> graveyard;
+    void bury(DeviceBuf& b) {
+        if (b.ptr) graveyard.push_back(b.ptr);
+        b.ptr = nullptr;
+        b.size = 0;
+    }
+    void free_graveyard() {
+        for (void* q : graveyard) (void)hipFree(q);
+        graveyard.clear();
+    }
     hipStream_t ctl = nullptr;  // cancel words go out here, past the running passes
     void* h_pin = nullptr;
     size_t h_pin_size = 0;
@@ -458,6 +470,7 @@ struct SweepPool {
                  hip_ok(hipHostMalloc((void**)&sl.h_status, sizeof(sweep::Status), hipHostMallocDefault), "hipHostMalloc");
     }
     ~SweepPool() {
+        free_graveyard();
         if (h_pin) (void)hipHostFree(h_pin);
         for (SweepSlot& sl : slots) {
             if (sl.h_status) (void)hipHostFree(sl.h_status);
@@ -531,20 +544,26 @@ struct HipSweepLauncher {
     // the band covers a fraction of them at a time), so somewhat more than one per SIMD is fine; far more would only slow
     // the passes that matter.
     int wave_budget() const {
-        static const int budget = std::getenv("PA_SWEEP_WAVE_BUDGET") ? std::atoi(std::getenv("PA_SWEEP_WAVE_BUDGET")) : 1024;
+        static const int budget = std::getenv("PA_SWEEP_WAVE_BUDGET") ? std::atoi(std::getenv("PA_SWEEP_WAVE_BUDGET")) : 1600;  // (C5: 1024 -> 1.9 s, 1600 -> 1.5 s, 4096 -> 4.9 s)
         return budget;
     }
 
     // bytes of a zero-initialised tagged buffer: cleared only when it is new (tags of older passes never match)
     void reserve_tagged(DeviceBuf& b, size_t bytes, hipStream_t st) {
-        bool grew = false;
-        if (!b.reserve(bytes, &grew)) hip_fail("hipMalloc");
-        if (grew && !hip_ok(hipMemsetAsync(b.ptr, 0, b.size, st), "memset")) hip_fail("memset");
+        if (reserve_no_sync(b, bytes) && !hip_ok(hipMemsetAsync(b.ptr, 0, b.size, st), "memset")) hip_fail("memset");
+    }
+    // grow-only, never a hipFree (see SweepPool::graveyard); true when a new, uninitialised buffer was allocated
+    bool reserve_no_sync(DeviceBuf& b, size_t bytes) {
+        if (b.ptr && b.size >= bytes) return false;
+        pool.bury(b);
+        if (!b.alloc(bytes + bytes / 4 + 256)) hip_fail("hipMalloc");
+        return true;
     }
 
     void begin_pair(int32_t n_, int32_t m_, int32_t nblk_, const int32_t* sh, bool tr) {
         using namespace sweep;
         if (!pool.ok) hip_fail("sweep pool");
+        pool.free_graveyard();  // (nothing is in flight between pairs)
         n = n_;
         m = m_;
         nblk = nblk_;
@@ -604,7 +623,8 @@ struct HipSweepLauncher {
         if (gran_bytes + col_bytes + pr_bytes > (size_t)40 << 30) throw SweepFallback("sweep buffers too large", -3);
         reserve_tagged(sl.d_start, (size_t)geo.nstrips * 8, sl.s);
         reserve_tagged(sl.d_pring, pr_bytes, sl.s);
-        if (!sl.d_gran.reserve(gran_bytes) || !sl.d_col.reserve(col_bytes)) hip_fail("hipMalloc");
+        (void)reserve_no_sync(sl.d_gran, gran_bytes);
+        (void)reserve_no_sync(sl.d_col, col_bytes);
         if (!hip_ok(hipMemsetAsync(sl.d_gran.ptr, 0, gran_bytes, sl.s), "memset granules")) hip_fail("memset");
 
         InitArgs ia;

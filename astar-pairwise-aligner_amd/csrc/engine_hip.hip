@@ -717,13 +717,13 @@ struct HipSweepLauncher {
     }
 
     // Give up every launched pass behind `seq` and wait until they (and their merges) are gone.
-    void cancel_after(int seq) {
+    void cancel_after(int seq, bool wait = true) {
         bool any = false;
         for (SweepSlot& sl : pool.slots)
             if (sl.live && sl.seq > seq) {
                 any = hip_ok(hipMemsetD32Async((hipDeviceptr_t)sl.cancel(), (int)sl.pass, 1, pool.ctl), "cancel") || any;
             }
-        if (!any) return;
+        if (!any || !wait) return;
         (void)hipStreamSynchronize(pool.ctl);
         for (int q = seq + 1; q <= seq + SweepPool::kSlots; ++q) {  // in launch order
             SweepSlot& sl = slot_of(q);

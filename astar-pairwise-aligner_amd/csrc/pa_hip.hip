@@ -1387,14 +1387,12 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
         // Both need every strip resident (at most four wavefronts per SIMD at <= 128 VGPRs); beyond that strips queue in ticket
         // order and only the priority rotation is kept.
         static const bool no_pace = getenv("PA_STRIP_NO_PACE") != nullptr;
-        static const int prio = getenv("PA_STRIP_PRIO") ? atoi(getenv("PA_STRIP_PRIO")) : 3;  // 0 = off, 3 = rotate (1, 2: experiments)
-        static const int lag = getenv("PA_STRIP_LAG") ? atoi(getenv("PA_STRIP_LAG")) : 0;
+        static const bool no_rotate = getenv("PA_STRIP_NO_ROTATE") != nullptr;
         const size_t simds = (size_t)(g_device_props_cus > 0 ? g_device_props_cus : 256) * 4;
         int tops = 0;
         for (const StripJob& j : p->jobs) tops += j.hin_gran == nullptr;
         for (StripJob& j : p->jobs) {
-            if (p->jobs.size() > simds) j.flags |= (prio & 3) << 1;
-            if (lag) j.flags |= kJobLag;
+            if (p->jobs.size() > simds && !no_rotate) j.flags |= kJobRotatePrio;
             if (!no_pace && p->jobs.size() > simds && p->jobs.size() <= 4 * simds && j.hin_gran == nullptr && tops > 1) {
                 j.flags |= kJobPace;
                 j.ckpt = p->d_misc.as<uint32_t>() + 4;  // the u64 progress counter (zeroed with the ticket before every pass)

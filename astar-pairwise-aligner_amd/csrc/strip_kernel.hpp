@@ -94,17 +94,13 @@ struct StripJob {
 };
 enum : int32_t {
     kJobVInitOne = 1,
-    kJobLag = 8,       // chained strips: a strip that had to poll for granule q keeps waiting until granule q + 4 is there too, so
-                       // that its next prefetches (issued one chunk ahead) hit instead of polling again at every chunk
     kJobLog = 16,      // diagnostics (cost-only strips): `values` points at 8 words that receive HW_ID, XCC_ID, start and end
                        // time and the number of chunks that had to poll (PA_STRIP_WAVELOG)
     kJobPace = 32,     // top strip of a pair in a chained batch (cost-only): `ckpt` points at a u64 counter that every such strip
                        // increments once per chunk, `ckpt_stride` = number of such strips; a strip more than kPaceLead chunks
                        // ahead of the average naps until the others caught up (bounded), one that finished adds kPaceDone so
                        // that nobody waits for it
-    kJobPrioMask = 6,  // chained strips: 1 = a strip that found its granule ready (it is behind its producer) raises its issue
-                       // priority, one that had to poll lowers it; 2 = additionally the top strip of a chain runs at the
-                       // highest priority.  Wavefronts of a SIMD are otherwise served oldest first.
+    kJobRotatePrio = 2,  // chained strips sharing SIMDs: rotate the issue priority chunk by chunk (see the chunk loop)
 };
 static_assert(sizeof(StripJob) == 136, "StripJob layout");
 
@@ -357,11 +353,6 @@ __device__ __attribute__((noinline)) void pace_top_strip(const uint32_t* counter
         ghi = rfl((uint32_t)(g >> 32));
     }
 }
-__device__ __attribute__((noinline)) bool wait_granule_ahead(const uint64_t* gran, int q) {
-    uint32_t lo, hi;
-    return resolve_granule<false>((gcu64)gran, 0, q, lo, hi);
-}
-
 // Process one strip.  On a spin timeout the error word is set and the strip stops early.
 // K = 32-row subwords per lane: the strip covers 64*K subwords = 32*K reference words.
 // LOCAL: the granules are produced and consumed by the SAME wavefront (pair_kernel, trace_kernel): workgroup-scope
@@ -500,8 +491,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
                __builtin_popcount(vlo & 0x55555555u) - __builtin_popcount(vhi & 0x55555555u);
     };
 
-    if (!LOCAL && ((job.flags & kJobPrioMask) >> 1) >= 2 && !has_gran) __builtin_amdgcn_s_setprio(3);
-    const bool extras = (job.flags & (kJobPrioMask | kJobLag | kJobPace | kJobLog)) != 0;
+    const bool extras = (job.flags & (kJobRotatePrio | kJobPace | kJobLog)) != 0;
     const uint32_t prio_slot = (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 4);  // HW_ID.wave_id: the slot on this SIMD
     const uint64_t log_t0 = (!FILL && (job.flags & kJobLog)) ? wall_clock64() : 0;
     uint32_t log_polled = 0;
@@ -544,24 +534,13 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
         uint32_t hin2 = has_hin ? (((hinb_next & 1u) << 31) | ((hinb_next & 2u) << 29)) : 0x80000000u;
         if (q < C && has_gran && (job.hin_n == 0 || q * 32 < job.hin_n)) {
             uint32_t glo, ghi;
-            if (!LOCAL && !FILL && extras) {  // (one test on the common path: none of this is on for a batch within one wavefront per SIMD)
-                if ((job.flags & kJobPrioMask) && (job.flags & kJobPrioMask) != kJobPrioMask) {
-                    if (rfl((uint32_t)gran_next) == 0u) __builtin_amdgcn_s_setprio(0);
-                    else __builtin_amdgcn_s_setprio(2);
-                }
-                if (rfl((uint32_t)gran_next) == 0u) ++log_polled;
-                if ((job.flags & kJobLag) && rfl((uint32_t)gran_next) == 0u) {
-                    const int lastg = (job.hin_n == 0 || job.hin_n >= n ? C : job.hin_n / 32) - 1;
-                    const int qa = q + 4 < lastg ? q + 4 : lastg;
-                    if (qa > q) alive = wait_granule_ahead(job.hin_gran, qa);
-                }
-            }
-            if (alive) alive = resolve_granule<LOCAL>(g_gran, gran_next, q, glo, ghi);
+            if (!LOCAL && !FILL && extras && rfl((uint32_t)gran_next) == 0u) ++log_polled;  // (diagnostics)
+            alive = resolve_granule<LOCAL>(g_gran, gran_next, q, glo, ghi);
             hin2 = ((upper ? ghi : glo) << sh) & 0xC0000000u;
             // every granule has exactly one consumer: hand it back zeroed, so the buffer needs clearing only once
             if (lane == 0) __hip_atomic_store((gu64)job.hin_gran + q, (uint64_t)0, __ATOMIC_RELAXED, kGranScope);
         }
-        if (!LOCAL && !FILL && extras && (job.flags & kJobPrioMask) == kJobPrioMask) {
+        if (!LOCAL && !FILL && extras && (job.flags & kJobRotatePrio)) {
             // rotate the issue priority chunk by chunk, with a phase per wave slot: the SIMD serves the highest priority
             // first and the OLDEST wavefront among equals, which starves the younger wavefronts of a shared SIMD -- and a
             // chain advances at the pace of its most starved strip

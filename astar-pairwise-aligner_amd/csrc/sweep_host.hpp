@@ -76,7 +76,7 @@ struct PassInit {
 //   launch_pass(seq, prev_seq, f_max, sparse_h, init)   start pass seq (asynchronous); it reads pass prev_seq's records while that
 //                                             runs, its merged records afterwards (prev_seq 0: no earlier pass)
 //   wait_pass(seq) -> Status                  block until pass seq is over and merged (passes are waited for in order)
-//   cancel_after(seq)                         give up every launched pass > seq and wait until they are gone
+//   cancel_after(seq, wait = true)            give up every launched pass > seq and (wait) block until they are gone
 //   read_merged(seq, k) -> BlockRec           block k's record after pass seq was merged (waited)
 //   read_blocks(seq, blocks)                  the blocks of pass seq for Blocks::trace
 //   pass_waves(f_max), wave_budget()          wavefronts a pass occupies / may be in flight together
@@ -326,7 +326,9 @@ class SweepAligner {
                 Status st;
                 try {
                     st = dev.wait_pass(cur.p.seq);
-                    if (st.state == kStDone && st.value <= cur.p.f_max) give_up();  // found: the passes behind it are not needed
+                    // found: the passes behind it are not needed.  (Waiting for them here costs less than letting them run into the
+                    // traceback's kernels: 14.4 against 14.9 ms on C3.)
+                    if (st.state == kStDone && st.value <= cur.p.f_max) give_up();
                     r = complete(cur.p, st);
                 } catch (...) {
                     give_up();

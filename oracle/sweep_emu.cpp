@@ -221,8 +221,8 @@ struct HostLauncher {
         }
         return sl.ctl.status;
     }
-    void cancel_after(int seq) {  // in launch order, so that every closer finds its predecessor's done word
-        for (int pass = 0; pass < 2; ++pass)
+    void cancel_after(int seq, bool wait = true) {  // in launch order, so that every closer finds its predecessor's done word
+        for (int pass = 0; pass < (wait ? 2 : 1); ++pass)
             for (int q = seq + 1; q <= seq + kSlots; ++q) {
                 Slot& sl = slot_of(q);
                 if (!sl.live || sl.seq <= seq) continue;

@@ -227,3 +227,16 @@ def test_dt_trace_divergence_mix_and_indels(pa, oracle):
               (rand_seq(700, seed=1), rand_seq(2300, seed=2)), (rand_seq(2300, seed=3), rand_seq(70, seed=4)), (a, a)]
     pairs += [gen_pair(n, e, seed=n + 7) for n in (5000, 20_000, 40_000) for e in (0.02, 0.1)]
     check_dt(pa, oracle, pairs)
+
+
+def test_trace_params_are_validated(pa, oracle):
+    from tests.test_gpu_engine import gpu_params
+
+    pairs = [gen_pair(500, 0.1, seed=1)]
+    bad = gpu_params(pa, oracle.make_params(domain="full", heuristic="none", doubling="none", block_width=256, sparse=True, dt_trace=True))
+    bad.front.max_g = 41  # the device table is sized for the presets' max_g = 40
+    with pytest.raises(pa.PaError):
+        pa.Batch(pairs, trace=True, trace_params=bad)
+    dense = gpu_params(pa, oracle.make_params(domain="full", heuristic="none", doubling="none", block_width=256, sparse=False))
+    with pytest.raises(pa.PaError):
+        pa.Batch(pairs, trace=True, trace_params=dense)

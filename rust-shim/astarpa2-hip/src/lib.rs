@@ -73,6 +73,15 @@ extern "C" {
                     cost_out: *mut i32, cigar_out: *mut *mut c_char, stats_out: *mut PaAstarPa2Stats) -> i32;
     pub fn astarpa_free_cigar(cigar: *mut u8);
     pub fn pa_last_error() -> *const c_char;
+    // many pairs at once (include/pa_bitpacking_hip.h): cost + CIGAR of every pair from one call, with the traceback options of
+    // `trace_params.front` (NULL: re-fill only), and the same sharded over several GPUs by host threads inside the library
+    pub fn pa_batch_create_trace_params(a: *const *const u8, a_len: *const usize, b: *const *const u8, b_len: *const usize, pairs: usize,
+                                        trace_params: *const PaAstarPa2Params) -> *mut core::ffi::c_void;
+    pub fn pa_batch_align(plan: *mut core::ffi::c_void, cost_out: *mut i32, cigar_out: *mut *mut c_char, forward_ms: *mut f32,
+                          trace_ms: *mut f32) -> i32;
+    pub fn pa_batch_destroy(plan: *mut core::ffi::c_void);
+    pub fn pa_batch_align_multi(a: *const *const u8, a_len: *const usize, b: *const *const u8, b_len: *const usize, pairs: usize,
+                                devices: *const i32, ndevices: i32, cost_out: *mut i32, cigar_out: *mut *mut c_char) -> i32;
 }
 
 /// The text form of `Cigar::to_string` (count omitted when 1; `=`, `X`, `I`, `D`; astarpa-c/example.cpp:16 `"=I4=X="`).

@@ -93,7 +93,9 @@ struct DtLds {
 constexpr int32_t kDtInf = 0x7FFFFFFF;
 
 template <bool DT>
-__global__ __launch_bounds__(64 * kStripBlockWaves) void trace_kernel(const TraceJob* __restrict__ jobs, int npairs, uint32_t* err) {
+// (wavefronts per SIMD asked of the register allocator, measured on C4: the DT variant 13.1 ms without the bound, 9.1 / 9.9 / 13.8 ms
+//  at 5 / 6 / 7; the re-fill variant 12.6 / 12.1 / 13.1 ms at 5 / 6 / 7)
+__global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kernel(const TraceJob* __restrict__ jobs, int npairs, uint32_t* err) {
     const int pair = (int)rfl((uint32_t)(blockIdx.x * kStripBlockWaves + (threadIdx.x >> 6)));
     if (pair >= npairs) return;
     const int lane = (int)(threadIdx.x & 63);

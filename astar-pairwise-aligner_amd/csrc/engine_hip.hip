@@ -423,11 +423,12 @@ static HipBackend& pooled_backend() {
 // buffers and stream; the merged block records of the completed passes alternate between two arrays.
 struct SweepSlot {
     DeviceBuf d_brec, d_trec, d_misc, d_start, d_pring, d_gran, d_col;
+    DeviceBuf d_merged;  // the block records of every earlier pass with this pass's on top (what the next pass reads once this one is over)
     hipStream_t s = nullptr;
     hipEvent_t merged_ev = nullptr;  // recorded behind the merge of the pass that ran here
     sweep::Status* h_status = nullptr;  // pinned
     // the pass that runs (or ran last) here
-    int seq = 0, mbuf = 0;
+    int seq = 0;
     uint32_t pass = 0;
     bool live = false;
     int32_t f_max = 0, waves = 0;
@@ -441,9 +442,12 @@ struct SweepSlot {
     sweep::Status* status() { return reinterpret_cast<sweep::Status*>(d_misc.as<uint8_t>() + 64); }
 };
 struct SweepPool {
-    static constexpr int kSlots = 6;
+    // a pass's records must outlive its successor, and a pass that is taken again (see sweep_host.hpp) follows a pass that was
+    // completed five launches earlier: two slots more than passes in flight
+    static constexpr int kSlots = 7;
+    static constexpr int kMaxInFlight = 5;
     SweepSlot slots[kSlots];
-    DeviceBuf d_merged[2], d_sh, d_recs, d_offs, d_pack;
+    DeviceBuf d_merged0, d_sh, d_recs, d_offs, d_pack;  // d_merged0: "no block exists yet" (what the first pass of a pair reads)
     // hipFree waits for the whole device -- with passes in flight that serialises them (C5 cold: 2.7 s instead of 1.x).  A slot
     // buffer that has to grow while other passes run is therefore replaced, and the old allocation freed when nothing is in flight.
     std::vector<void*> graveyard;
@@ -526,9 +530,9 @@ struct HipSweepLauncher {
     // correctness: passes are submitted in order and wait for their predecessors only.
     int max_in_flight() const {
         static const int depth = [] {
-            if (const char* e = std::getenv("PA_SWEEP_DEPTH")) return std::min(std::max(std::atoi(e), 1), SweepPool::kSlots - 1);
+            if (const char* e = std::getenv("PA_SWEEP_DEPTH")) return std::min(std::max(std::atoi(e), 1), SweepPool::kMaxInFlight);
             const char* q = std::getenv("GPU_MAX_HW_QUEUES");
-            return (q && std::atoi(q) >= 8) ? SweepPool::kSlots - 1 : 3;
+            return (q && std::atoi(q) >= 8) ? SweepPool::kMaxInFlight : 3;
         }();
         return depth;
     }
@@ -576,10 +580,11 @@ struct HipSweepLauncher {
                     if (b->ptr && !hip_ok(hipMemsetAsync(b->ptr, 0, b->size, be.s), "memset")) hip_fail("memset");
             pool.pass_id = 0;
         }
-        for (int k = 0; k < 2; ++k)
-            if (!pool.d_merged[k].reserve(recs * sizeof(BlockRec))) hip_fail("merged records");
-        if (!hip_ok(hipMemsetD32Async((hipDeviceptr_t)pool.d_merged[0].ptr, (int)kNone, recs * sizeof(BlockRec) / 4, be.s), "memset merged")) hip_fail("merged records");
+        if (!pool.d_merged0.reserve(recs * sizeof(BlockRec)) ||
+            !hip_ok(hipMemsetD32Async((hipDeviceptr_t)pool.d_merged0.ptr, (int)kNone, recs * sizeof(BlockRec) / 4, be.s), "memset merged"))
+            hip_fail("merged records");
         for (SweepSlot& sl : pool.slots) {
+            if (!sl.d_merged.reserve(recs * sizeof(BlockRec))) hip_fail("merged records");
             reserve_tagged(sl.d_brec, recs * sizeof(BRec), be.s);
             reserve_tagged(sl.d_trec, recs * sizeof(TRec), be.s);
             reserve_tagged(sl.d_misc, 1024, be.s);
@@ -597,8 +602,9 @@ struct HipSweepLauncher {
 
     sweep::BlockRec read_merged(int seq, int32_t k) {  // after wait_pass(seq)
         sweep::BlockRec r;
-        const int mb = seq == 0 ? 0 : slot_of(seq).mbuf;
-        if (!hip_ok(hipMemcpyAsync(&r, pool.d_merged[mb].as<sweep::BlockRec>() + k, sizeof(r), hipMemcpyDeviceToHost, be.s), "D2H rec") ||
+        const DeviceBuf& mb = seq == 0 ? pool.d_merged0 : slot_of(seq).d_merged;
+        if (seq != 0 && slot_of(seq).seq != seq) hip_fail("merged records of a pass whose slot was reused");
+        if (!hip_ok(hipMemcpyAsync(&r, mb.as<sweep::BlockRec>() + k, sizeof(r), hipMemcpyDeviceToHost, be.s), "D2H rec") ||
             !hip_ok(hipStreamSynchronize(be.s), "sync"))
             hip_fail("read_merged");
         return r;
@@ -609,10 +615,12 @@ struct HipSweepLauncher {
         SweepSlot& sl = slot_of(seq);
         if (sl.live) hip_fail("sweep slot busy");
         SweepSlot* pv = prev_seq ? &slot_of(prev_seq) : nullptr;
+        if (pv && (pv == &sl || pv->seq != prev_seq)) hip_fail("sweep slot of the previous pass was reused");
+        const bool pv_running = pv && pv->live;  // still in flight: read its records as they appear; else only its merged array
+        const BlockRec* merged_in = pv ? pv->d_merged.as<BlockRec>() : pool.d_merged0.as<BlockRec>();
         pool.pass_id += 1;
         sl.seq = seq;
         sl.pass = pool.pass_id;
-        sl.mbuf = pv ? 1 - pv->mbuf : 1;  // (before any pass the merged records are d_merged[0])
         sl.f_max = f_max;
         sl.geo = pass_geometry(n, m, f_max);
         const PassGeometry& geo = sl.geo;
@@ -659,10 +667,10 @@ struct HipSweepLauncher {
         c.sparse_h = sparse_h;
         c.sh_h = has_sh ? pool.d_sh.as<int32_t>() : nullptr;
         c.store_cols = trace ? 1 : 0;
-        c.d_old = pool.d_merged[1 - sl.mbuf].as<BlockRec>();
-        c.prev_brec = pv ? pv->d_brec.as<BRec>() : nullptr;
-        c.prev_pass = pv ? pv->pass : 0;
-        c.prev_done = pv ? pv->done() : sl.done();
+        c.d_old = merged_in;
+        c.prev_brec = pv_running ? pv->d_brec.as<BRec>() : nullptr;
+        c.prev_pass = pv_running ? pv->pass : 0;
+        c.prev_done = pv_running ? pv->done() : sl.done();
         c.cancel = sl.cancel();
         c.brec = sl.d_brec.as<BRec>();
         c.trec = sl.d_trec.as<TRec>();
@@ -690,9 +698,9 @@ struct HipSweepLauncher {
         }
         hipLaunchKernelGGL(sweep_kernel, dim3((unsigned)c.nwaves), dim3(64), 0, sl.s, c);
         // behind the pass: merge its records into the older ones (after the previous pass's merge), then the done word
-        if (pv && !hip_ok(hipStreamWaitEvent(sl.s, pv->merged_ev, 0), "hipStreamWaitEvent")) hip_fail("event");
-        hipLaunchKernelGGL(sweep_merge_kernel, dim3((unsigned)((nblk + 2 + 255) / 256)), dim3(256), 0, sl.s, sl.d_brec.as<BRec>(),
-                           pool.d_merged[1 - sl.mbuf].as<BlockRec>(), pool.d_merged[sl.mbuf].as<BlockRec>(), sl.status(), nblk);
+        if (pv_running && !hip_ok(hipStreamWaitEvent(sl.s, pv->merged_ev, 0), "hipStreamWaitEvent")) hip_fail("event");
+        hipLaunchKernelGGL(sweep_merge_kernel, dim3((unsigned)((nblk + 2 + 255) / 256)), dim3(256), 0, sl.s, sl.d_brec.as<BRec>(), merged_in,
+                           sl.d_merged.as<BlockRec>(), sl.status(), nblk);
         hipLaunchKernelGGL(sweep_done_kernel, dim3(1), dim3(1), 0, sl.s, sl.done(), sl.pass);
         if (!hip_ok(hipEventRecord(sl.merged_ev, sl.s), "hipEventRecord") || !hip_ok(hipGetLastError(), "sweep launch") ||
             !hip_ok(hipMemcpyAsync(sl.h_status, sl.status(), sizeof(Status), hipMemcpyDeviceToHost, sl.s), "D2H status"))

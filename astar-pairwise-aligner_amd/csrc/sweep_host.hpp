@@ -210,13 +210,13 @@ class SweepAligner {
     }
     // The rest of the pass once its status is known (in pass order).  nullopt = no path for this bound (domain.rs returns None).
     std::optional<std::pair<Cost, std::optional<engine::Cigar>>> complete(const Prepared& p, const Status& st) {
+        stats.block_stats.t_compute += engine::now_s() - p.t0;
+        if (st.state == kStAbort || st.state == kStTimeout || st.state == kStRunning)
+            throw SweepFallback(st.state == kStAbort ? "sweep pass aborted" : "sweep pass timed out", st.state == kStAbort ? st.value : -1);
         stats.block_stats.num_blocks += p.nd.d_num_blocks;
         stats.block_stats.unique_lanes += p.nd.d_unique_add - p.nd.d_unique_sub;
         stats.block_stats.computed_lanes += p.nd.d_computed;
         stats.block_stats.num_incremental_blocks += p.nd.d_incremental;
-        stats.block_stats.t_compute += engine::now_s() - p.t0;
-        if (st.state == kStAbort || st.state == kStTimeout || st.state == kStRunning)
-            throw SweepFallback(st.state == kStAbort ? "sweep pass aborted" : "sweep pass timed out", st.state == kStAbort ? st.value : -1);
         stats.block_stats.num_blocks += st.stats.num_blocks;
         stats.block_stats.unique_lanes += st.stats.unique_lanes;
         stats.block_stats.computed_lanes += st.stats.computed_lanes;

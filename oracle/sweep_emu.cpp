@@ -24,7 +24,7 @@ using pa_oracle_cpu::CpuBackend;
 namespace {
 
 struct HostLauncher {
-    static constexpr int kSlots = 4;
+    static constexpr int kSlots = 5;  // (two more than passes in flight, like the device launcher)
     const uint8_t *a, *b;
     int32_t n = 0, m = 0, nblk = 0;
     const int32_t* sh_h = nullptr;
@@ -35,11 +35,12 @@ struct HostLauncher {
     uint32_t spin_limit = 1u << 24;
     int32_t heur_kind = kHeurGap;
     std::vector<uint32_t> codes, prof;
-    std::vector<BlockRec> merged[2];
+    std::vector<BlockRec> merged0;  // "no block exists yet" 
     // One pass in flight: its own records and buffers, its wavefront threads, and a closer thread that merges its records
     // into the older ones and publishes the done word (what sweep_merge_kernel / sweep_done_kernel do behind the launch).
     struct Slot {
-        int seq = 0, prev_seq = 0, mbuf = 0;
+        int seq = 0, prev_seq = 0;
+        std::vector<BlockRec> merged;  // the earlier passes' records with this pass's on top
         uint32_t pass = 0;
         std::vector<BRec> brec;
         std::vector<TRec> trec;
@@ -72,7 +73,7 @@ struct HostLauncher {
         nblk = nblk_;
         sh_h = sh;
         trace = tr;
-        if (const char* e = std::getenv("PA_SWEEP_EMU_DEPTH")) in_flight = std::atoi(e) < 1 ? 1 : (std::atoi(e) > kSlots - 1 ? kSlots - 1 : std::atoi(e));
+        if (const char* e = std::getenv("PA_SWEEP_EMU_DEPTH")) in_flight = std::atoi(e) < 1 ? 1 : (std::atoi(e) > kSlots - 2 ? kSlots - 2 : std::atoi(e));
         codes.assign((size_t)(n + 15) / 16 + 16, 0);
         for (int32_t i = 0; i < n; ++i) {
             const uint8_t ch = a[i];
@@ -87,26 +88,31 @@ struct HostLauncher {
         BlockRec none;
         none.js = none.je = none.ojs = none.oje = none.fs = none.fe = kNone;
         none.top_val = none.bot_val = 0;
-        merged[0].assign((size_t)nblk + 2, none);
-        merged[1].assign((size_t)nblk + 2, none);
+        merged0.assign((size_t)nblk + 2, none);
         for (Slot& sl : slots) {
+            sl.merged.assign((size_t)nblk + 2, none);
             sl.ctl.cancel = 0;
             sl.done = 0;
             sl.brec.assign((size_t)nblk + 2, BRec{});
             sl.trec.assign((size_t)nblk + 2, TRec{});
         }
     }
-    BlockRec read_merged(int seq, int32_t k) { return seq == 0 ? merged[0][(size_t)k] : merged[slot_of(seq).mbuf][(size_t)k]; }
+    BlockRec read_merged(int seq, int32_t k) {
+        if (seq != 0 && slot_of(seq).seq != seq) std::abort();
+        return seq == 0 ? merged0[(size_t)k] : slot_of(seq).merged[(size_t)k];
+    }
 
     void launch_pass(int seq, int prev_seq, int32_t f_max, int32_t sparse_h, const PassInit& init) {
         Slot& sl = slot_of(seq);
-        if (sl.live) std::abort();  // (the aligner never has more than kSlots - 1 passes in flight)
+        if (sl.live) std::abort();  // (the aligner never has more than kSlots - 2 passes in flight)
         Slot* pv = prev_seq ? &slot_of(prev_seq) : nullptr;
+        if (pv && (pv == &sl || pv->seq != prev_seq)) std::abort();
+        const bool pv_running = pv && pv->live;
+        const std::vector<BlockRec>* merged_in = pv ? &pv->merged : &merged0;
         pass_id += 1;
         sl.seq = seq;
         sl.prev_seq = prev_seq;
         sl.pass = pass_id;
-        sl.mbuf = pv ? 1 - pv->mbuf : 1;  // (before any pass the merged records are merged[0])
         sl.geo = pass_geometry(n, m, f_max);
         const PassGeometry& geo = sl.geo;
         sl.strip_start.resize((size_t)geo.nstrips, 0);
@@ -148,10 +154,10 @@ struct HostLauncher {
         c.sparse_h = sparse_h;
         c.sh_h = sh_h;
         c.store_cols = trace ? 1 : 0;
-        c.d_old = merged[1 - sl.mbuf].data();
-        c.prev_brec = pv ? pv->brec.data() : nullptr;
-        c.prev_pass = pv ? pv->pass : 0;
-        c.prev_done = pv ? &pv->done : &sl.done;
+        c.d_old = merged_in->data();
+        c.prev_brec = pv_running ? pv->brec.data() : nullptr;
+        c.prev_pass = pv_running ? pv->pass : 0;
+        c.prev_done = pv_running ? &pv->done : &sl.done;
         c.cancel = &sl.ctl.cancel;
         c.brec = sl.brec.data();
         c.trec = sl.trec.data();
@@ -175,13 +181,13 @@ struct HostLauncher {
         for (int w = 0; w < c.nwaves; ++w) sl.waves.emplace_back([&c]() { wave_main<HostWave>(c); });
         // behind the pass: merge (after the previous pass's merge, like the stream-ordered kernels on the device), then the done word
         const uint64_t prev_pass_id = pv ? pv->pass : 0;
-        sl.closer = std::thread([this, &sl, pv, prev_pass_id]() {
+        sl.closer = std::thread([this, &sl, pv, pv_running, prev_pass_id, merged_in]() {
             for (auto& t : sl.waves) t.join();
-            if (pv)
+            if (pv_running)
                 while (__atomic_load_n(&pv->done, __ATOMIC_ACQUIRE) != prev_pass_id) std::this_thread::yield();
             const Status& st = sl.ctl.status;
-            const std::vector<BlockRec>& mo = merged[1 - sl.mbuf];
-            std::vector<BlockRec>& mn = merged[sl.mbuf];
+            const std::vector<BlockRec>& mo = *merged_in;
+            std::vector<BlockRec>& mn = sl.merged;
             const bool ended = st.state == kStDone || st.state == kStNoPath;
             for (int32_t k = 0; k <= nblk + 1; ++k) {
                 BlockRec d = mo[(size_t)k];

@@ -175,3 +175,4 @@ def test_pipelined_passes_equal_sequential_passes(oracle, monkeypatch):
         for rc, cost, cigar, stats in (r1, r2, r3):
             assert rc == 0 and (cost, cigar) == (want[0], want[1])
             assert {k: stats[k] for k in KEYS} == {k: want[2][k] for k in KEYS}
+

@@ -1122,7 +1122,7 @@ static void plan_banded_pair(pa_batch* p, size_t i, int32_t t, std::vector<Strip
 // as chained strips, where a pair's time is set by the columns along the diagonal (n steps of the step latency) and
 // low strips keep that latency low.  Strip height: minimise (strips x (strip rows + band width)) x step cost.
 static void choose_band_shape(pa_batch* p) {
-    static const double kLone[4] = {52.9, 76.5, 121.0, 210.0};
+    static const double kLone[4] = {52.9, 76.5, 103.0, 178.0};  // (k = 4, 8: eq words from LDS, 50 / 90 instead of 59 / 107 instructions)
     static const int kK[4] = {1, 2, 4, 8};
     const double simds = (double)(g_device_props_cus > 0 ? g_device_props_cus : 256) * 4.0;
     size_t live = 0;

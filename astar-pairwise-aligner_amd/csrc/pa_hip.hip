@@ -1000,7 +1000,7 @@ struct BatchShape {
 static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, size_t pairs) {
     // ns per strip step (measured, profiles/r02_runs): a wavefront alone on its SIMD; one of W fairly served wavefronts of a SIMD
     // (rotating issue priority + paced top strips, per wavefront and per W); chained strips queueing beyond residency
-    static const double kLone[4] = {52.9, 76.5, 121.0, 200.0}, kFair[4] = {40.0, 58.0, 82.0, 138.0}, kSatChain[4] = {50.8, 65.0, 100.0, 150.0};
+    static const double kLone[4] = {52.9, 76.5, 121.0, 200.0}, kFair[4] = {40.0, 66.0, 82.0, 138.0}, kSatChain[4] = {50.8, 65.0, 100.0, 150.0};
     static const double kShare[4] = {1.0, 0.85, 0.80, 0.78};  // per-wavefront step cost at 1, 2, 3, >= 4 wavefronts per SIMD
     static const int kK[4] = {1, 2, 4, 8};
     const double simds = (double)(g_device_props_cus > 0 ? g_device_props_cus : 256) * 4.0;

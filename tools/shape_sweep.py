@@ -14,7 +14,8 @@ base = [generate_pair(n, 0.05, seed=s + 1) for s in range(16)]
 for pairs in sizes:
     ps = [base[i % len(base)] for i in range(pairs)]
     row = []
-    for mode, k in [(None, None)] + [(m, k) for m in ("chain", "seq") for k in (2, 4, 8)]:
+    # (one wavefront per pair only makes sense with about a pair per SIMD: skip it for small batches, it takes minutes)
+    for mode, k in [(None, None)] + [(m, k) for m in ("chain", "seq") for k in (2, 4, 8) if m == "chain" or pairs * (n / 100000) >= 200]:
         for v in ("PA_BATCH_MODE", "PA_STRIP_K"):
             os.environ.pop(v, None)
         if mode:

@@ -337,6 +337,12 @@ class SweepAligner {
                 waves_in_flight -= cur.waves;
                 // assumption (b) for the passes launched behind this one
                 if (head < fl.size() && (int64_t)st.k_end + 1 < (len_before > 2 ? len_before : 2)) give_up();
+                // (tests: PA_SWEEP_TEST_GIVE_UP=k pretends that an assumption failed after every k-th pass, so that giving up,
+                //  cancelling and launching again from the real state run all the time; read per pair)
+                if (const char* e = std::getenv("PA_SWEEP_TEST_GIVE_UP")) {
+                    const int k = std::atoi(e);
+                    if (k > 0 && head < fl.size() && cur.p.seq % k == 0) give_up();
+                }
             }
             // ---- band.rs:100-182 ----
             if (r) {

@@ -131,3 +131,20 @@ def test_c5_10mbp_doubling_band(pa, oracle):
     costs, _ = pa.Batch([(a, b)], band=0.05).run()
     assert int(costs[0]) == cost
     assert dt < 8.0, dt
+
+
+@pytest.mark.parametrize("k", ["1", "2", "3"])
+def test_giving_up_speculative_passes_changes_nothing(pa, oracle, monkeypatch, k):
+    """tests/test_sweep_emu.py::test_giving_up_speculative_passes_changes_nothing on the device: after every k-th pass the
+    passes launched ahead are cancelled and launched again from the real state (streams, cancel words, slots, merged records)."""
+    monkeypatch.setenv("PA_SWEEP_TEST_GIVE_UP", k)
+    rng = random.Random(int(k))
+    vs = variants(oracle)
+    for _ in range(12):
+        name = rng.choice(list(vs))
+        n = rng.choice([rng.randint(500, 4000), rng.randint(4000, 40000)])
+        a, b = gen_pair(n, rng.choice([0.05, 0.15, 0.3, 0.5]), rng.randint(1, 10**6))
+        both(pa, oracle, a, b, vs[name], trace=rng.random() < 0.8)
+    a, b = gen_pair(100_000, 0.05, 1)
+    cost, cigar, stats = both(pa, oracle, a, b, oracle.params_simple())
+    assert cost == 4810

@@ -176,3 +176,21 @@ def test_pipelined_passes_equal_sequential_passes(oracle, monkeypatch):
             assert rc == 0 and (cost, cigar) == (want[0], want[1])
             assert {k: stats[k] for k in KEYS} == {k: want[2][k] for k in KEYS}
 
+
+def test_giving_up_speculative_passes_changes_nothing(oracle, monkeypatch):
+    """The passes launched ahead rest on two assumptions about the pass before them (sweep_host.hpp search()); when one fails they
+    are cancelled and the search goes on from the real state.  That almost never happens on its own, so PA_SWEEP_TEST_GIVE_UP makes
+    it happen after every k-th pass: cancel words, slots taken again by later passes, merged records of given-up passes -- the
+    results must not move."""
+    import random
+
+    rng = random.Random(21)
+    vs = variants(oracle)
+    monkeypatch.setenv("PA_SWEEP_EMU_DEPTH", "3")
+    for k in ("1", "2", "3"):
+        monkeypatch.setenv("PA_SWEEP_TEST_GIVE_UP", k)
+        for _ in range(20):
+            name = rng.choice(list(vs))
+            n = rng.choice([rng.randint(500, 4000), rng.randint(4000, 20000)])
+            a, b = gen_pair(n, rng.choice([0.05, 0.15, 0.3, 0.5]), rng.randint(1, 10**6))
+            both(oracle, a, b, vs[name], trace=rng.random() < 0.8)

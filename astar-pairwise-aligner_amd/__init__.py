@@ -7,7 +7,7 @@ this package is the thin host-side mirror of the reference's interfaces.  No CPU
 from . import _build, aligner, capi, generate  # noqa: F401
 from .aligner import (AstarPa2, AstarPa2Params, BlockParams, astarpa2_full, astarpa2_nw,  # noqa: F401
                       astarpa2_simple, c_abi_align)
-from .capi import (Batch, PaError, align_file, align_multi, compute, fill, profile_build, read_pairs, require_gpu, search,  # noqa: F401
+from .capi import (Batch, OperatorContext, PaError, align_file, align_multi, compute, fill, profile_build, read_pairs, require_gpu, search,  # noqa: F401
                    search_trace)
 
 

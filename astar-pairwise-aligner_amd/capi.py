@@ -23,6 +23,7 @@ EXPORTED_SYMBOLS = [
     "pa_batch_create_banded", "pa_batch_create_trace", "pa_batch_align", "pa_batch_trace_fallbacks", "pa_params_batch_align",
     "pa_pairs_read", "pa_pairs_count", "pa_pairs_get", "pa_pairs_free", "pa_write_results_csv", "pa_align_file",
     "pa_align", "pa_batch_align_multi", "pa_batch_create_trace_params",
+    "pa_bp_ctx_create", "pa_bp_ctx_compute", "pa_bp_ctx_fill", "pa_bp_ctx_destroy",
 ]
 
 _lib = None
@@ -75,6 +76,13 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_batch_create_banded.restype = vp
     L.pa_batch_create_trace.argtypes = [vp, vp, vp, vp, sz]
     L.pa_batch_create_trace.restype = vp
+    L.pa_bp_ctx_create.argtypes = [vp, sz, vp, sz]
+    L.pa_bp_ctx_create.restype = vp
+    L.pa_bp_ctx_compute.argtypes = [vp, C.c_int32, C.c_int32, sz, sz, vp, C.c_int, C.POINTER(C.c_int32)]
+    L.pa_bp_ctx_compute.restype = C.c_int
+    L.pa_bp_ctx_fill.argtypes = [vp, C.c_int32, C.c_int32, sz, sz, vp, vp, vp]
+    L.pa_bp_ctx_fill.restype = C.c_int
+    L.pa_bp_ctx_destroy.argtypes = [vp]
     L.pa_batch_create_trace_params.argtypes = [vp, vp, vp, vp, sz, vp]
     L.pa_batch_create_trace_params.restype = vp
     L.pa_batch_align.argtypes = [vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -213,6 +221,47 @@ def align_file(input_path: str, output_path: str) -> int:
     if rc != 0:
         raise PaError(f"pa_align_file rc={rc}: {last_error()}")
     return int(n.value)
+
+
+class OperatorContext:
+    """Device-resident operator handle (pa_bp_ctx_*): a, b, the profile and the stored h row stay on the GPU between calls."""
+
+    H_NONE, H_INPUT, H_UPDATE, H_OUTPUT = 0, 1, 2, 3
+
+    def __init__(self, a: bytes, b: bytes):
+        L = load()
+        self._keep = (a, b)
+        self._h = L.pa_bp_ctx_create(C.cast(C.c_char_p(a), C.c_void_p), len(a), C.cast(C.c_char_p(b), C.c_void_p), len(b))
+        if not self._h:
+            raise PaError(last_error())
+
+    def compute(self, i0: int, i1: int, w0: int, w1: int, v: np.ndarray, h_mode: int = 0) -> int:
+        """v: uint64[w1 - w0, 2] (p, m), updated in place; returns the sum of the bottom-row deltas."""
+        s = C.c_int32(0)
+        rc = load().pa_bp_ctx_compute(self._h, i0, i1, w0, w1, _p(v), h_mode, C.byref(s))
+        if rc != 0:
+            raise PaError(f"pa_bp_ctx_compute rc={rc}: {last_error()}")
+        return int(s.value)
+
+    def fill(self, i0: int, i1: int, w0: int, w1: int, v: np.ndarray):
+        """-> (values uint64[i1 - i0, w1 - w0, 2], bottom-row deltas int8[i1 - i0]); v updated in place."""
+        values = np.zeros((i1 - i0, w1 - w0, 2), np.uint64)
+        hb = np.zeros(max(i1 - i0, 1), np.int8)
+        rc = load().pa_bp_ctx_fill(self._h, i0, i1, w0, w1, _p(v), _p(values), _p(hb))
+        if rc != 0:
+            raise PaError(f"pa_bp_ctx_fill rc={rc}: {last_error()}")
+        return values, hb[: i1 - i0]
+
+    def close(self):
+        if self._h:
+            load().pa_bp_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def align_multi(pairs: list[tuple[bytes, bytes]], devices: list[int], trace: bool = True):

@@ -893,6 +893,66 @@ int align_hip(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, co
 
 using namespace pa;
 
+// ---- device-resident operator handles (route 2 of INTEGRATION.md: the reference's engine over HIP operators) ------------------
+// The sequences, the profile and the persistent h row of one pair stay on the GPU between calls; a call moves only the v
+// words of its rectangle.  This is HipBackend behind a C handle.
+struct pa_bp_ctx {
+    HipBackend be;
+    engine::BlockParams bp;
+};
+
+extern "C" pa_bp_ctx* pa_bp_ctx_create(const uint8_t* a, size_t n, const uint8_t* b, size_t m) {
+    if (n > (size_t)(1u << 30) || m > (size_t)(1u << 30)) {
+        set_error("sequence too long for i32 coordinates");
+        return nullptr;
+    }
+    std::unique_ptr<pa_bp_ctx> c(new (std::nothrow) pa_bp_ctx());
+    if (!c) {
+        set_error("out of memory");
+        return nullptr;
+    }
+    c->be.bind(a, n, b, m);
+    if (!c->be.ok) return nullptr;
+    try {
+        c->be.enable_h_row();
+    } catch (const engine::EnginePanic&) {
+        return nullptr;
+    }
+    return c.release();
+}
+
+extern "C" int pa_bp_ctx_compute(pa_bp_ctx* c, int32_t i0, int32_t i1, size_t w0, size_t w1, uint64_t* v, int h_mode, int32_t* sum_out) {
+    if (!c || i0 < 0 || i1 < i0 || i1 > c->be.n() || w1 < w0 || w1 > (size_t)((c->be.m() + 63) / 64) || (!v && w1 > w0) || h_mode < 0 || h_mode > 3) {
+        set_error("pa_bp_ctx_compute: bad arguments");
+        return PA_E_ARG;
+    }
+    static_assert(sizeof(engine::V) == 16, "V is (p: u64, m: u64)");
+    try {
+        const engine::Cost s = c->be.compute(i0, i1, w0, w1, reinterpret_cast<engine::V*>(v), (engine::HMode)h_mode, c->bp);
+        if (sum_out) *sum_out = s;
+    } catch (const engine::EnginePanic&) {
+        return c->be.err ? c->be.err : PA_E_INTERNAL;
+    }
+    return 0;
+}
+
+extern "C" int pa_bp_ctx_fill(pa_bp_ctx* c, int32_t i0, int32_t i1, size_t w0, size_t w1, uint64_t* v, uint64_t* values, int8_t* h_bottom) {
+    if (!c || i0 < 0 || i1 < i0 || i1 > c->be.n() || w1 < w0 || w1 > (size_t)((c->be.m() + 63) / 64) || !v || !values) {
+        set_error("pa_bp_ctx_fill: bad arguments");
+        return PA_E_ARG;
+    }
+    try {
+        std::vector<int8_t> hb((size_t)(i1 - i0) + 1, 0);
+        c->be.fill(i0, i1, w0, w1, reinterpret_cast<engine::V*>(v), reinterpret_cast<engine::V*>(values), hb.data(), c->bp);
+        if (h_bottom) std::memcpy(h_bottom, hb.data(), (size_t)(i1 - i0));
+    } catch (const engine::EnginePanic&) {
+        return c->be.err ? c->be.err : PA_E_INTERNAL;
+    }
+    return 0;
+}
+
+extern "C" void pa_bp_ctx_destroy(pa_bp_ctx* c) { delete c; }
+
 extern "C" void pa_params_nw(pa_astarpa2_params* p) { engine::params_to_c(engine::AstarPa2Params::nw(), p); }
 extern "C" void pa_params_simple(pa_astarpa2_params* p) { engine::params_to_c(engine::AstarPa2Params::simple(), p); }
 extern "C" void pa_params_full(pa_astarpa2_params* p) { engine::params_to_c(engine::AstarPa2Params::full(), p); }

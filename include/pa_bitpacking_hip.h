@@ -59,6 +59,21 @@ int32_t pa_bp_compute(const uint64_t* a2, size_t n, const uint64_t* b2, size_t w
 int32_t pa_bp_fill(const uint64_t* a2, size_t n, const uint64_t* b2, size_t w, uint64_t* h2, uint64_t* v2,
                    uint64_t* values);
 
+/* ---- device-resident operator handles ---------------------------------------------------------------------------------
+ * For a host engine that calls the operators block by block (astarpa2/src/blocks.rs:112 BitProfile::build once,
+ * :719-724 compute per block range, :631 fill during traceback): the sequences, the profile and the persistent row of
+ * horizontal deltas (`Blocks::h`, blocks.rs:103-105) stay on the GPU; a call uploads and downloads only the `v` words of its
+ * rectangle -- columns [i0, i1) of a, 64-row words [w0, w1) of b.
+ * h_mode is blocks.rs:665-671: 0 None (top row +1, bottom row dropped), 1 Input (top row from the stored h), 2 Update (stored
+ * h in, bottom row stored back), 3 Output (top row +1, bottom row stored).  *sum_out = sum of the bottom-row deltas. */
+typedef struct pa_bp_ctx pa_bp_ctx;
+pa_bp_ctx* pa_bp_ctx_create(const uint8_t* a, size_t n, const uint8_t* b, size_t m); /* ASCII "ACGT"; NULL on error */
+int pa_bp_ctx_compute(pa_bp_ctx* ctx, int32_t i0, int32_t i1, size_t w0, size_t w1, uint64_t* v, int h_mode, int32_t* sum_out);
+/* fill (blocks.rs:627-648): values[((i - i0) * (w1 - w0) + (j - w0)) * 2 + {0,1}] = V of word j after column i; h_bottom[i - i0]
+ * (optional) = bottom-row delta of column i in {-1, 0, +1}.  The stored h row is not touched. */
+int pa_bp_ctx_fill(pa_bp_ctx* ctx, int32_t i0, int32_t i1, size_t w0, size_t w1, uint64_t* v, uint64_t* values, int8_t* h_bottom);
+void pa_bp_ctx_destroy(pa_bp_ctx* ctx);
+
 /* pa_bitpacking::search(pattern, text, unmatched_cost).out (pa-bitpacking/src/search.rs:46-120; pa_python/src/lib.rs:4-7):
  * semi-global search of a short pattern (may contain N, n or an asterisk = any base, Y/y = C or T, R/r = A or G) in a text (actgACTG).
  * out[|pattern| + |text| + 1] = costs along the bottom row, then up the right column.  Runs the ScatterProfile

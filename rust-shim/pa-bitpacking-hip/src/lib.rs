@@ -20,6 +20,14 @@ extern "C" {
     pub fn pa_bp_compute(a2: *const u64, n: usize, b2: *const u64, w: usize, h2: *mut u64, v2: *mut u64, exact_end: i32) -> i32;
     /// `simd::fill` (simd.rs:326-437): additionally `values[(i * w + j) * 2 + {0, 1}]`.
     pub fn pa_bp_fill(a2: *const u64, n: usize, b2: *const u64, w: usize, h2: *mut u64, v2: *mut u64, values: *mut u64) -> i32;
+    /// Device-resident handles: the sequences, the profile and the row of horizontal deltas (`Blocks::h`) stay on the GPU between
+    /// the calls of one pair; `h_mode` = `HMode::{None, Input, Update, Output}` as 0..3 (blocks.rs:665-671).
+    pub fn pa_bp_ctx_create(a: *const u8, n: usize, b: *const u8, m: usize) -> *mut core::ffi::c_void;
+    pub fn pa_bp_ctx_compute(ctx: *mut core::ffi::c_void, i0: i32, i1: i32, w0: usize, w1: usize, v: *mut u64, h_mode: i32,
+                             sum_out: *mut i32) -> i32;
+    pub fn pa_bp_ctx_fill(ctx: *mut core::ffi::c_void, i0: i32, i1: i32, w0: usize, w1: usize, v: *mut u64, values: *mut u64,
+                          h_bottom: *mut i8) -> i32;
+    pub fn pa_bp_ctx_destroy(ctx: *mut core::ffi::c_void);
     pub fn pa_last_error() -> *const c_char;
     pub fn pa_device_count() -> i32;
     pub fn pa_set_device(device: i32) -> i32;

@@ -185,3 +185,78 @@ def test_banded_batch_is_exact_for_any_hint(pa, oracle, monkeypatch, k, hint, mo
 def test_batch_invalid_base(pa):
     with pytest.raises(ValueError):
         pa.Batch([(b"ACGTN", b"ACGT")]).run()
+
+
+def _ones(n, w):
+    h, v = np.zeros((n, 2), np.uint64), np.zeros((w, 2), np.uint64)
+    h[:, 0] = 1
+    v[:, 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    return h, v
+
+
+@pytest.mark.parametrize("n,m", [(300, 200), (1000, 2049), (5000, 4097), (20000, 9000)])
+def test_operator_context_block_loop(pa, oracle, n, m):
+    """Device-resident operator handle (pa_bp_ctx_*), used the way the reference's engine uses the operators (blocks.rs:719-724):
+    256-column blocks, v carried on the host, the horizontal deltas kept on the device.  (1) whole-height blocks, h_mode None;
+    (2) every block as two row ranges, the upper one storing its bottom row (Output), the lower one reading it (Input) -- the
+    incremental-doubling pattern of blocks.rs:370-469; (3) Update over a stored row.  All against one oracle call on the full
+    rectangle."""
+    a, b = rand_seq(n, seed=n), rand_seq(m, seed=m + 1)
+    w = (m + 63) // 64
+    oa, ob = oracle.bitprofile_build(a, b)
+    h, v = _ones(n, w)
+    h_or, v_or = h.copy().view(oracle.H_DTYPE).reshape(n), v.copy().view(oracle.V_DTYPE).reshape(w)
+    want = oracle.simd_compute(oa, ob, h_or, v_or, True)
+    ctx = pa.OperatorContext(a, b)
+    # (1)
+    _, v1 = _ones(n, w)
+    total = 0
+    for i0 in range(0, n, 256):
+        total += ctx.compute(i0, min(n, i0 + 256), 0, w, v1, ctx.H_NONE)
+    assert total == want and np.array_equal(v1, _as_u64(v_or))
+    # (2)
+    if w >= 2:
+        cut = w // 2
+        _, v2 = _ones(n, w)
+        total = 0
+        for i0 in range(0, n, 256):
+            i1 = min(n, i0 + 256)
+            top, bot = v2[:cut].copy(), v2[cut:].copy()
+            ctx.compute(i0, i1, 0, cut, top, ctx.H_OUTPUT)
+            total += ctx.compute(i0, i1, cut, w, bot, ctx.H_INPUT)
+            v2[:cut], v2[cut:] = top, bot
+        assert total == want and np.array_equal(v2, _as_u64(v_or))
+    # (3) Update: the stored row (from (2): the bottom row of the upper half) in, this range's bottom row out, then Input below
+    if w >= 3:
+        c1, c2 = w // 3, 2 * w // 3
+        _, v3 = _ones(n, w)
+        total = 0
+        for i0 in range(0, n, 256):
+            i1 = min(n, i0 + 256)
+            r1, r2, r3 = v3[:c1].copy(), v3[c1:c2].copy(), v3[c2:].copy()
+            ctx.compute(i0, i1, 0, c1, r1, ctx.H_OUTPUT)
+            ctx.compute(i0, i1, c1, c2, r2, ctx.H_UPDATE)
+            total += ctx.compute(i0, i1, c2, w, r3, ctx.H_INPUT)
+            v3[:c1], v3[c1:c2], v3[c2:] = r1, r2, r3
+        assert total == want and np.array_equal(v3, _as_u64(v_or))
+    ctx.close()
+
+
+def test_operator_context_fill(pa, oracle):
+    n, m = 700, 1000
+    a, b = rand_seq(n, seed=3), rand_seq(m, seed=4)
+    w = (m + 63) // 64
+    oa, ob = oracle.bitprofile_build(a, b)
+    ctx = pa.OperatorContext(a, b)
+    i0, i1 = 256, 512
+    h, v = _ones(i1 - i0, w)
+    h_or, v_or = h.copy().view(oracle.H_DTYPE).reshape(i1 - i0), v.copy().view(oracle.V_DTYPE).reshape(w)
+    want, values_or = oracle.scalar_fill(oa[i0:i1], ob, h_or, v_or)
+    vg = v.copy()
+    values, hb = ctx.fill(i0, i1, 0, w, vg)
+    assert np.array_equal(vg, _as_u64(v_or))
+    assert np.array_equal(values.reshape(-1, 2), values_or.reshape(-1).view(np.uint64).reshape(-1, 2))
+    assert int(hb.astype(np.int64).sum()) == want
+    with pytest.raises(pa.PaError):
+        ctx.compute(0, n + 1, 0, w, vg)
+    ctx.close()

@@ -186,6 +186,25 @@ struct GcshHeuristic : Heuristic {
         }
         std::stable_sort(keys.begin(), keys.end(),
                          [](const std::pair<uint32_t, I>& x, const std::pair<uint32_t, I>& y) { return x.first < y.first; });
+        // first index of every distinct key in the sorted list, in an open-addressing table (a lookup per position of b: the binary
+        // search over the seeds was most of the 10 ms this constructor took on a 100 kbp pair)
+        size_t tbits = 4;
+        while (((size_t)1 << tbits) < 2 * keys.size() + 1) ++tbits;
+        const size_t tmask = ((size_t)1 << tbits) - 1;
+        std::vector<int32_t> slot(tmask + 1, -1);
+        auto hash = [tbits](uint32_t key) { return (size_t)((key * 0x9E3779B1u) >> (32 - tbits)); };
+        for (size_t idx = 0; idx < keys.size(); ++idx) {
+            if (idx > 0 && keys[idx].first == keys[idx - 1].first) continue;
+            size_t h = hash(keys[idx].first);
+            while (slot[h] >= 0) h = (h + 1) & tmask;
+            slot[h] = (int32_t)idx;
+        }
+        auto first_of = [&](uint32_t key) -> size_t {
+            for (size_t h = hash(key);; h = (h + 1) & tmask) {
+                if (slot[h] < 0) return keys.size();
+                if (keys[(size_t)slot[h]].first == key) return (size_t)slot[h];
+            }
+        };
         const TP tt = t_target;
         CenteredVec next_match_per_diag(tt.x - tt.y);  // MatchBuilder::new, matches.rs:166-185
         std::vector<I> fr, next_fr;
@@ -199,9 +218,7 @@ struct GcshHeuristic : Heuristic {
                 if (m - 1 - pos < k - 1) continue;
                 const I j = pos;
                 const uint32_t key = (uint32_t)q;
-                auto it = std::lower_bound(keys.begin(), keys.end(), std::make_pair(key, (I)INT32_MIN),
-                                           [](const std::pair<uint32_t, I>& x, const std::pair<uint32_t, I>& y) { return x.first < y.first; });
-                for (; it != keys.end() && it->first == key; ++it) {
+                for (auto it = keys.begin() + (std::ptrdiff_t)first_of(key); it != keys.end() && it->first == key; ++it) {
                     const I i = it->second;
                     num_matches_pushed += 1;
                     // MatchBuilder::push, matches.rs:205-247

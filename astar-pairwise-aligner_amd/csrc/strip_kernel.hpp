@@ -170,13 +170,22 @@ __device__ __forceinline__ void lds_eq_fetch(uint32_t addr, uint32_t (&e)[K]) {
     }
 }
 
-template <int K, bool PRED, bool PASS, bool SCATTER, bool LDSEQ = false>
+// HALF (K = 1, strips of <= 32 lanes): the strip lives in lanes 32..63 and the column input enters at lane 32 (written into
+// lane 31's X, which the DPP shift then delivers), so the skew is 32 steps instead of 64.
+template <int K, bool PRED, bool PASS, bool SCATTER, bool LDSEQ = false, bool HALF = false>
 __device__ __forceinline__ void myers_step(uint32_t s_x, uint32_t& X, uint32_t (&vp)[K], uint32_t (&vm)[K],
                                            const uint32_t (&nb0)[K], const uint32_t (&nb1)[K], const uint32_t (&nb2)[K],
                                            const uint32_t (&nb3)[K], uint32_t& acc, bool active, bool pass_lane, uint32_t k40,
                                            uint32_t k80, uint32_t (&eqn)[K], uint32_t lds_lane, uint32_t kcm) {
     acc = __builtin_amdgcn_alignbit(acc, X, 30);  // (acc << 2) | (X >> 30)
-    const uint32_t Xin = dpp_wave_shr1(s_x, X);
+    uint32_t Xin;
+    if (HALF) {
+        uint32_t Xw = X;
+        asm("v_writelane_b32 %0, %1, 31" : "+v"(Xw) : "s"(s_x));
+        Xin = dpp_wave_shr1(Xw, Xw);
+    } else {
+        Xin = dpp_wave_shr1(s_x, X);
+    }
     uint32_t a0 = 0, a1 = 0;
     uint32_t eq[K], vx[K], sm[K], hp[K], hm[K];
     if (LDSEQ) {
@@ -246,7 +255,8 @@ __device__ __forceinline__ void myers_step(uint32_t s_x, uint32_t& X, uint32_t (
 
 // One chunk = 32 columns = 32 unrolled steps.  Lane j (< 32) of XS carries the packed pipeline input of column 32q+j.
 // The lagged accumulator of steps 0..15 is acc_lo, of steps 16..31 acc_hi (static, so no register moves).
-template <int K, bool PRED, bool PASS, bool FILL, bool SCATTER, bool CKPT, bool LDSEQ = false>
+// `lane` is the LOGICAL lane (HALF: physical lane - 32, negative for the idle half).
+template <int K, bool PRED, bool PASS, bool FILL, bool SCATTER, bool CKPT, bool LDSEQ = false, bool HALF = false>
 __device__ __forceinline__ void run_chunk(const StripJob& job, int q, uint32_t XS, uint32_t& X, uint32_t (&vp)[K],
                                           uint32_t (&vm)[K], const uint32_t (&nb0)[K], const uint32_t (&nb1)[K],
                                           const uint32_t (&nb2)[K], const uint32_t (&nb3)[K], uint32_t& acc_lo,
@@ -257,14 +267,14 @@ __device__ __forceinline__ void run_chunk(const StripJob& job, int q, uint32_t X
         const uint32_t s_x = (uint32_t)__builtin_amdgcn_readlane((int)XS, j);
         const int col = q * 32 + j - lane;
         const bool active = PRED ? ((unsigned)col < (unsigned)job.n) : true;
-        myers_step<K, PRED, PASS, SCATTER, LDSEQ>(s_x, X, vp, vm, nb0, nb1, nb2, nb3, j < 16 ? acc_lo : acc_hi, active, pass_lane, k40,
-                                                  k80, eqn, lds_lane, kcm);
+        myers_step<K, PRED, PASS, SCATTER, LDSEQ, HALF>(s_x, X, vp, vm, nb0, nb1, nb2, nb3, j < 16 ? acc_lo : acc_hi, active, pass_lane,
+                                                        k40, k80, eqn, lds_lane, kcm);
         if (FILL) {
             if (active) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const int sub = lane * K + k;
-                    if (sub < job.nlanes) {
+                    if ((unsigned)sub < (unsigned)job.nlanes) {
                         gu32 dst = vout + (size_t)col * (size_t)job.fill_stride * 4 + (size_t)(sub >> 1) * 4 + (sub & 1);
                         dst[0] = vp[k];
                         dst[2] = vm[k];
@@ -358,11 +368,16 @@ __device__ __attribute__((noinline)) void pace_top_strip(const uint32_t* counter
 // LOCAL: the granules are produced and consumed by the SAME wavefront (pair_kernel, trace_kernel): workgroup-scope
 // accesses, so the rows stay in the L2 instead of being written through / fetched around it 8 bytes at a time.
 // LDSEQ: eq words come from the wavefront's LDS slice at byte offset `lds_wave` (LdsEq<K>::kWaveBytes, aligned to its size).
-template <int K, bool FILL, bool SCATTER, bool CKPT = false, bool LOCAL = false, bool LDSEQ = false>
+// HALF (K = 1 and nlanes <= 32 only): the strip occupies lanes 32..63, the pipeline is 32 steps deep instead of 64, so the
+// strip takes C + 1 chunks instead of C + 2 -- 10 % of a 256-column block of the engine, of a traceback re-fill.
+template <int K, bool FILL, bool SCATTER, bool CKPT = false, bool LOCAL = false, bool LDSEQ = false, bool HALF = false>
 __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, uint32_t lds_wave = 0) {
     static_assert(!LDSEQ || (K >= 4 && !SCATTER && !FILL), "LDSEQ: tall cost-only strips");
+    static_assert(!HALF || (K == 1 && !CKPT && !LDSEQ), "HALF: short K = 1 strips without checkpoints");
     constexpr int kGranScope = LOCAL ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT;
-    const int lane = (int)(threadIdx.x & 63);
+    constexpr int kDrain = HALF ? 1 : 2;               // chunks between a column entering the strip and leaving lane 63
+    const int plane = (int)(threadIdx.x & 63);         // physical lane: builds the chunk inputs, publishes
+    const int lane = HALF ? plane - 32 : plane;        // logical lane: rows 32K*lane .. of the strip (negative: idle)
     const int n = job.n;
     const int C = (n + 31) >> 5;  // 32-column chunks == granules
     const bool pass_lane = lane * K >= job.nlanes;  // the whole lane is below the rectangle
@@ -375,7 +390,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
         const int sub = lane * K + k;  // subword of this strip: word = word0 + sub/2, half = sub&1
         const int word = job.word0 + (sub >> 1), half = sub & 1;
         vp[k] = vm[k] = nb0[k] = nb1[k] = nb2[k] = nb3[k] = 0;
-        if (sub < job.nlanes) {
+        if ((unsigned)sub < (unsigned)job.nlanes) {
             if (SCATTER) {  // [B; 4] per word
                 nb0[k] = g_prof[word * 8 + half];
                 nb1[k] = g_prof[word * 8 + 2 + half];
@@ -398,7 +413,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
     if (FILL) vout = (gu32)job.values + (size_t)job.fill_word0 * 4;
     uint32_t eqn[K];
     uint32_t kcm = LdsEq<K>::kCodeMask;
-    const uint32_t lds_lane = lds_wave + 16u * (uint32_t)lane;
+    const uint32_t lds_lane = lds_wave + 16u * (uint32_t)plane;
 #pragma unroll
     for (int k = 0; k < K; ++k) eqn[k] = 0;
     if (LDSEQ) {
@@ -423,10 +438,10 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
     int32_t sum = 0;
     uint32_t k40 = 0x40000000u, k80 = 0x80000000u;  // see myers_step; kept in VGPRs (SGPR operands halve the issue rate)
     asm volatile("" : "+v"(k40), "+v"(k80));
-    const int cj = lane & 15;
-    const bool upper = (lane & 16) != 0;          // lanes 16..31 build columns 16..31 of the chunk
+    const int cj = plane & 15;
+    const bool upper = (plane & 16) != 0;          // lanes 16..31 build columns 16..31 of the chunk
     const uint32_t sh = 2u * (uint32_t)cj;
-    const bool exact_tail = job.exact_tail != 0 && job.nlanes < 64 * K;
+    const bool exact_tail = job.exact_tail != 0 && job.nlanes < (HALF ? 32 : 64) * K;
 
     // Per-chunk inputs.  The packed sequence is read with SCALAR loads (constant address space -> s_load, tracked by
     // lgkmcnt, so it never waits behind the granule stores); the granule and the optional top-row bytes are vector
@@ -458,7 +473,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
         return s2 == 0 ? lo64 : ((lo64 >> s2) | ((uint64_t)r.w2 << (64 - s2)));
     };
     auto load_hin_byte = [&](int q) -> uint32_t {  // lanes 0..31: top delta byte of column 32q + lane
-        int c = 32 * q + (lane & 31);
+        int c = 32 * q + (plane & 31);
         c = c < n ? c : n - 1;
         return (uint32_t)hin_src[has_hin ? job.col0 + c : 0];
     };
@@ -477,14 +492,14 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
             vhi &= ch == 0 ? 0u : ~(0xFFFFFFFFu >> (2 * ch));
         }
         if (job.hout_gran) {
-            if (lane == 0)
+            if (plane == 0)
                 __hip_atomic_store((gu64)job.hout_gran + g, (((uint64_t)vhi << 32) | (uint64_t)vlo) + kGranuleBias,
                                    __ATOMIC_RELAXED, kGranScope);
         }
         if (job.hout_arr) {
-            if (lane < 32 && lane < cols) {
+            if (plane < 32 && plane < cols) {
                 const uint32_t tb = ((upper ? vhi : vlo) >> (30 - 2 * cj)) & 3u;  // bit1 = p, bit0 = m
-                ((gu8)job.hout_arr)[job.col0 + 32 * g + lane] = (uint8_t)((tb >> 1) | ((tb & 1u) << 1));
+                ((gu8)job.hout_arr)[job.col0 + 32 * g + plane] = (uint8_t)((tb >> 1) | ((tb & 1u) << 1));
             }
         }
         sum += __builtin_popcount(vlo & 0xAAAAAAAAu) + __builtin_popcount(vhi & 0xAAAAAAAAu) -
@@ -500,7 +515,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
     uint32_t hinb_next = load_hin_byte(0);
 
     // Steps t = 0 .. 32*(C+2)-1; lane l handles column t-l.  The accumulators lag one step, so after chunk q lane 63's
-    // (acc_lo, acc_hi) hold the bottom-row deltas of columns 32(q-2) .. 32(q-2)+31 == granule q-2.
+    // (acc_lo, acc_hi) hold the bottom-row deltas of columns 32(q-2) .. 32(q-2)+31 == granule q-2 (HALF: C+1 chunks, q-1).
     // Order inside an iteration: decode inputs (the only waits) -> publish the previous chunk's granule -> prefetch the
     // next chunk -> 32 steps.  Nothing conditional is ever younger than a prefetch, so its wait stays cheap.
     bool alive = true;
@@ -509,7 +524,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
     // two drain chunks exist for lane 63's bottom row, which nobody reads then.
     const bool fill_only = FILL && !job.hout_gran && !job.hout_arr && !job.sum_out && !job.vsum_out;
     const int last_lane = (job.nlanes + K - 1) / K;  // real lanes
-    const int Q = fill_only ? ((n + last_lane + 31) >> 5 < C + 2 ? (n + last_lane + 31) >> 5 : C + 2) : C + 2;
+    const int Q = fill_only ? ((n + last_lane + 31) >> 5 < C + kDrain ? (n + last_lane + 31) >> 5 : C + kDrain) : C + kDrain;
     for (int q = 0; q < Q && alive; ++q) {
         PA_DBG(2, q + 1);
         // ---- decode this chunk's inputs (both prefetched values are consumed here so the only vector-memory wait of
@@ -521,13 +536,13 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
         }
         const uint64_t codes64 = decode_codes(codes_next, q);
         const uint32_t cw = upper ? (uint32_t)(codes64 >> 32) : (uint32_t)codes64;
-        uint32_t code = (32 * q + (lane & 31) < n) ? ((cw >> sh) & 3u) : 0u;
+        uint32_t code = (32 * q + (plane & 31) < n) ? ((cw >> sh) & 3u) : 0u;
         if (LDSEQ) {
             // the pipeline carries the code of the NEXT column (its eq is fetched one step ahead), as an LDS offset
             const unsigned s2 = 2u * (unsigned)((job.col0 + 32 * (q < Cm1 ? q : Cm1)) & 15);
             const uint64_t ahead = (codes64 >> 2) | ((uint64_t)((codes_next.w2 >> s2) & 3u) << 62);
             const uint32_t cwa = upper ? (uint32_t)(ahead >> 32) : (uint32_t)ahead;
-            code = (32 * q + (lane & 31) + 1 < n) ? (((cwa >> sh) & 3u) << LdsEq<K>::kCodeShift) : 0u;
+            code = (32 * q + (plane & 31) + 1 < n) ? (((cwa >> sh) & 3u) << LdsEq<K>::kCodeShift) : 0u;
             if (q == 0) lds_eq_fetch<K>((((uint32_t)codes64 & 3u) << LdsEq<K>::kCodeShift) | lds_lane, eqn);  // column 0, for lane 0's step 0
         }
         // top delta of this lane's column as (p << 31) | (m << 30); H::one() when there is no top row (blocks.rs:732)
@@ -538,7 +553,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
             alive = resolve_granule<LOCAL>(g_gran, gran_next, q, glo, ghi);
             hin2 = ((upper ? ghi : glo) << sh) & 0xC0000000u;
             // every granule has exactly one consumer: hand it back zeroed, so the buffer needs clearing only once
-            if (lane == 0) __hip_atomic_store((gu64)job.hin_gran + q, (uint64_t)0, __ATOMIC_RELAXED, kGranScope);
+            if (plane == 0) __hip_atomic_store((gu64)job.hin_gran + q, (uint64_t)0, __ATOMIC_RELAXED, kGranScope);
         }
         if (!LOCAL && !FILL && extras && (job.flags & kJobRotatePrio)) {
             // rotate the issue priority chunk by chunk, with a phase per wave slot: the SIMD serves the highest priority
@@ -553,18 +568,18 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
         if (!LOCAL && !CKPT && !FILL && extras && (job.flags & kJobPace) && q < C) pace_top_strip(job.ckpt, job.ckpt_stride, q);
         const uint32_t XS = code | hin2;
         // ---- publish the granule completed by the previous chunk (q-1) ----
-        if (q >= 3) publish(q - 3);
+        if (q >= kDrain + 1) publish(q - kDrain - 1);
         // ---- prefetch the next chunk ----
         codes_next = load_codes(q + 1);
         gran_next = load_gran(q + 1);
         hinb_next = load_hin_byte(q + 1);
 
-        const bool interior = (q >= 2) && (q * 32 + 31 < n);  // every lane is inside [0, n): no predication needed
+        const bool interior = (q >= kDrain) && (q * 32 + 31 < n);  // every lane is inside [0, n): no predication needed
         // a 256-column block can only complete in a chunk whose first column is 0, 32 or 224 (mod 256): lane l reaches column
         // 255 (mod 256) at step 32q + j = 255 + l.  Only those chunks pay for the checkpoint test.
         const bool ck_chunk = CKPT && job.ckpt != nullptr && ((q & 7) <= 1 || (q & 7) == 7);
 #define PA_RUN_CHUNK(PRED_, PASS_, FILL_, CK_) \
-    run_chunk<K, PRED_, PASS_, FILL_, SCATTER, CK_, LDSEQ>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80, eqn, lds_lane, kcm)
+    run_chunk<K, PRED_, PASS_, FILL_, SCATTER, CK_, LDSEQ, HALF>(job, q, XS, X, vp, vm, nb0, nb1, nb2, nb3, acc_lo, acc_hi, lane, pass_lane, vout, k40, k80, eqn, lds_lane, kcm)
         if (CKPT && ck_chunk) {
             if (interior) {
                 if (exact_tail) PA_RUN_CHUNK(false, true, FILL, CKPT);
@@ -585,9 +600,9 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
 #undef PA_RUN_CHUNK
     }
     if (alive) publish(C - 1);  // the last granule (completed by chunk Q-1 = C+1)
-    if (!LOCAL && !CKPT && !FILL && (job.flags & kJobPace) && lane == 0)
+    if (!LOCAL && !CKPT && !FILL && (job.flags & kJobPace) && plane == 0)
         (void)__hip_atomic_fetch_add((PA_GLOBAL unsigned long long*)job.ckpt, kPaceDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!FILL && (job.flags & kJobLog) && lane == 0) {
+    if (!FILL && (job.flags & kJobLog) && plane == 0) {
         const uint64_t t1 = wall_clock64();
         gu32 lg = (gu32)job.values;
         lg[0] = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID
@@ -600,13 +615,13 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
     }
     PA_DBG(1, 2);
     if (!alive) {
-        if (lane == 0) __hip_atomic_store((gu32)err, (uint32_t)PA_ERR_SPIN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (plane == 0) __hip_atomic_store((gu32)err, (uint32_t)PA_ERR_SPIN_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int sub = lane * K + k;
-        if (sub < job.nlanes) {
+        if ((unsigned)sub < (unsigned)job.nlanes) {
             const int word = job.word0 + (sub >> 1), half = sub & 1;
             g_v[word * 4 + half] = vp[k];
             g_v[word * 4 + 2 + half] = vm[k];
@@ -617,7 +632,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int sub = lane * K + k;
-            if (sub < job.nlanes) {
+            if ((unsigned)sub < (unsigned)job.nlanes) {
                 uint32_t keep = 0xFFFFFFFFu;
                 if (job.tail_rows >= 0) {
                     const int row0 = 64 * job.word0 + 32 * sub;
@@ -630,16 +645,16 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        if (lane == 0) atomicAdd((int32_t*)job.vsum_out, c);
+        if (plane == 0) atomicAdd((int32_t*)job.vsum_out, c);
     }
     if (job.sum_out) {
         int32_t c = 0;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int sub = lane * K + k;
-            const bool real = sub < job.nlanes;
+            const bool real = (unsigned)sub < (unsigned)job.nlanes;
             // zero pad rows: subtract their right-edge value (simd.rs:202-224)
-            if (!exact_tail && !real) c += __builtin_popcount(vp[k]) - __builtin_popcount(vm[k]);
+            if (!exact_tail && !real && lane >= 0) c += __builtin_popcount(vp[k]) - __builtin_popcount(vm[k]);
             if (job.tail_rows >= 0 && real) {
                 const int row0 = 64 * job.word0 + 32 * sub;  // first DP row of this subword
                 int over = row0 + 32 - job.tail_rows;         // its rows at or beyond |b|
@@ -651,7 +666,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
         sum -= c;
-        if (lane == 0) *(gi32)job.sum_out = sum;
+        if (plane == 0) *(gi32)job.sum_out = sum;
     }
     PA_DBG(1, 3);
 }
@@ -674,7 +689,12 @@ __global__ __launch_bounds__(64 * (K >= 4 ? kStripMaxBlockWaves : kStripBlockWav
     PA_DBG(0, t + 1);
     if (t < (uint32_t)njobs) {
         const StripJob job = jobs[t];
-        run_strip<K, FILL, SCATTER, CKPT, false, LDSEQ>(job, err, rfl((uint32_t)(threadIdx.x >> 6)) * LdsEq<K>::kWaveBytes);
+        if constexpr (K == 1 && !CKPT) {
+            if (job.nlanes <= 32) run_strip<1, FILL, SCATTER, false, false, false, true>(job, err);  // half-wave: one chunk less
+            else run_strip<1, FILL, SCATTER, false, false, false>(job, err);
+        } else {
+            run_strip<K, FILL, SCATTER, CKPT, false, LDSEQ>(job, err, rfl((uint32_t)(threadIdx.x >> 6)) * LdsEq<K>::kWaveBytes);
+        }
     }
     PA_DBG(0, 0x1000 + t);
 }
@@ -733,7 +753,8 @@ __global__ __launch_bounds__(64) void rect_kernel(RectArgs r) {
     j.ckpt_stride = 0;
     j.hin_n = 0;
     j.vsum_out = nullptr;
-    run_strip<K, false, false>(j, r.err);
+    if (K == 1 && j.nlanes <= 32) run_strip<1, false, false, false, false, false, true>(j, r.err);  // half-wave: one chunk less
+    else run_strip<K, false, false>(j, r.err);
     // completion: results first (system scope: v and the sum are in host memory), then the count, then the flag
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     uint32_t c = 0;
@@ -809,7 +830,8 @@ __global__ __launch_bounds__(64) void rect_chain_kernel(ChainArgs r) {
     j.ckpt_stride = 0;
     j.hin_n = 0;
     j.vsum_out = nullptr;
-    run_strip<K, false, false>(j, r.err);
+    if (K == 1 && j.nlanes <= 32) run_strip<1, false, false, false, false, false, true>(j, r.err);  // half-wave: one chunk less
+    else run_strip<K, false, false>(j, r.err);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     uint32_t c = 0;
     if (lane == 0) c = __hip_atomic_fetch_add(r.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);

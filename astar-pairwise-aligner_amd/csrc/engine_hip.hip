@@ -4,6 +4,7 @@
 // horizontal-delta row (one byte per column, blocks.rs:103-105) resident on the GPU; every
 // compute / fill rectangle of the engine is one chained-strip launch of strip_kernel.  Block right-edge
 // columns (`Block::v`) live in host memory because the band logic reads them (Block::index).
+#include <atomic>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -434,10 +435,11 @@ struct SweepSlot {
     int32_t f_max = 0, waves = 0;
     sweep::PassGeometry geo{};
     double t_launch = 0;
-    // bprog @0, ticket @16, done @24, cancel @56 (directly before the status block), status @64, phase clocks @512
+    // bprog @0, ticket @16, done @24, merge counter @32, cancel @56 (directly before the status block), status @64, phase clocks @512
     uint64_t* bprog() { return d_misc.as<uint64_t>(); }
     uint32_t* ticket() { return d_misc.as<uint32_t>() + 4; }
     uint64_t* done() { return d_misc.as<uint64_t>() + 3; }
+    uint32_t* merge_count() { return d_misc.as<uint32_t>() + 8; }
     uint64_t* cancel() { return d_misc.as<uint64_t>() + 7; }
     sweep::Status* status() { return reinterpret_cast<sweep::Status*>(d_misc.as<uint8_t>() + 64); }
 };
@@ -514,8 +516,13 @@ struct HipSweepLauncher {
     bool has_sh = false;
     int32_t heur_kind = sweep::kHeurGap;
 
-    HipSweepLauncher(HipBackend& backend, SweepPool& p) : be(backend), pool(p) {}
-    ~HipSweepLauncher() { cancel_after(0); }
+    HipSweepLauncher(HipBackend& backend, SweepPool& p) : be(backend), pool(p) { active_callers().fetch_add(1, std::memory_order_relaxed); }
+    ~HipSweepLauncher() {
+        cancel_after(0);
+        active_callers().fetch_sub(1, std::memory_order_relaxed);
+    }
+    HipSweepLauncher(const HipSweepLauncher&) = delete;
+    HipSweepLauncher& operator=(const HipSweepLauncher&) = delete;
 
     void hip_fail(const char* what) { throw sweep::SweepFallback(what, -2); }
     static bool timing_on() {
@@ -528,13 +535,40 @@ struct HipSweepLauncher {
     // multiplexes all streams of a process over GPU_MAX_HW_QUEUES of them (default 4; pa_sweep_runtime_hints below asks for 16
     // when the library is loaded before the runtime starts).  A pass queued BEHIND a later one would only cost time, never
     // correctness: passes are submitted in order and wait for their predecessors only.
+    // Every pass in flight is a RUNNING kernel (it polls its predecessor) on a stream of its own, and the GPU serves only so many
+    // queues side by side: with five passes each, four host threads got 716 pairs/s out of the drop-in loop (10 kbp pairs), with
+    // two each 1042; eight threads 698 -> 1489 (profiles/r02_runs/dropin_threads.log).  Short pairs rarely need more than three
+    // tries, passes beyond that are launches and cancellations for nothing.
     int max_in_flight() const {
-        static const int depth = [] {
-            if (const char* e = std::getenv("PA_SWEEP_DEPTH")) return std::min(std::max(std::atoi(e), 1), SweepPool::kMaxInFlight);
-            const char* q = std::getenv("GPU_MAX_HW_QUEUES");
-            return (q && std::atoi(q) >= 8) ? SweepPool::kMaxInFlight : 3;
+        static const int forced = [] {
+            const char* e = std::getenv("PA_SWEEP_DEPTH");
+            return e ? std::min(std::max(std::atoi(e), 1), SweepPool::kMaxInFlight) : 0;
         }();
-        return depth;
+        if (forced) return forced;
+        static const int queues = [] {
+            const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+            return q ? std::max(std::atoi(q), 1) : 4;
+        }();
+        const int base = queues >= 8 ? (nblk > kShortPairBlocks ? SweepPool::kMaxInFlight : 3) : 3;
+        const int callers = recent_callers();
+        return callers == 1 ? base : (callers == 2 ? std::min(base, 3) : 2);
+    }
+    // The callers inside an alignment now, or the most seen during the last 20 ms: a thread between two calls of a loop still counts.
+    static int recent_callers() {
+        static std::atomic<int> peak{0};
+        static std::atomic<int64_t> peak_ns{0};
+        const int now_callers = std::max(active_callers().load(std::memory_order_relaxed), 1);
+        const int64_t now = (int64_t)(engine::now_s() * 1e9);
+        if (now_callers >= peak.load(std::memory_order_relaxed) || now - peak_ns.load(std::memory_order_relaxed) > 20'000'000) {
+            peak.store(now_callers, std::memory_order_relaxed);  // (racing updates can only misjudge the depth for a moment)
+            peak_ns.store(now, std::memory_order_relaxed);
+        }
+        return std::max(now_callers, peak.load(std::memory_order_relaxed));
+    }
+    static constexpr int32_t kShortPairBlocks = 128;  // 32 kbp
+    static std::atomic<int>& active_callers() {  // host threads inside a sweep alignment right now
+        static std::atomic<int> n{0};
+        return n;
     }
     // wavefronts: one per strip the band can cover at a time (+ slack), one workgroup each
     int pass_waves(int32_t f_max) const {
@@ -633,7 +667,6 @@ struct HipSweepLauncher {
         reserve_tagged(sl.d_pring, pr_bytes, sl.s);
         (void)reserve_no_sync(sl.d_gran, gran_bytes);
         (void)reserve_no_sync(sl.d_col, col_bytes);
-        if (!hip_ok(hipMemsetAsync(sl.d_gran.ptr, 0, gran_bytes, sl.s), "memset granules")) hip_fail("memset");
 
         InitArgs ia;
         ia.brec = sl.d_brec.as<BRec>();
@@ -652,7 +685,16 @@ struct HipSweepLauncher {
         ia.fs0 = init.fs0;
         ia.last_strip = init.last_strip;
         ia.nstrips = geo.nstrips;
-        hipLaunchKernelGGL(sweep_init_kernel, dim3(1), dim3(64), 0, sl.s, ia);
+        // workgroup 0 sets the pass up, all of them clear the hand-off granules (16 words per thread and round); a large granule
+        // buffer (long pairs: a pass takes milliseconds, a launch more does not matter) is left to the runtime's fill kernel
+        ia.gran = sl.d_gran.as<uint64_t>();
+        ia.gran_words = gran_bytes / 8;
+        if (gran_bytes > ((size_t)4 << 20)) {
+            ia.gran_words = 0;
+            if (!hip_ok(hipMemsetAsync(sl.d_gran.ptr, 0, gran_bytes, sl.s), "memset granules")) hip_fail("memset");
+        }
+        const uint64_t init_groups = std::min<uint64_t>(std::max<uint64_t>(ia.gran_words / ((uint64_t)kInitThreads * 16), 1), 2048);
+        hipLaunchKernelGGL(sweep_init_kernel, dim3((unsigned)init_groups), dim3(kInitThreads), 0, sl.s, ia);
 
         Ctx c;
         c.a_codes = be.d_codes.as<uint32_t>();
@@ -697,14 +739,12 @@ struct HipSweepLauncher {
             sl.t_launch = engine::now_s();
         }
         hipLaunchKernelGGL(sweep_kernel, dim3((unsigned)c.nwaves), dim3(64), 0, sl.s, c);
-        // behind the pass: merge its records into the older ones (after the previous pass's merge), then the done word
+        // behind the pass: merge its records into the older ones (after the previous pass's merge); the same launch then publishes
+        // the done word and writes the status into the pinned copy that wait_pass reads
         if (pv_running && !hip_ok(hipStreamWaitEvent(sl.s, pv->merged_ev, 0), "hipStreamWaitEvent")) hip_fail("event");
         hipLaunchKernelGGL(sweep_merge_kernel, dim3((unsigned)((nblk + 2 + 255) / 256)), dim3(256), 0, sl.s, sl.d_brec.as<BRec>(), merged_in,
-                           sl.d_merged.as<BlockRec>(), sl.status(), nblk);
-        hipLaunchKernelGGL(sweep_done_kernel, dim3(1), dim3(1), 0, sl.s, sl.done(), sl.pass);
-        if (!hip_ok(hipEventRecord(sl.merged_ev, sl.s), "hipEventRecord") || !hip_ok(hipGetLastError(), "sweep launch") ||
-            !hip_ok(hipMemcpyAsync(sl.h_status, sl.status(), sizeof(Status), hipMemcpyDeviceToHost, sl.s), "D2H status"))
-            hip_fail("sweep pass");
+                           sl.d_merged.as<BlockRec>(), sl.status(), nblk, sl.merge_count(), sl.done(), sl.pass, sl.h_status);
+        if (!hip_ok(hipEventRecord(sl.merged_ev, sl.s), "hipEventRecord") || !hip_ok(hipGetLastError(), "sweep launch")) hip_fail("sweep pass");
         sl.live = true;
     }
 

@@ -274,9 +274,14 @@ struct InitArgs {
     uint32_t* ticket;
     uint32_t pass;
     int32_t js1, je1, ojs1, oje1, flags1, top1, fs0, last_strip, nstrips;
+    uint64_t* gran;       // the pass's hand-off granules: cleared here (one launch less than a memset in front of this kernel)
+    uint64_t gran_words;  // 8-byte words
 };
 
-__global__ __launch_bounds__(64) void sweep_init_kernel(InitArgs a) {
+constexpr int kInitThreads = 256;
+__global__ __launch_bounds__(kInitThreads) void sweep_init_kernel(InitArgs a) {
+    for (uint64_t i = (uint64_t)blockIdx.x * kInitThreads + threadIdx.x; i < a.gran_words; i += (uint64_t)gridDim.x * kInitThreads) a.gran[i] = 0;
+    if (blockIdx.x != 0) return;
     const uint32_t l = threadIdx.x;
     const uint32_t t1 = blk_tag(a.pass, 1);
     if (l == 0) {
@@ -299,8 +304,8 @@ __global__ __launch_bounds__(64) void sweep_init_kernel(InitArgs a) {
         *a.ticket = 0;
     }
     uint32_t* st = reinterpret_cast<uint32_t*>(a.status);
-    for (uint32_t i = l; i < sizeof(Status) / 4; i += 64) st[i] = 0;
-    for (int32_t r = (int32_t)l; r <= a.last_strip && r < a.nstrips; r += 64) a.strip_start[r] = tw_make(a.pass, 1);
+    for (uint32_t i = l; i < sizeof(Status) / 4; i += kInitThreads) st[i] = 0;
+    for (int32_t r = (int32_t)l; r <= a.last_strip && r < a.nstrips; r += kInitThreads) a.strip_start[r] = tw_make(a.pass, 1);
 }
 
 __global__ __launch_bounds__(64) void sweep_kernel(Ctx c) { wave_main<DeviceWave>(c); }
@@ -308,28 +313,40 @@ __global__ __launch_bounds__(64) void sweep_kernel(Ctx c) { wave_main<DeviceWave
 // After a pass: merged_new = the older passes' records with this pass's on top (Blocks::blocks persists across
 // align_for_bounded_dist calls, lib.rs:140-158; a block the pass did not reach, or did not fix, keeps its older record).  A pass
 // that did not end by itself (aborted, cancelled) merges nothing.  The two merged arrays alternate from pass to pass.
-__global__ void sweep_merge_kernel(const BRec* brec, const BlockRec* merged_old, BlockRec* merged_new, const Status* status, int32_t nblk) {
+// The workgroup that finishes last (a counter, left at zero) then publishes the word the next pass polls, after the merged
+// records, and copies the pass's status into the host's pinned copy -- no separate launch, no copy command behind the pass.
+__global__ void sweep_merge_kernel(const BRec* brec, const BlockRec* merged_old, BlockRec* merged_new, const Status* status, int32_t nblk,
+                                   uint32_t* counter, uint64_t* done, uint32_t pass, Status* host_status) {
     const int32_t k = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (k > nblk + 1) return;
-    BlockRec d = merged_old[k];
-    const bool ended = status->state == kStDone || status->state == kStNoPath;
-    if (ended && k >= 1 && k <= nblk && k <= status->k_end) {
-        const BRec& s = brec[k];
-        d.js = tw_val(s.js);
-        d.je = tw_val(s.je);
-        d.ojs = tw_val(s.ojs);
-        d.oje = tw_val(s.oje);
-        if (k <= status->k_fixed) {
-            d.fs = tw_val(s.fs);
-            d.fe = tw_val(s.fe);
-            d.top_val = tw_val(s.top_val);
-            d.bot_val = tw_val(s.bot_val);
+    if (k <= nblk + 1) {
+        BlockRec d = merged_old[k];
+        const bool ended = status->state == kStDone || status->state == kStNoPath;
+        if (ended && k >= 1 && k <= nblk && k <= status->k_end) {
+            const BRec& s = brec[k];
+            d.js = tw_val(s.js);
+            d.je = tw_val(s.je);
+            d.ojs = tw_val(s.ojs);
+            d.oje = tw_val(s.oje);
+            if (k <= status->k_fixed) {
+                d.fs = tw_val(s.fs);
+                d.fe = tw_val(s.fe);
+                d.top_val = tw_val(s.top_val);
+                d.bot_val = tw_val(s.bot_val);
+            }
         }
+        merged_new[k] = d;
     }
-    merged_new[k] = d;
+    __threadfence();  // this thread's records are visible device-wide ...
+    __syncthreads();  // ... for every thread of the workgroup, before it counts itself
+    if (threadIdx.x != 0) return;
+    const uint32_t c = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (c + 1 != gridDim.x) return;
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(status);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(host_status);
+    for (uint32_t i = 0; i < sizeof(Status) / 4; ++i) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(done, (uint64_t)pass, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-// ... and only then (stream order) the word the next pass polls
-__global__ void sweep_done_kernel(uint64_t* done, uint32_t pass) { *done = pass; }
 
 // Traceback: gather the blocks' columns (window-addressed, see col_base_word) into one packed buffer, and the fields of
 // the block records the host needs.

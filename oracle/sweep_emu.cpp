@@ -37,7 +37,7 @@ struct HostLauncher {
     std::vector<uint32_t> codes, prof;
     std::vector<BlockRec> merged0;  // "no block exists yet" 
     // One pass in flight: its own records and buffers, its wavefront threads, and a closer thread that merges its records
-    // into the older ones and publishes the done word (what sweep_merge_kernel / sweep_done_kernel do behind the launch).
+    // into the older ones and publishes the done word (what sweep_merge_kernel does behind the launch).
     struct Slot {
         int seq = 0, prev_seq = 0;
         std::vector<BlockRec> merged;  // the earlier passes' records with this pass's on top

@@ -342,6 +342,34 @@ def main():
         dtl = time.perf_counter() - t
         out["dropin_loop"] = {"workload": "200 x 10 kbp pairs (1/5/10/15 %), one astarpa2_simple() call after the other (cost + CIGAR each)",
                               "pairs_per_sec": round(len(loop_pairs) / dtl, 1)}
+        # the same loop from 8 host threads at once (the C ABI is re-entrant; ctypes releases the GIL): what a multi-threaded
+        # caller of the drop-in symbol gets from ONE GPU.  Reporting only: never allowed to break the bench line.
+        try:
+            import threading
+            from concurrent.futures import ThreadPoolExecutor
+
+            T = 8
+            gate = threading.Barrier(T)
+
+            def _warm(tid):  # every worker exactly once: device buffers are pooled per host thread
+                gate.wait()
+                pa.c_abi_align("astarpa2_simple", *loop_pairs[tid])
+
+            def _work(tid):
+                return [(i, pa.c_abi_align("astarpa2_simple", *loop_pairs[i])) for i in range(tid, len(loop_pairs), T)]
+
+            with ThreadPoolExecutor(T) as ex:
+                list(ex.map(_warm, range(T)))
+                t = time.perf_counter()
+                parts = list(ex.map(_work, range(T)))
+                dtt = time.perf_counter() - t
+            got_t = [r for _, r in sorted(x for part in parts for x in part)]
+            assert got_t == got, "drop-in loop: results under 8 threads differ from the sequential loop"
+            out["dropin_loop"]["threads8_pairs_per_sec"] = round(len(loop_pairs) / dtt, 1)
+        except AssertionError:
+            raise
+        except Exception as e:  # (reporting only)
+            out["dropin_loop"]["threads8_pairs_per_sec"] = f"failed: {e}"
         if not args.no_cpu_baseline:
             t = time.perf_counter()
             want = [_orc.cpu_align(a, b, _orc.params_simple())[:2] for a, b in loop_pairs[:50]]

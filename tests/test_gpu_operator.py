@@ -45,7 +45,9 @@ def test_profile_build_matches_oracle(pa, oracle):
 
 # shapes: tiny, ragged tails (1..7 words past 8), one strip exactly, strip boundaries, several strips
 SHAPES = [(1, 1), (3, 1), (15, 2), (16, 3), (17, 5), (31, 7), (64, 8), (100, 9), (256, 12), (256, 31), (256, 32),
-          (256, 33), (250, 63), (256, 64), (256, 65), (300, 100), (512, 129), (1000, 40), (77, 97)]
+          (256, 33), (250, 63), (256, 64), (256, 65), (300, 100), (512, 129), (1000, 40), (77, 97),
+          # around the half-wave threshold (strips of <= 16 words run in lanes 32..63 with a 32-step skew) and its chunk edges
+          (1, 16), (31, 16), (32, 16), (33, 16), (64, 15), (255, 15), (256, 16), (257, 17), (288, 16), (1000, 16)]
 
 
 @pytest.mark.parametrize("n,w", SHAPES)
@@ -72,7 +74,7 @@ def test_compute_matches_oracle(pa, oracle, n, w, exact):
             assert np.array_equal(h_gpu, _as_u64(h_or))
 
 
-@pytest.mark.parametrize("n,w", [(1, 1), (5, 3), (16, 4), (100, 9), (256, 10), (256, 33), (64, 70)])
+@pytest.mark.parametrize("n,w", [(1, 1), (5, 3), (16, 4), (100, 9), (256, 10), (256, 33), (64, 70), (33, 16), (256, 16), (300, 15), (31, 17)])
 def test_fill_matches_oracle(pa, oracle, n, w):
     rng = np.random.default_rng(n * 31 + w)
     a, b = rand_seq(n, seed=n), rand_seq(64 * w - 5, seed=w)

@@ -52,7 +52,6 @@ struct GcshHeuristic : Heuristic {
     I n, m, k;
     int p;
     bool prune_enabled;
-    std::vector<Cost> potential;  // n+1
     I nseeds = 0;
     TP t_target{0, 0};
     std::vector<Match> by_start;  // sorted by (i, j)
@@ -61,7 +60,12 @@ struct GcshHeuristic : Heuristic {
     bool dirty = false;
     size_t num_matches_pushed = 0, num_matches_kept = 0;
 
-    Cost P(I i) const { return (i < 0 || i > n) ? 0 : potential[(size_t)i]; }
+    // seeds start at 0, k, 2k, ...: the number of them at >= i, in closed form (a table of n + 1 entries cost 0.2 ms per 100 kbp)
+    Cost P(I i) const {
+        if (i < 0 || i > n) return 0;
+        const I before = (i + k - 1) / k;  // seeds starting before i
+        return before < nseeds ? nseeds - before : 0;
+    }
     TP T(I i, I j) const { return TP{i - j - P(i), j - i - P(i)}; }
 
     // ---- matches/prepruning.rs:24-66: extend_right / extend_right_simd (same control flow, scalar) ----
@@ -161,50 +165,46 @@ struct GcshHeuristic : Heuristic {
         : a(a_), b(b_), n(n_), m(m_), k(k_ < 1 ? 1 : k_), p(p_), prune_enabled(prune_) {
         // seeds + potentials (qgrams.rs:99-109, seeds.rs:34-71)
         nseeds = n >= k ? (n - k) / k + 1 : 0;
-        potential.assign((size_t)n + 1, 0);
-        {
-            Cost cur = 0;
-            I next_seed = nseeds - 1;
-            for (I i = n; i >= 0; --i) {
-                if (next_seed >= 0 && i == next_seed * k) {
-                    cur += 1;
-                    next_seed -= 1;
-                }
-                potential[(size_t)i] = cur;
-            }
-        }
         t_target = T(n, m);
 
         // exact matches: hash a's seeds, look up b's k-mers in decreasing j (exact.rs:15-69)
         auto bits = [](uint8_t c) -> uint64_t { return (uint64_t)((c >> 1) & 3); };
-        std::vector<std::pair<uint32_t, I>> keys;
-        keys.reserve((size_t)nseeds);
+        std::vector<uint32_t> keys((size_t)nseeds);  // the k-mer of seed sidx (a[sidx * k ..])
         for (I sidx = 0; sidx < nseeds; ++sidx) {
             uint64_t q = 0;
             for (I t = 0; t < k; ++t) q = (q << 2) | bits(a[sidx * k + t]);
-            keys.emplace_back((uint32_t)q, sidx * k);
+            keys[(size_t)sidx] = (uint32_t)q;
         }
-        std::stable_sort(keys.begin(), keys.end(),
-                         [](const std::pair<uint32_t, I>& x, const std::pair<uint32_t, I>& y) { return x.first < y.first; });
-        // first index of every distinct key in the sorted list, in an open-addressing table (a lookup per position of b: the binary
-        // search over the seeds was most of the 10 ms this constructor took on a 100 kbp pair)
+        // open-addressing table: key -> the FIRST seed with that k-mer; seeds sharing a k-mer are chained in increasing order
+        // (the order the reference's per-key vectors have).  A lookup per position of b: a binary search over the sorted seeds was
+        // most of the 10 ms this constructor once took on a 100 kbp pair; sorting them at all another 0.3 ms.
         size_t tbits = 4;
         while (((size_t)1 << tbits) < 2 * keys.size() + 1) ++tbits;
         const size_t tmask = ((size_t)1 << tbits) - 1;
-        std::vector<int32_t> slot(tmask + 1, -1);
+        std::vector<int32_t> slot(tmask + 1, -1), next_same((size_t)nseeds, -1);
         auto hash = [tbits](uint32_t key) { return (size_t)((key * 0x9E3779B1u) >> (32 - tbits)); };
-        for (size_t idx = 0; idx < keys.size(); ++idx) {
-            if (idx > 0 && keys[idx].first == keys[idx - 1].first) continue;
-            size_t h = hash(keys[idx].first);
-            while (slot[h] >= 0) h = (h + 1) & tmask;
-            slot[h] = (int32_t)idx;
+        for (I sidx = nseeds - 1; sidx >= 0; --sidx) {
+            const uint32_t key = keys[(size_t)sidx];
+            size_t h = hash(key);
+            while (slot[h] >= 0 && keys[(size_t)slot[h]] != key) h = (h + 1) & tmask;
+            next_same[(size_t)sidx] = slot[h];  // (-1 when the key is new)
+            slot[h] = sidx;
         }
-        auto first_of = [&](uint32_t key) -> size_t {
+        auto first_of = [&](uint32_t key) -> int32_t {
             for (size_t h = hash(key);; h = (h + 1) & tmask) {
-                if (slot[h] < 0) return keys.size();
-                if (keys[(size_t)slot[h]].first == key) return (size_t)slot[h];
+                if (slot[h] < 0) return -1;
+                if (keys[(size_t)slot[h]] == key) return slot[h];
             }
         };
+        // in front of the table: one bit per hashed seed key, 8 KB (stays in L1).  Most positions of b match no seed at all and
+        // stop here instead of walking the 128 KB table (the scan below: 1.7 -> 1.0 ms for a 100 kbp pair)
+        constexpr unsigned kSieveBits = 16;
+        std::vector<uint64_t> sieve((size_t)1 << (kSieveBits - 6), 0);
+        auto sieve_of = [](uint32_t key) { return (uint32_t)((key * 0x85EBCA6Bu) >> (32 - kSieveBits)); };
+        for (const uint32_t key : keys) {
+            const uint32_t hb = sieve_of(key);
+            sieve[hb >> 6] |= (uint64_t)1 << (hb & 63);
+        }
         const TP tt = t_target;
         CenteredVec next_match_per_diag(tt.x - tt.y);  // MatchBuilder::new, matches.rs:166-185
         std::vector<I> fr, next_fr;
@@ -218,8 +218,10 @@ struct GcshHeuristic : Heuristic {
                 if (m - 1 - pos < k - 1) continue;
                 const I j = pos;
                 const uint32_t key = (uint32_t)q;
-                for (auto it = keys.begin() + (std::ptrdiff_t)first_of(key); it != keys.end() && it->first == key; ++it) {
-                    const I i = it->second;
+                const uint32_t hb = sieve_of(key);
+                if (!((sieve[hb >> 6] >> (hb & 63)) & 1)) continue;
+                for (int32_t sidx = first_of(key); sidx >= 0; sidx = next_same[(size_t)sidx]) {
+                    const I i = (I)sidx * k;
                     num_matches_pushed += 1;
                     // MatchBuilder::push, matches.rs:205-247
                     if (!le(T(i, j), tt)) continue;                                   // transform filter

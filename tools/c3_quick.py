@@ -1,6 +1,9 @@
 """C3 through pa_align, both presets, best of 5 (no oracle): python tools/c3_quick.py"""
-import sys, time
-sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import astar_pairwise_aligner_amd as pa
 from astar_pairwise_aligner_amd.generate import generate_pair
 pa.require_gpu()

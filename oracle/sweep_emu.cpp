@@ -24,7 +24,7 @@ using pa_oracle_cpu::CpuBackend;
 namespace {
 
 struct HostLauncher {
-    static constexpr int kSlots = 5;  // (two more than passes in flight, like the device launcher)
+    static constexpr int kSlots = 8;  // (two more than passes in flight, like the device launcher)
     const uint8_t *a, *b;
     int32_t n = 0, m = 0, nblk = 0;
     const int32_t* sh_h = nullptr;

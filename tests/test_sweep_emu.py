@@ -167,12 +167,12 @@ def test_pipelined_passes_equal_sequential_passes(oracle, monkeypatch):
         n = rng.choice([rng.randint(300, 3000), rng.randint(3000, 15000)])
         cases.append((rng.choice(list(vs)), gen_pair(n, rng.choice([0.02, 0.1, 0.25, 0.5]), rng.randint(1, 10**6))))
     results = {}
-    for depth in ("1", "2", "3"):
+    for depth in ("1", "2", "3", "6"):
         monkeypatch.setenv("PA_SWEEP_EMU_DEPTH", depth)
         results[depth] = [oracle.sweep_emu_align(a, b, vs[name], trace=True, nwaves=16)[:4] for name, (a, b) in cases]
-    for (name, (a, b)), r1, r2, r3 in zip(cases, results["1"], results["2"], results["3"]):
+    for (name, (a, b)), r1, r2, r3, r6 in zip(cases, results["1"], results["2"], results["3"], results["6"]):
         want = oracle.cpu_align(a, b, vs[name], trace=True)
-        for rc, cost, cigar, stats in (r1, r2, r3):
+        for rc, cost, cigar, stats in (r1, r2, r3, r6):
             assert rc == 0 and (cost, cigar) == (want[0], want[1])
             assert {k: stats[k] for k in KEYS} == {k: want[2][k] for k in KEYS}
 
@@ -186,8 +186,8 @@ def test_giving_up_speculative_passes_changes_nothing(oracle, monkeypatch):
 
     rng = random.Random(21)
     vs = variants(oracle)
-    monkeypatch.setenv("PA_SWEEP_EMU_DEPTH", "3")
-    for k in ("1", "2", "3"):
+    for k in ("1", "2", "3", "5"):
+        monkeypatch.setenv("PA_SWEEP_EMU_DEPTH", "6" if k == "5" else "3")
         monkeypatch.setenv("PA_SWEEP_TEST_GIVE_UP", k)
         for _ in range(20):
             name = rng.choice(list(vs))

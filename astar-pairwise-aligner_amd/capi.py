@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = [
     "pa_pairs_read", "pa_pairs_count", "pa_pairs_get", "pa_pairs_free", "pa_write_results_csv", "pa_align_file",
     "pa_align", "pa_batch_align_multi", "pa_batch_create_trace_params",
     "pa_bp_ctx_create", "pa_bp_ctx_compute", "pa_bp_ctx_fill", "pa_bp_ctx_destroy",
+    "pa_batch_create_params", "pa_batch_pair_stats",
 ]
 
 _lib = None
@@ -85,6 +86,10 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_bp_ctx_destroy.argtypes = [vp]
     L.pa_batch_create_trace_params.argtypes = [vp, vp, vp, vp, sz, vp]
     L.pa_batch_create_trace_params.restype = vp
+    L.pa_batch_create_params.argtypes = [vp, vp, vp, vp, sz, vp]
+    L.pa_batch_create_params.restype = vp
+    L.pa_batch_pair_stats.argtypes = [vp, vp]
+    L.pa_batch_pair_stats.restype = C.c_int
     L.pa_batch_align.argtypes = [vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.pa_batch_align.restype = C.c_int
     L.pa_batch_trace_fallbacks.argtypes = [vp]
@@ -294,9 +299,11 @@ def align_multi(pairs: list[tuple[bytes, bytes]], devices: list[int], trace: boo
 class Batch:
     """Device-resident batch of independent pairs; run() = full-DP edit distance of every pair."""
 
-    def __init__(self, pairs: list[tuple[bytes, bytes]], trace: bool = False, band: float | None = None, trace_params=None):
+    def __init__(self, pairs: list[tuple[bytes, bytes]], trace: bool = False, band: float | None = None, trace_params=None, params=None):
         """band: expected edit rate (e.g. 0.05) -> diagonal-band DP, re-run wider where it was too narrow (still exact).
-        trace_params: an AstarPa2Params whose `front` (dt_trace, max_g, fr_drop) the batched traceback follows."""
+        trace_params: an AstarPa2Params whose `front` (dt_trace, max_g, fr_drop) the batched traceback follows.
+        params: an AstarPa2Params of the `simple` family -> batched A*PA2 (pa_batch_create_params): align() returns what a loop over
+        AstarPa2(params).align(a, b) returns, pair_stats() the statistics."""
         L = load()
         self._keep = pairs
         self.trace = trace
@@ -305,9 +312,14 @@ class Batch:
         bp = (C.c_void_p * n)(*[C.cast(C.c_char_p(b), C.c_void_p) for _, b in pairs])
         al = (C.c_size_t * n)(*[len(a) for a, _ in pairs])
         bl = (C.c_size_t * n)(*[len(b) for _, b in pairs])
+        self.astar = params is not None
         if band is not None and trace:
             raise ValueError("banded batches are cost-only")
-        if band is not None:
+        if params is not None:
+            cp = params._to_c()
+            self.trace = True
+            self._h = L.pa_batch_create_params(ap, al, bp, bl, n, C.byref(cp))
+        elif band is not None:
             self._h = L.pa_batch_create_banded(ap, al, bp, bl, n, C.c_float(band))
         elif trace and trace_params is not None:
             cp = trace_params._to_c()
@@ -353,6 +365,16 @@ class Batch:
                 if cig[i]:
                     L.astarpa_free_cigar(C.c_void_p(cig[i]))
         return out, cigars, float(fms.value), float(tms.value)
+
+    def pair_stats(self) -> list[dict]:
+        """AstarPa2Stats of every pair of the last align() (batches made with `params`)."""
+        from .aligner import _StatsC
+
+        arr = (_StatsC * max(self.pairs, 1))()
+        rc = load().pa_batch_pair_stats(self._h, arr)
+        if rc != 0:
+            raise PaError(f"pa_batch_pair_stats rc={rc}: {last_error()}")
+        return [{n: getattr(arr[i], n) for n, _ in _StatsC._fields_} for i in range(self.pairs)]
 
     def trace_fallbacks(self) -> int:
         return int(load().pa_batch_trace_fallbacks(self._h))

@@ -1,0 +1,271 @@
+// apa2_kernel.hpp -- the gfx950 backend of apa2_logic.hpp: ONE WAVEFRONT runs A*PA2's whole band search for one pair.
+//
+// What it replaces: the loop `for (a, b) in pairs { aligner.align(a, b) }` of pa-bin (pa-bin/src/main.rs:24-35) over
+// AstarPa2Params::simple() and its relatives (astarpa2/src/lib.rs:122-175, band.rs:100-182, domain.rs:356-541,
+// blocks.rs:205-340), for many pairs at once.
+//
+// MI355X-first shape:
+//  * A persistent grid: every wavefront pulls the next pair from an atomic ticket (heaviest pairs first), runs every pass of
+//    its band search -- j_range, the DP of each 256-column block, fixed_j_range, the reuse test, the doubling of the bound --
+//    and writes the pair's result.  No host round trip per block, per pass or per pair; no wavefront ever waits for another.
+//  * The DP of a block is the strip step of strip_kernel.hpp (lane = 32 rows, anti-diagonal skew inside the wave); a band taller
+//    than 2048 rows runs as several strips top to bottom, the bottom row handed down through two granule rows that stay in
+//    the L2 (produced and consumed by the same wavefront).  Bands of at most 1024 rows use the half-wave strip.
+//  * Block::index is a wave-parallel popcount prefix sum over the stored column; the two probing loops of fixed_j_range are
+//    exact wave-parallel searches (see apa2_logic.hpp for why they end where the reference's jumping probes end).
+//  * The right-edge column of every block stays in HBM at its absolute word position (slot k of the pair's column store), so
+//    the traceback (trace_kernel.hpp) reads the blocks of the successful pass where the forward pass left them.
+#pragma once
+#include "apa2_logic.hpp"
+#include "strip_kernel.hpp"
+
+namespace pa {
+namespace apa2 {
+
+struct PairJob {
+    const uint32_t* a_codes;  // packed 2-bit codes of a
+    const uint32_t* b_prof;   // BitProfile words of b, u32 view
+    BlockRec* rec;            // [nblk + 1] persistent block records
+    uint32_t* col;            // column store: slot k (block k's right-edge column) = col + k * col_stride * 4, indexed by absolute word
+    int64_t col_stride;       // words per slot (ceil(m / 64))
+    const int32_t* sh_h;      // SH: h(i) for i = 0..n, else nullptr
+    uint64_t* gran;           // 2 rows x 8 granules, zero between uses
+    int32_t* sum;             // scratch: bottom-row sum of the last strip
+    PairResult* result;
+    int32_t n, m;
+};
+
+__device__ __forceinline__ int32_t wsum(int32_t x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return (int32_t)rfl((uint32_t)x);
+}
+
+struct DevBackend {
+    const PairJob& job;
+    HeurParams hp;
+    uint32_t* err;
+    uint32_t* dbg;  // diagnostics: host-mapped progress markers, or nullptr
+    int lane;
+
+    __device__ __forceinline__ DevBackend(const PairJob& j, const HeurParams& h, uint32_t* e, uint32_t* d) : job(j), hp(h), err(e), dbg(d) { lane = (int)(threadIdx.x & 63); }
+    __device__ __forceinline__ void mark(int slot_, uint32_t value) const {
+        if (dbg && lane == 0) __hip_atomic_store(dbg + slot_, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+
+    __device__ __forceinline__ bool failed() const { return rfl(__hip_atomic_load((const PA_GLOBAL uint32_t*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != PA_ERR_NONE; }
+
+    __device__ __forceinline__ gu32 slot(int32_t k) const { return (gu32)job.col + (size_t)k * (size_t)job.col_stride * 4; }
+
+    __device__ __forceinline__ BlockRec load_rec(int32_t k) const {
+        const PA_GLOBAL int32_t* p = (const PA_GLOBAL int32_t*)job.rec + (size_t)k * 8;
+        const int32_t x = lane < 8 ? p[lane] : 0;
+        BlockRec r;
+        r.js = __builtin_amdgcn_readlane(x, 0);
+        r.je = __builtin_amdgcn_readlane(x, 1);
+        r.ojs = __builtin_amdgcn_readlane(x, 2);
+        r.oje = __builtin_amdgcn_readlane(x, 3);
+        r.fs = __builtin_amdgcn_readlane(x, 4);
+        r.fe = __builtin_amdgcn_readlane(x, 5);
+        r.top_val = __builtin_amdgcn_readlane(x, 6);
+        r.bot_val = __builtin_amdgcn_readlane(x, 7);
+        return r;
+    }
+    __device__ __forceinline__ void store_rec(int32_t k, const BlockRec& r) const {
+        PA_GLOBAL int32_t* p = (PA_GLOBAL int32_t*)job.rec + (size_t)k * 8;
+        int32_t x = r.js;
+        x = lane == 1 ? r.je : x;
+        x = lane == 2 ? r.ojs : x;
+        x = lane == 3 ? r.oje : x;
+        x = lane == 4 ? r.fs : x;
+        x = lane == 5 ? r.fe : x;
+        x = lane == 6 ? r.top_val : x;
+        x = lane == 7 ? r.bot_val : x;
+        if (lane < 8) p[lane] = x;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the same wavefront reads it back (ordering only)
+    }
+
+    // Sum of the vertical deltas of rows [64 * w_from, j) of column slot k; words at or beyond w_end count +1 per row.
+    __device__ __forceinline__ int32_t prefix(int32_t k, int32_t w_from, int32_t w_end, int32_t j) const {
+        const gcu32 c = (gcu32)slot(k);
+        const int32_t full = j >> 6, rem = j & 63;  // whole words [w_from, full), then `rem` rows of word `full`
+        int32_t acc = 0;
+        for (int32_t base = w_from; base <= full; base += 64) {
+            const int32_t wi = base + lane;
+            if (wi < full || (wi == full && rem != 0)) {
+                uint64_t p = ~0ull, mm = 0ull;
+                if (wi < w_end) {
+                    p = (uint64_t)c[(size_t)wi * 4 + 0] | ((uint64_t)c[(size_t)wi * 4 + 1] << 32);
+                    mm = (uint64_t)c[(size_t)wi * 4 + 2] | ((uint64_t)c[(size_t)wi * 4 + 3] << 32);
+                }
+                const uint64_t mask = wi < full ? ~0ull : ((1ull << rem) - 1ull);
+                acc += __builtin_popcountll(p & mask) - __builtin_popcountll(mm & mask);
+            }
+        }
+        return wsum(acc);
+    }
+
+    // Block::index (block.rs:69-122; from the top: the column is consistent, top_val + all deltas == bot_val)
+    __device__ __forceinline__ int32_t index(int32_t k, const BlockRec& r, int32_t j) const {
+        if (k == 0) return j;  // the first column: V::one from (0, 0)
+        if (j > r.je) return r.bot_val + (j - r.je);
+        return r.top_val + prefix(k, r.js >> 6, r.je >> 6, j);
+    }
+
+    // init_v_with_overlap (blocks.rs:753-767) + compute_block(HMode::None) (blocks.rs:686-748) for block k; the bottom-row sum.
+    __device__ __forceinline__ int32_t compute(int32_t k, const BlockRec& prev, const BlockRec& cur, int32_t i0, int32_t i1) const {
+        const int32_t w0 = cur.js >> 6, w1 = cur.je >> 6, words = w1 - w0;
+        if (words <= 0) return i1 - i0;  // no rows: the bottom row is the top row (+1 per column)
+        const int32_t pw0 = prev.js >> 6, pw1 = prev.je >> 6;
+        const gu32 dst = slot(k);
+        const gcu32 src = (gcu32)slot(k - 1);
+        for (int32_t wi = w0 + lane; wi < w1; wi += 64) {
+            uint32_t x0 = 0xFFFFFFFFu, x1 = 0xFFFFFFFFu, x2 = 0u, x3 = 0u;
+            if (k > 1 && wi >= pw0 && wi < pw1) {
+                x0 = src[(size_t)wi * 4 + 0];
+                x1 = src[(size_t)wi * 4 + 1];
+                x2 = src[(size_t)wi * 4 + 2];
+                x3 = src[(size_t)wi * 4 + 3];
+            }
+            dst[(size_t)wi * 4 + 0] = x0;
+            dst[(size_t)wi * 4 + 1] = x1;
+            dst[(size_t)wi * 4 + 2] = x2;
+            dst[(size_t)wi * 4 + 3] = x3;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        const int32_t S = (words + 31) >> 5;
+        for (int32_t st = 0; st < S; ++st) {
+            mark(6, (uint32_t)st);
+            StripJob j;
+            j.a_codes = job.a_codes;
+            j.b_prof = job.b_prof;
+            j.v = job.col + (size_t)k * (size_t)job.col_stride * 4;
+            j.hin_gran = st > 0 ? job.gran + (size_t)((st - 1) & 1) * 8 : nullptr;
+            j.hin_arr = nullptr;
+            j.hout_gran = st + 1 < S ? job.gran + (size_t)(st & 1) * 8 : nullptr;
+            j.hout_arr = nullptr;
+            j.values = nullptr;
+            j.sum_out = st + 1 < S ? nullptr : job.sum;
+            j.n = i1 - i0;
+            j.word0 = w0 + 32 * st;
+            j.nlanes = 2 * (words - 32 * st < 32 ? words - 32 * st : 32);
+            j.fill_stride = 0;
+            j.fill_word0 = 0;
+            j.exact_tail = st + 1 < S ? 1 : 0;
+            j.flags = 0;
+            j.col0 = i0;
+            j.tail_rows = -1;
+            j.k = 1;
+            j.ckpt = nullptr;
+            j.ckpt_stride = 0;
+            j.hin_n = 0;
+            j.vsum_out = nullptr;
+            if (j.nlanes <= 32) run_strip<1, false, false, false, true, false, true>(j, err);
+            else run_strip<1, false, false, false, true>(j, err);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+        return (int32_t)rfl((uint32_t)*(const PA_GLOBAL int32_t*)job.sum);
+    }
+
+    __device__ __forceinline__ int32_t hval(int32_t i, int32_t j, int32_t sh_i) const {
+        if (hp.kind == sweep::kHeurGap) {
+            const int32_t d = (hp.n - i) - (hp.m - j);
+            return d < 0 ? -d : d;
+        }
+        return hp.kind == sweep::kHeurSH ? sh_i : 0;
+    }
+
+    // First (LAST = false) / last (LAST = true) row j in [lo, hi] with index(j) + h(i, j) <= f_max.
+    template <bool LAST>
+    __device__ __forceinline__ bool scan(int32_t k, const BlockRec& r, int32_t i, int32_t f_max, int32_t lo, int32_t hi, int32_t* out) const {
+        const gcu32 c = (gcu32)slot(k);
+        const int32_t w_end = r.je >> 6;
+        const int32_t wlo = lo >> 6, whi = hi >> 6;
+        const int32_t sh_i = hp.kind == sweep::kHeurSH ? (int32_t)rfl((uint32_t)((const PA_GLOBAL int32_t*)hp.sh_h)[i]) : 0;
+        int32_t base = index(k, r, wlo << 6);  // value at the first row of word wlo
+        bool found = false;
+        for (int32_t wc = wlo; wc <= whi; wc += 64) {
+            const int32_t wi = wc + lane;
+            const bool valid = wi <= whi;
+            uint64_t p = ~0ull, mm = 0ull;  // rows at or beyond the block's end: +1 each (block.rs:75-77)
+            if (valid && wi < w_end) {
+                p = (uint64_t)c[(size_t)wi * 4 + 0] | ((uint64_t)c[(size_t)wi * 4 + 1] << 32);
+                mm = (uint64_t)c[(size_t)wi * 4 + 2] | ((uint64_t)c[(size_t)wi * 4 + 3] << 32);
+            }
+            const int32_t val = valid ? __builtin_popcountll(p) - __builtin_popcountll(mm) : 0;
+            int32_t incl = val;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int32_t t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            const int32_t P = base + incl - val;  // value at the first row of word wi
+            // f drops by at most 2 per row: a word whose first row is more than 126 above the bound holds no row within it
+            const bool cand = valid && (P + hval(i, wi << 6, sh_i) - 126 <= f_max);
+            uint64_t mask = __ballot(cand);
+            while (mask) {
+                const int l = LAST ? 63 - __builtin_clzll(mask) : __builtin_ctzll(mask);
+                mask &= ~(1ull << l);
+                const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)p, l), phi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(p >> 32), l);
+                const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mm, l), mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mm >> 32), l);
+                const int32_t Pw = __builtin_amdgcn_readlane(P, l);
+                const uint64_t pw = (uint64_t)plo | ((uint64_t)phi << 32), mw = (uint64_t)mlo | ((uint64_t)mhi << 32);
+                const uint64_t bits = (1ull << lane) - 1ull;
+                const int32_t j = ((wc + l) << 6) + lane;
+                const int32_t f = Pw + __builtin_popcountll(pw & bits) - __builtin_popcountll(mw & bits) + hval(i, j, sh_i);
+                const uint64_t okm = __ballot(f <= f_max && j >= lo && j <= hi);
+                if (okm) {
+                    *out = ((wc + l) << 6) + (LAST ? 63 - __builtin_clzll(okm) : __builtin_ctzll(okm));
+                    found = true;
+                    break;
+                }
+            }
+            if (found && !LAST) return true;
+            base += __builtin_amdgcn_readlane(incl, 63);
+        }
+        return found;
+    }
+    __device__ __forceinline__ bool scan_first(int32_t k, const BlockRec& r, int32_t i, int32_t f_max, int32_t lo, int32_t hi, int32_t* out) const {
+        return scan<false>(k, r, i, f_max, lo, hi, out);
+    }
+    __device__ __forceinline__ bool scan_last(int32_t k, const BlockRec& r, int32_t i, int32_t f_max, int32_t lo, int32_t hi, int32_t* out) const {
+        return scan<true>(k, r, i, f_max, lo, hi, out);
+    }
+};
+
+// Pairs are claimed by ticket in the order of `order` (heaviest first); a block is four independent wavefronts.
+__global__ __launch_bounds__(64 * kStripBlockWaves) void apa2_kernel(const PairJob* __restrict__ jobs, const int32_t* __restrict__ order, int npairs,
+                                                                    SearchParams sp, uint32_t* ticket, uint32_t* err, uint32_t* dbg) {
+    const int lane = (int)(threadIdx.x & 63);
+    for (;;) {
+        // The ticket, WITHOUT a lane-dependent branch: with `if (lane == 0) t = atomicAdd(..)` here and `if (lane == 0) store` at the
+        // end of the body, LLVM threads lanes 1..63 from the end of one iteration straight into the next with t = 0 known, so that
+        // readfirstlane runs with lane 0 masked off and those lanes process pair 0 again, for ever (seen in the ISA of the first
+        // version).  Every lane adds (lane 0: 1, the others 0; the compiler folds it into one atomic) and lane 0's old value counts.
+        uint32_t t = atomicAdd(ticket, lane == 0 ? 1u : 0u);
+        t = rfl(t);
+        if (t >= (uint32_t)npairs) break;
+        const int pair = (int)rfl((uint32_t)order[t]);
+        const PairJob job = jobs[pair];
+        HeurParams hp;
+        hp.kind = sp.heur;
+        hp.n = job.n;
+        hp.m = job.m;
+        hp.sh_h = job.sh_h;
+        DevBackend be(job, hp, err, dbg);
+        be.mark(7, (uint32_t)pair + 1u);
+        PairProg<DevBackend> prog(be, hp, sp);
+        PairResult res;
+        if (job.n > 0 && job.m > 0) {
+            prog.run(&res);
+        } else {  // an empty sequence: left to the host engine
+            res = PairResult{};
+            res.status = kErrDegenerate;
+        }
+        if (rfl(*(const PA_GLOBAL uint32_t*)err) != PA_ERR_NONE && res.status == kOk) res.status = kErrDevice;
+        *job.result = res;  // (every lane stores the same 64 bytes: no lane-dependent branch at the end of the loop body either)
+    }
+}
+
+}  // namespace apa2
+}  // namespace pa

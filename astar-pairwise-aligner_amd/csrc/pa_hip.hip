@@ -3,6 +3,7 @@
 #include "pa_hip_internal.hpp"
 #include "engine_capi.hpp"
 #include "trace_kernel.hpp"
+#include "apa2_kernel.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -13,6 +14,7 @@
 #include <memory>
 #include <mutex>
 #include <set>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -972,6 +974,13 @@ struct pa_batch {
     hipEvent_t ev2 = nullptr;
     uint8_t* h_text = nullptr;  // pinned host buffer for the packed CIGAR text
     size_t h_text_size = 0;
+    // A*PA2 mode (pa_batch_create_params): one wavefront runs the whole band search of a pair (apa2_kernel.hpp); d_ckpt is the
+    // pairs' column store, the traceback reads the blocks of the successful pass from it
+    bool astar = false;
+    pa_astarpa2_params aparams_c{};
+    apa2::SearchParams sp{};
+    DeviceBuf d_rec, d_results, d_pjobs, d_order, d_tstats, d_sh;
+    std::vector<pa_astarpa2_stats> pair_stats;  // of the last pa_batch_align
     double cells = 0, word_updates = 0, algo_bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1165,12 +1174,85 @@ static void choose_band_shape(pa_batch* p) {
     p->k = best_k;
 }
 
+// ---- A*PA2 for many pairs: one wavefront per pair runs the whole band search (apa2_logic.hpp / apa2_kernel.hpp) -----------
+static bool apa2_supported(const engine::AstarPa2Params& p) {
+    using namespace engine;
+    return p.domain == DomainKind::Astar && (p.heuristic == HeuristicKind::None || p.heuristic == HeuristicKind::Gap || p.heuristic == HeuristicKind::SH) &&
+           p.block_width == sweep::kBlockW && p.front.sparse && !p.front.incremental_doubling && !p.prune &&
+           (p.doubling == DoublingKind::BandDoubling || p.doubling == DoublingKind::LinearSearch) &&
+           (!p.front.dt_trace || (p.front.max_g >= 1 && p.front.max_g <= kDtMaxG));
+}
+
+// The per-pair descriptors of the A*PA2 mode; completes the trace jobs (banded blocks, statistics).
+static bool astar_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t* const* b, std::vector<TraceJob>& tjobs) {
+    const engine::AstarPa2Params ap = engine::params_from_c(p->aparams_c);
+    const size_t P = p->pairs;
+    p->sp.heur = ap.heuristic == engine::HeuristicKind::Gap ? sweep::kHeurGap : (ap.heuristic == engine::HeuristicKind::SH ? sweep::kHeurSH : sweep::kHeurNone);
+    p->sp.sparse_h = ap.sparse_h ? 1 : 0;
+    p->sp.doubling = ap.doubling == engine::DoublingKind::LinearSearch ? apa2::kDoublingLinear : apa2::kDoublingBand;
+    p->sp.start = (int32_t)ap.start;
+    p->sp.factor = ap.factor;
+    p->sp.delta = (int32_t)ap.delta;
+    std::vector<size_t> rec_off(P), sh_off(P);
+    size_t tr = 0, tsh = 0;
+    for (size_t i = 0; i < P; ++i) {
+        rec_off[i] = tr;
+        tr += (p->n[i] + 255) / 256 + 2;
+        sh_off[i] = tsh;
+        if (p->sp.heur == sweep::kHeurSH) tsh += p->n[i] + 1;
+    }
+    if (!p->d_rec.alloc(std::max<size_t>(tr, 1) * sizeof(sweep::BlockRec)) || !p->d_results.alloc(std::max<size_t>(P, 1) * sizeof(apa2::PairResult)) ||
+        !p->d_pjobs.alloc(std::max<size_t>(P, 1) * sizeof(apa2::PairJob)) || !p->d_order.alloc(std::max<size_t>(P, 1) * 4) ||
+        !p->d_tstats.alloc(std::max<size_t>(P, 1) * 32) || !p->d_sh.alloc(std::max<size_t>(tsh, 1) * 4))
+        return false;
+    if (p->sp.heur == sweep::kHeurSH && tsh) {  // SeedHeuristicH (pa-heuristic sh.rs:47-106): host-built per-column table
+        std::vector<int32_t> sh(tsh);
+        for (size_t i = 0; i < P; ++i) {
+            engine::SeedHeuristicH h(a[i], (engine::I)p->n[i], b[i], (engine::I)p->m[i], ap.heuristic_k);
+            std::copy(h.h_by_i.begin(), h.h_by_i.end(), sh.begin() + sh_off[i]);
+        }
+        if (!hip_ok(hipMemcpy(p->d_sh.ptr, sh.data(), tsh * 4, hipMemcpyHostToDevice), "H2D sh")) return false;
+    }
+    std::vector<apa2::PairJob> pj(P);
+    std::vector<int32_t> order(P);
+    for (size_t i = 0; i < P; ++i) {
+        const size_t w = (p->m[i] + 63) / 64, nblk = (p->n[i] + 255) / 256;
+        apa2::PairJob& j = pj[i];
+        j.a_codes = p->d_codes.as<uint32_t>() + p->code_off[i];
+        j.b_prof = p->d_prof.as<uint32_t>() + p->prof_off[i] * 4;
+        j.rec = p->d_rec.as<sweep::BlockRec>() + rec_off[i];
+        j.col = p->d_ckpt.as<uint32_t>() + p->ckpt_off[i];
+        j.col_stride = (int64_t)w;
+        j.sh_h = p->sp.heur == sweep::kHeurSH ? p->d_sh.as<int32_t>() + sh_off[i] : nullptr;
+        j.gran = p->d_scratch_gran.as<uint64_t>() + i * 16;
+        j.sum = p->d_sums.as<int32_t>() + i;
+        j.result = p->d_results.as<apa2::PairResult>() + i;
+        j.n = (int32_t)p->n[i];
+        j.m = (int32_t)p->m[i];
+        TraceJob& t = tjobs[i];
+        t.rec = j.rec;
+        t.res = j.result;
+        t.tstats = p->d_tstats.as<uint32_t>() + 8 * i;
+        t.final_v = p->d_ckpt.as<uint32_t>() + p->ckpt_off[i] + nblk * w * 4;
+        order[i] = (int32_t)i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return p->n[x] + p->m[x] > p->n[y] + p->m[y]; });  // heaviest first
+    if (P && (!hip_ok(hipMemcpy(p->d_pjobs.ptr, pj.data(), P * sizeof(apa2::PairJob), hipMemcpyHostToDevice), "H2D pair jobs") ||
+              !hip_ok(hipMemcpy(p->d_order.ptr, order.data(), P * 4, hipMemcpyHostToDevice), "H2D order")))
+        return false;
+    return true;
+}
+
 static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len, size_t pairs,
-                              bool trace, float band_hint = -1.f, int dt_max_g = 0, int dt_fr_drop = 0) {
+                              bool trace, float band_hint = -1.f, int dt_max_g = 0, int dt_fr_drop = 0, const pa_astarpa2_params* astar = nullptr) {
     if (!ensure_device()) return nullptr;
     auto p = std::make_unique<pa_batch>();
     p->pairs = pairs;
     p->trace = trace;
+    if (astar) {
+        p->astar = true;
+        p->aparams_c = *astar;
+    }
     p->dt_max_g = dt_max_g;
     p->dt_fr_drop = dt_fr_drop;
     p->banded = band_hint >= 0.f;
@@ -1186,7 +1268,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
         p->n.clear();
         p->m.clear();
     } else {
-        const BatchShape sh = choose_batch_shape(a_len, b_len, pairs);
+        const BatchShape sh = astar ? BatchShape() : choose_batch_shape(a_len, b_len, pairs);
         p->k = sh.k;
         p->sequential = sh.sequential;
         p->block_waves = sh.block_waves;
@@ -1209,8 +1291,9 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
         tb += (b_len[i] + 15) & ~size_t(15);
         tc += (a_len[i] + 15) / 16;
         tp += w;
-        tg += p->banded ? (size_t)(p->sequential ? 2 : std::max(1, strip_plan((int)w, p->k, false).strips() - 1)) * (a_len[i] / 32 + 2)
-                        : rect_granules((int)a_len[i], (int)w, p->k, p->sequential);
+        tg += astar ? 0
+              : p->banded ? (size_t)(p->sequential ? 2 : std::max(1, strip_plan((int)w, p->k, false).strips() - 1)) * (a_len[i] / 32 + 2)
+                          : rect_granules((int)a_len[i], (int)w, p->k, p->sequential);
         p->cells += (double)a_len[i] * (double)b_len[i];
         p->word_updates += (double)a_len[i] * (double)w;
         // algorithmic HBM bytes, cost-only rectangle: 0.75 B/column + 48 B/word
@@ -1225,7 +1308,8 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             p->cigar_off.push_back(tcg);
             p->word_off.push_back(tw);
             tw += std::min<size_t>(std::max<size_t>(w, 1), (size_t)kTraceScratchWords);
-            tck += (a_len[i] / 256 + 1) * w * 4;  // u32: one V column per 256 columns of a (slot 0 unused)
+            // u32: one V column per 256 columns of a (slot 0 unused); A*PA2 mode: slots 0 .. ceil(n / 256)
+            tck += (astar ? (a_len[i] + 255) / 256 + 1 : a_len[i] / 256 + 1) * w * 4;
             tcg += a_len[i] + b_len[i] + 2;
         }
         if (tcg >= (size_t(1) << 62) || !p->d_ckpt.alloc(tck * 4) || !p->d_cigar.alloc(tcg * 4) || !p->d_packed.alloc(tcg) || !p->d_text.alloc(tcg) ||
@@ -1302,7 +1386,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
         first[i] = (int32_t)p->jobs.size();
         first[i + 1] = first[i];
         const int w = (int)((b_len[i] + 63) / 64);
-        if (w == 0 || a_len[i] == 0) continue;
+        if (w == 0 || a_len[i] == 0 || astar) continue;
         if (p->banded) {
             plan_banded_pair(p.get(), i, p->band_t[i], p->jobs);
             p->last_job[i] = (int)p->jobs.size() - 1;
@@ -1376,6 +1460,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             t.dt_fr_drop = dt_fr_drop;
             src_off[i] = p->cigar_off[i];
         }
+        if (astar && !astar_jobs(p.get(), a, b, tjobs)) return nullptr;
         if (!hip_ok(hipMemsetAsync(p->d_scratch_gran.ptr, 0, pairs * 16 * 8, p->stream), "memset trace granules") ||
             !hip_ok(hipMemcpyAsync(p->d_tjobs.ptr, tjobs.data(), pairs * sizeof(TraceJob), hipMemcpyHostToDevice, p->stream), "H2D trace jobs") ||
             !hip_ok(hipMemcpyAsync(p->d_cig_src_off.ptr, src_off.data(), pairs * 8, hipMemcpyHostToDevice, p->stream), "H2D offsets") ||
@@ -1455,6 +1540,23 @@ extern "C" pa_batch* pa_batch_create_trace_params(const uint8_t* const* a, const
     return batch_create(a, a_len, b, b_len, pairs, true, -1.f, tp.front.dt_trace ? (int)tp.front.max_g : 0, tp.front.dt_trace ? (int)tp.front.fr_drop : 0);
 }
 
+// A*PA2 for many pairs (the `simple` preset and its relatives): what a loop over pa_align(a, b, params, trace = 1) returns --
+// cost, CIGAR and statistics -- with every pair's whole band search run by one wavefront on the GPU.
+extern "C" pa_batch* pa_batch_create_params(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len,
+                                            size_t pairs, const pa_astarpa2_params* params) {
+    if (!params || !engine::params_valid(*params)) {
+        set_error("pa_batch_create_params: invalid A*PA2 parameters");
+        return nullptr;
+    }
+    const engine::AstarPa2Params ap = engine::params_from_c(*params);
+    if (!apa2_supported(ap)) {
+        set_error("pa_batch_create_params: the batched band search runs Domain::Astar with NoCost / GapCost / SH, sparse 256-column blocks, "
+                  "no incremental doubling, no pruning (the `simple` preset and its relatives); use pa_align for other parameters");
+        return nullptr;
+    }
+    return batch_create(a, a_len, b, b_len, pairs, true, -1.f, ap.front.dt_trace ? (int)ap.front.max_g : 0, ap.front.dt_trace ? (int)ap.front.fr_drop : 0, params);
+}
+
 // Profiles -> (granule clear) -> DP kernel, all queued on the batch's stream; ev0/ev1 bracket the DP kernel.
 static int batch_forward(pa_batch* p) {
     hipStream_t s = p->stream;
@@ -1483,7 +1585,42 @@ static int batch_forward(pa_batch* p) {
     if (!hip_ok(hipMemsetAsync(p->d_sums.ptr, 0, std::max<size_t>(p->pairs * 4, 16), s), "memset sums")) return PA_E_HIP;
     // d_misc (ticket, err, -, bad-base flag) was zeroed above; the events bracket the strip kernel alone
     if (!hip_ok(hipEventRecord(p->ev0, s), "event")) return PA_E_HIP;
-    if (p->sequential) {
+    if (p->astar) {
+        if (p->pairs) {
+            // a persistent grid: wavefronts pull pairs by ticket; at most kApa2BlocksPerCu blocks of four wavefronts per CU
+            static const int per_cu = getenv("PA_APA2_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("PA_APA2_BLOCKS_PER_CU"))) : 4;
+            const int cus = g_device_props_cus > 0 ? g_device_props_cus : 256;
+            const int grid = (int)std::min<size_t>((p->pairs + kStripBlockWaves - 1) / kStripBlockWaves, (size_t)cus * per_cu);
+            uint32_t* dbg = nullptr;
+            if (getenv("PA_APA2_DEBUG")) {
+                void* hp = nullptr;
+                if (!hip_ok(hipHostMalloc(&hp, 256, hipHostMallocMapped), "hipHostMalloc(debug)")) return PA_E_HIP;
+                std::memset(hp, 0, 256);
+                dbg = (uint32_t*)hp;
+            }
+            hipLaunchKernelGGL(apa2::apa2_kernel, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, p->d_pjobs.as<apa2::PairJob>(), p->d_order.as<int32_t>(),
+                               (int)p->pairs, p->sp, p->d_misc.as<uint32_t>(), p->d_misc.as<uint32_t>() + 1, dbg);
+            if (!hip_ok(hipGetLastError(), "apa2_kernel launch")) return PA_E_HIP;
+            if (dbg) {  // diagnostics: the forward pass alone, progress markers and first results on stderr
+                std::fprintf(stderr, "[apa2] forward launched: grid %d, pairs %zu\n", grid, p->pairs);
+                for (int sec = 0; sec < 8 && hipStreamQuery(s) == hipErrorNotReady; ++sec) {
+                    const volatile uint32_t* d = dbg;
+                    std::fprintf(stderr, "[apa2] t=%ds stage %u f_max %d tries %u block %u js %d je %d strip %u pair %u\n", sec, d[0], (int)d[1], d[2], d[3], (int)d[4], (int)d[5], d[6], d[7]);
+                    std::this_thread::sleep_for(std::chrono::milliseconds(1000));
+                }
+                if (hipStreamQuery(s) == hipErrorNotReady) {
+                    std::fprintf(stderr, "[apa2] the forward kernel does not finish: giving up\n");
+                    std::_Exit(3);
+                }
+                if (!hip_ok(hipStreamSynchronize(s), "sync")) return PA_E_HIP;
+                std::vector<apa2::PairResult> r(std::min<size_t>(p->pairs, 8));
+                if (!hip_ok(hipMemcpy(r.data(), p->d_results.ptr, r.size() * sizeof(apa2::PairResult), hipMemcpyDeviceToHost), "D2H")) return PA_E_HIP;
+                for (size_t i = 0; i < r.size(); ++i)
+                    std::fprintf(stderr, "[apa2] pair %zu: status %d cost %d f_max %d tries %u blocks %u lanes %llu last %d len %d\n", i, r[i].status, r[i].cost, r[i].f_max,
+                                 r[i].f_max_tries, r[i].num_blocks, (unsigned long long)r[i].computed_lanes, r[i].last_block_idx, r[i].blocks_len);
+            }
+        }
+    } else if (p->sequential) {
         if (!launch_pairs(p->d_jobs.as<StripJob>(), p->d_first.as<int32_t>(), (int)p->pairs, p->d_misc.as<uint32_t>(), s, p->k, p->trace))
             return PA_E_HIP;
     } else if (!launch_strips(p->d_jobs.as<StripJob>(), (int)p->jobs.size(), false, p->d_misc.as<uint32_t>(), s, false, false, p->k,
@@ -1683,9 +1820,34 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
     p->gran_dirty = false;
     if (forward_ms) {
         *forward_ms = 0.f;
-        if (!p->jobs.empty() && !hip_ok(hipEventElapsedTime(forward_ms, p->ev0, p->ev1), "elapsed")) return PA_E_HIP;
+        if ((p->astar || !p->jobs.empty()) && !hip_ok(hipEventElapsedTime(forward_ms, p->ev0, p->ev1), "elapsed")) return PA_E_HIP;
     }
     if (trace_ms && !hip_ok(hipEventElapsedTime(trace_ms, p->ev1, p->ev2), "elapsed")) return PA_E_HIP;
+    std::vector<apa2::PairResult> results;
+    if (p->astar) {  // per-pair statistics (domain.rs:31-43) of the band search and the traceback
+        results.resize(P);
+        std::vector<uint32_t> ts(P * 8, 0);
+        if (P && (!hip_ok(hipMemcpy(results.data(), p->d_results.ptr, P * sizeof(apa2::PairResult), hipMemcpyDeviceToHost), "D2H results") ||
+                  !hip_ok(hipMemcpy(ts.data(), p->d_tstats.ptr, P * 32, hipMemcpyDeviceToHost), "D2H trace stats")))
+            return PA_E_HIP;
+        p->pair_stats.assign(P, pa_astarpa2_stats{});
+        for (size_t i = 0; i < P; ++i) {
+            pa_astarpa2_stats& st = p->pair_stats[i];
+            const apa2::PairResult& r = results[i];
+            st.num_blocks = r.num_blocks;
+            st.num_incremental_blocks = r.num_incremental_blocks;
+            st.computed_lanes = r.computed_lanes;
+            st.unique_lanes = r.unique_lanes;
+            st.f_max_tries = r.f_max_tries;
+            st.sanity_violations = r.sanity_violations;
+            st.dt_trace_tries = ts[8 * i + 0];
+            st.dt_trace_success = ts[8 * i + 1];
+            st.dt_trace_fallback = ts[8 * i + 2];
+            st.fill_tries = ts[8 * i + 3];
+            st.fill_success = ts[8 * i + 4];
+            st.fill_fallback = ts[8 * i + 5];
+        }
+    }
     // CIGAR text is produced on the GPU; gather it into one packed buffer and copy once
     std::vector<uint32_t> tlens(P, 0);
     std::vector<uint64_t> dst_off(P, 0);
@@ -1724,8 +1886,8 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
         }
     }
     mark("pack kernel + text D2H");
-    pa_astarpa2_params fallback = traced_batch_params();
-    if (p->dt_max_g > 0) {
+    pa_astarpa2_params fallback = p->astar ? p->aparams_c : traced_batch_params();
+    if (!p->astar && p->dt_max_g > 0) {
         fallback.front.dt_trace = 1;
         fallback.front.max_g = p->dt_max_g;
         fallback.front.fr_drop = p->dt_fr_drop;
@@ -1741,7 +1903,7 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
     };
     for (size_t i = 0; i < P; ++i) {
         cost_out[i] = costs[i];
-        if (!cigar_out) continue;
+        if (!cigar_out && !(p->astar && lens[i] == kTraceFailed)) continue;  // (A*PA2 mode: a pair handed back has no cost yet either)
         if (lens[i] != kTraceFailed) {  // the common case: one allocation, one copy out of the packed buffer
             char* out = (char*)std::malloc((size_t)tlens[i] + 1);
             if (!out) {
@@ -1761,12 +1923,19 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
             (p->m[i] && !hip_ok(hipMemcpy(bb.data(), p->d_b.as<uint8_t>() + p->b_off[i], p->m[i], hipMemcpyDeviceToHost), "D2H b")))
             return fail_out(i, PA_E_HIP);
         int32_t c = 0;
-        const int rc = align_hip(ba.data(), p->n[i], bb.data(), p->m[i], fallback, true, false, &c, &text, nullptr);
+        pa_astarpa2_stats fst{};
+        const int rc = align_hip(ba.data(), p->n[i], bb.data(), p->m[i], fallback, true, false, &c, &text, &fst);
         if (rc != 0) return fail_out(i, rc);
+        if (p->astar) {
+            p->pair_stats[i] = fst;
+            if (results[i].status != apa2::kOk) costs[i] = c;  // the forward pass itself handed the pair back
+            cost_out[i] = c;
+        }
         if (c != costs[i]) {
             set_error("traceback fallback disagrees with the batched cost (pair %zu: %d vs %d)", i, c, costs[i]);
             return fail_out(i, PA_E_INTERNAL);
         }
+        if (!cigar_out) continue;
         cigar_out[i] = (char*)std::malloc(text.size() + 1);
         if (!cigar_out[i]) {
             set_error("out of memory");
@@ -1779,6 +1948,15 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
 }
 
 extern "C" size_t pa_batch_trace_fallbacks(const pa_batch* p) { return p ? p->trace_fallbacks : 0; }
+
+extern "C" int pa_batch_pair_stats(const pa_batch* p, pa_astarpa2_stats* stats_out) {
+    if (!p || !p->astar || !stats_out || p->pair_stats.size() != p->pairs) {
+        set_error("pa_batch_pair_stats needs a batch made by pa_batch_create_params after pa_batch_align");
+        return PA_E_ARG;
+    }
+    for (size_t i = 0; i < p->pairs; ++i) stats_out[i] = p->pair_stats[i];
+    return 0;
+}
 
 extern "C" void pa_batch_stats(const pa_batch* p, double* cells, double* word_updates, double* strips, double* algo_bytes) {
     if (cells) *cells = p->cells;

@@ -456,6 +456,10 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
     const gcu64 gran_src = has_gran ? g_gran : (gcu64)job.a_codes;
     const int Cm1 = C > 0 ? C - 1 : 0;
     const int last_word = (job.col0 + n - 1) >> 4;  // last valid dword of a_codes for this rectangle
+    // LDSEQ: the pipeline register carries the LDS offset of the NEXT column's code, and a lane fetches the eq words of its first
+    // column one step before it gets there, from whatever its idle predecessor passes down -- so every lane starts out passing
+    // column 0's code (an idle lane keeps bits 29:0 of what it receives).  With X = 0 lanes >= 1 took eq('A') for column 0.
+    if (LDSEQ && n > 0) X = ((c_codes[job.col0 >> 4] >> (2u * ((unsigned)job.col0 & 15u))) & 3u) << LdsEq<K>::kCodeShift;
     // raw code words of columns col0+32q .. +31 (three dwords cover any alignment of col0); shifted only at decode time
     struct RawCodes {
         uint32_t w0, w1, w2;

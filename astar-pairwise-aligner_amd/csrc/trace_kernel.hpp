@@ -15,6 +15,7 @@
 // as several strips one after the other, like pair_kernel, up to kTraceScratchWords words.  A pair that needs more, or that
 // hits a state the reference itself would panic on, is flagged and redone by the host engine.
 #pragma once
+#include "apa2_logic.hpp"
 #include "strip_kernel.hpp"
 
 namespace pa {
@@ -37,6 +38,12 @@ struct TraceJob {
     int32_t n, m, w;           // |a|, |b|, words of b
     uint32_t cigar_cap;
     int32_t dt_max_g, dt_fr_drop;  // DT-trace (trace.rs:231-416) before every re-fill: max_g (0 = off, <= kDtMaxG), fr_drop
+    // Banded blocks (the A*PA2 batch of apa2_kernel.hpp): block k's right-edge column covers rows [rec[k].js, rec[k].je) only and
+    // starts at rec[k].top_val; `ckpt` is then the pair's column store (slot k = block k, words at their absolute index, `w` words
+    // per slot), `final_v` its last slot, and the cost comes from `res`.  nullptr: full-height checkpoints (pair_kernel<K, CKPT>).
+    const sweep::BlockRec* rec;
+    const apa2::PairResult* res;
+    uint32_t* tstats;              // out (optional): TraceStats counters dt_trace_{tries, success, fallback}, fill_{tries, success, fallback}
 };
 enum : uint32_t { kTraceFailed = 0xFFFFFFFFu };
 // Re-fills of up to 128 words (8192 rows, four strips) stay on the GPU; a pair with a taller one (an indel of more than
@@ -65,6 +72,13 @@ __device__ __forceinline__ int32_t column_prefix(gcu32 col, int rows, int lane) 
         }
     }
     return wave_sum(acc);
+}
+
+// The same for a column whose stored words end after `lim` rows: the rows beyond count +1 each (Block::index below the block's
+// range, block.rs:75-77).
+__device__ __forceinline__ int32_t column_prefix_lim(gcu32 col, int rows, int lim, int lane) {
+    if (rows <= lim) return column_prefix(col, rows, lane);
+    return column_prefix(col, lim, lane) + (rows - lim);
 }
 
 // Vertical delta of row `r` (relative to the column's first row); nullptr = V::one.
@@ -107,11 +121,20 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kerne
     const gu32 cig = (gu32)tj.cigar;
     const int n = tj.n, m = tj.m, w = tj.w;
 
-    int32_t g = (n == 0) ? m : (m == 0 ? n : 64 * w + (int32_t)rfl((uint32_t)*(const PA_GLOBAL int32_t*)tj.sum));
+    const bool banded = tj.rec != nullptr;
+    int32_t g;
+    bool failed = false;
+    if (banded) {
+        const PA_GLOBAL apa2::PairResult* rs = (const PA_GLOBAL apa2::PairResult*)tj.res;
+        g = (int32_t)rfl((uint32_t)rs->cost);
+        failed = rfl((uint32_t)rs->status) != 0u;  // the forward pass handed this pair back to the host engine
+    } else {
+        g = (n == 0) ? m : (m == 0 ? n : 64 * w + (int32_t)rfl((uint32_t)*(const PA_GLOBAL int32_t*)tj.sum));
+    }
     if (lane == 0) *(gi32)tj.cost_out = g;
 
     uint32_t len = 0, cur_op = 0, cur_cnt = 0;
-    bool failed = false;
+    uint32_t n_dt_try = 0, n_dt_ok = 0, n_dt_fb = 0, n_fill_try = 0, n_fill_ok = 0, n_fill_fb = 0;  // TraceStats (trace.rs:3-14)
     auto emit = [&](uint32_t op, uint32_t cnt) {
         if (cur_cnt != 0 && cur_op == op) {
             cur_cnt += cnt;
@@ -139,6 +162,19 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kerne
     auto ckpt_col = [&](int i0) -> gcu32 {  // the stored column at i0 (a multiple of 256); column 0 is V::one
         return i0 == 0 ? (gcu32) nullptr : (gcu32)tj.ckpt + (size_t)(i0 >> 8) * (size_t)w * 4;
     };
+    // rows [js, je) and top value of stored block kb (its right-edge column is at column min(256 kb, n))
+    struct BlkMeta {
+        int32_t js, je, top;
+    };
+    auto blk_meta = [&](int kb) -> BlkMeta {
+        if (!banded) return BlkMeta{0, 64 * w, kb == 0 ? 0 : (kb * 256 < n ? kb * 256 : n)};
+        const PA_GLOBAL int32_t* rp = (const PA_GLOBAL int32_t*)tj.rec + (size_t)kb * 8;
+        BlkMeta bm;
+        bm.js = (int32_t)rfl((uint32_t)rp[0]);
+        bm.je = (int32_t)rfl((uint32_t)rp[1]);
+        bm.top = kb == 0 ? 0 : (int32_t)rfl((uint32_t)rp[6]);
+        return bm;
+    };
     auto filled_col = [&](int i) -> gcu32 { return fcols + (size_t)(i - f_i0 - 1) * (size_t)f_words * 4; };
 
     while (!failed && (to_i > 0 || to_j > 0)) {
@@ -148,7 +184,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kerne
             to_j = 0;
             break;
         }
-        if (to_j == 0) {  // top row: every column costs one deletion
+        if (to_j == 0 && !banded) {  // top row: every column costs one deletion (banded: the general path, for the statistics)
             emit(kOpDel, (uint32_t)to_i);
             g -= to_i;
             to_i = 0;
@@ -161,6 +197,8 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kerne
                 const int G = tj.dt_max_g, drop = tj.dt_fr_drop;
                 const int st_i = to_i, st_j = to_j, cols = st_i - i0;
                 const gcu32 ck = ckpt_col(i0);
+                const BlkMeta cm = blk_meta(i0 >> 8);
+                n_dt_try += 1;
                 const int b_lo = st_j - cols - G - 1 > 0 ? st_j - cols - G - 1 : 0;
                 {
                     uint8_t* awb = reinterpret_cast<uint8_t*>(L.aw) + 8;
@@ -193,13 +231,15 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kerne
                 };
                 // prev_block.index(j) = value at (i0, j): one prefix over the whole column per block (as the re-fill needs for its
                 // top-left value), then only the words between
-                const int vj0 = (st_j - cols - G > 0 ? st_j - cols - G : 0) & ~63;
+                int vj0 = (st_j - cols - G > 0 ? st_j - cols - G : 0) & ~63;
+                vj0 = vj0 > cm.js ? vj0 : cm.js;
                 int32_t vbase = 0;
                 bool vbase_ok = false;
-                auto value_at = [&](int j) -> int32_t {
-                    if (ck == nullptr) return i0 + j;
+                auto value_at = [&](int j) -> int32_t {  // prev_block.get(j) (block.rs:126-131); kDtInf: outside the block's rows
+                    if (j < cm.js || j > cm.je) return kDtInf;
+                    if (ck == nullptr) return cm.top + (j - cm.js);
                     if (!vbase_ok) {
-                        vbase = i0 + column_prefix(ck, vj0, lane);
+                        vbase = cm.top + column_prefix(ck + (size_t)(cm.js >> 6) * 4, vj0 - cm.js, lane);
                         vbase_ok = true;
                     }
                     return vbase + column_prefix(ck + (size_t)(vj0 >> 6) * 4, j - vj0, lane);
@@ -335,42 +375,54 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kerne
                     g -= found_g;
                     to_i = i0;
                     to_j = st_j - cols - found_d;
+                    n_dt_ok += 1;
                     continue;
                 }
+                n_dt_fb += 1;
             }
         }
         // ---- re-fill when the walk has left the filled columns (trace.rs:83-125) ----
         if (!(f_i0 < to_i && to_i <= f_i1) && to_i == n && ((n - 1) & 255) == 0) {
             // the last sparse block is a single column next to a checkpoint: the reference walks it as stored, without a
             // re-fill (trace.rs:86: neither `prev.e < to.i - 1` nor `block.e > to.i`)
+            const BlkMeta lm = blk_meta((n + 255) >> 8);
             f_i0 = n - 1;
             f_i1 = n;
-            f_jlo = 0;
-            f_jhi = 64 * w;
-            f_words = w;
-            f_T0 = n - 1;
-            fcols = (gcu32)tj.final_v;
+            f_jlo = lm.js;
+            f_jhi = lm.je;
+            f_words = (lm.je - lm.js) >> 6;
+            f_T0 = lm.top - 1;
+            fcols = (gcu32)tj.final_v + (size_t)(lm.js >> 6) * 4;
         }
         if (!(f_i0 < to_i && to_i <= f_i1)) {
             fcols = (gcu32)vals;
             const int i0 = ((to_i - 1) >> 8) << 8;
             const int cols = to_i - i0;
             const gcu32 ck = ckpt_col(i0);
-            int height = to_j < cols * 5 / 4 ? to_j : cols * 5 / 4;
+            const BlkMeta cm = blk_meta(i0 >> 8);          // the stored block left of the rectangle (prev_block)
+            const int blk_js = blk_meta((i0 >> 8) + 1).js;  // first row of the block the walk is in (trace.rs:93)
+            if (to_j < blk_js) {  // (jr would be empty: not a state the reference reaches)
+                failed = true;
+                break;
+            }
+            int height = to_j - blk_js < cols * 5 / 4 ? to_j - blk_js : cols * 5 / 4;
             for (;;) {
-                const int jlo_raw = to_j - height > 0 ? to_j - height : 0;
+                const int jlo_raw = to_j - height > cm.js ? to_j - height : cm.js;
                 const int jlo = jlo_raw & ~63, jhi = (to_j + 63) & ~63;
                 const int words = (jhi - jlo) >> 6;
                 if (words > tj.scratch_words) {  // taller than this pair's scratch: leave it to the host engine
                     failed = true;
                     break;
                 }
-                // left column = the checkpoint's words of these rows (init_v_with_overlap, blocks.rs:753-767)
+                n_fill_try += 1;
+                // left column = the checkpoint's words of these rows, V::one outside its range (init_v_with_overlap, blocks.rs:753-767)
                 for (int wi = lane; wi < words; wi += 64) {
+                    const int aw = (jlo >> 6) + wi;
+                    const bool inr = ck != nullptr && aw >= (cm.js >> 6) && aw < (cm.je >> 6);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) sv[wi * 4 + c] = ck ? ck[((jlo >> 6) + wi) * 4 + c] : (c < 2 ? 0xFFFFFFFFu : 0u);
+                    for (int c = 0; c < 4; ++c) sv[wi * 4 + c] = inr ? ck[aw * 4 + c] : (c < 2 ? 0xFFFFFFFFu : 0u);
                 }
-                const int32_t T0 = i0 + column_prefix(ck, jlo, lane);
+                const int32_t T0 = cm.top + (ck ? column_prefix_lim(ck + (size_t)(cm.js >> 6) * 4, jlo - cm.js, cm.je - cm.js, lane) : jlo - cm.js);
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // same wavefront produces and consumes: ordering only, no L2 write-back
                 const int S = (words + 31) >> 5;  // strips of 32 words, top to bottom
                 for (int st = 0; st < S; ++st) {
@@ -408,8 +460,12 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kerne
                 f_words = words;
                 f_T0 = T0;
                 const int32_t val = T0 + cols + column_prefix(filled_col(to_i), to_j - jlo, lane);
-                if (val == g) break;
-                if (jlo == 0) {  // "No trace found through block"
+                if (val == g) {
+                    n_fill_ok += 1;
+                    break;
+                }
+                n_fill_fb += 1;
+                if (jlo == 0 || height == 0 || to_j - height <= cm.js) {  // "No trace found through block" (the others: the reference would loop)
                     failed = true;
                     break;
                 }
@@ -437,9 +493,12 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kerne
         }
         // previous column: the checkpoint itself when to_i - 1 == f_i0, else a filled column
         const bool prev_ck = (to_i - 1 == f_i0);
-        const gcu32 pc = prev_ck ? ckpt_col(f_i0) : filled_col(to_i - 1);
-        const int p_jlo = prev_ck ? 0 : f_jlo;
-        const int32_t p_top = prev_ck ? f_i0 : f_T0 + (to_i - 1 - f_i0);
+        BlkMeta pm{f_jlo, f_jhi, f_T0 + (to_i - 1 - f_i0)};
+        if (prev_ck) pm = blk_meta(((f_i0 + 255) >> 8));
+        const gcu32 pc_raw = prev_ck ? ckpt_col(f_i0) : filled_col(to_i - 1);
+        const gcu32 pc = (prev_ck && pc_raw) ? pc_raw + (size_t)(pm.js >> 6) * 4 : pc_raw;  // first stored row = pm.js
+        const int p_jlo = pm.js;
+        const int32_t p_top = pm.top;
         const bool p_idx = to_j >= p_jlo;  // Block::index is defined there
         int32_t p_part = 0;                 // this lane's share of the prefix sum of the previous column up to row to_j
         uint32_t prev_p = 0, prev_m = 0;    // the dwords of the previous column that hold row r
@@ -491,7 +550,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kerne
             }
         }
         int32_t hd = 1;
-        if (p_idx) hd = g - (p_top + (prev_ck ? column_prefix(pc, to_j, lane) : (p_wide ? column_prefix(pc, to_j - p_jlo, lane) : wave_sum(p_part))));
+        if (p_idx) hd = g - (p_top + (prev_ck ? column_prefix_lim(pc, to_j - p_jlo, pm.je - p_jlo, lane) : (p_wide ? column_prefix(pc, to_j - p_jlo, lane) : wave_sum(p_part))));
         if (hd == 1) {
             g -= 1;
             to_i -= 1;
@@ -503,8 +562,14 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kerne
             break;
         }
         int32_t pd;
-        if (prev_ck) {
-            pd = column_diff(pc, r);
+        if (prev_ck && to_j > pm.je) {  // trace.rs:210-215: one row below the previous block's range
+            if (to_j != pm.je + 1) {
+                failed = true;
+                break;
+            }
+            pd = 1 - hd;  // dd = 1
+        } else if (prev_ck) {
+            pd = column_diff(pc, r - p_jlo);
         } else {
             const uint32_t p = rfl(prev_p), m = rfl(prev_m);
             pd = (int32_t)((p >> (r & 31)) & 1u) - (int32_t)((m >> (r & 31)) & 1u);
@@ -531,6 +596,15 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kerne
         if (g != 0) failed = true;  // "trace ends at distance 0"
     }
     if (lane == 0) *(gu32)tj.cigar_len = failed ? kTraceFailed : len;
+    if (tj.tstats && lane == 0) {
+        gu32 ts = (gu32)tj.tstats;
+        ts[0] = n_dt_try;
+        ts[1] = n_dt_ok;
+        ts[2] = n_dt_fb;
+        ts[3] = n_fill_try;
+        ts[4] = n_fill_ok;
+        ts[5] = n_fill_fb;
+    }
 }
 
 }  // namespace pa

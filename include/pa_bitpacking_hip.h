@@ -138,6 +138,21 @@ int pa_batch_align(pa_batch* plan, int32_t* cost_out, char** cigar_out, float* f
 /* Pairs (summed over all pa_batch_align calls of this plan) whose traceback was redone by the host engine. */
 size_t pa_batch_trace_fallbacks(const pa_batch* plan);
 
+/* ---- batched A*PA2 (band-limited alignment of many pairs) ------------------------------------------------------------ */
+/* What a loop over pa_align(a, b, params, trace = 1, ..) returns -- cost, CIGAR and statistics of AstarPa2Params::simple()
+ * and its relatives (astarpa2/src/params.rs:70-96; the loop of pa-bin/src/main.rs:24-35) -- for many pairs at once: ONE
+ * WAVEFRONT runs a pair's whole band search on the GPU (every align_for_bounded_dist pass of domain.rs:356-541, the doubling
+ * of band.rs:100-141 included, no host round trip per block, pass or pair), a second kernel walks the blocks of the
+ * successful pass back (Blocks::trace with DT-trace, blocks/trace.rs:21-416).  Only the band is computed, not the matrix.
+ * Supported parameters: Domain::Astar with NoCost / GapCost / SH, block_width 256, front.sparse, no incremental doubling, no
+ * pruning, BandDoubling or LinearSearch (NULL otherwise: use pa_align).  Results come from pa_batch_align(); a pair the
+ * kernels hand back (an empty sequence, a re-fill taller than 8192 rows, a state the reference would panic on) is redone by
+ * pa_align's engine transparently.  pa_batch_pair_stats: the statistics of every pair of the last pa_batch_align (timers 0). */
+struct pa_astarpa2_stats;
+pa_batch* pa_batch_create_params(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len,
+                                 size_t pairs, const struct pa_astarpa2_params* params);
+int pa_batch_pair_stats(const pa_batch* plan, struct pa_astarpa2_stats* stats_out);
+
 /* Many-pair mode over several GPUs from ONE process (independent pairs shard with no data-path exchange; the
  * reference runs them one after another, pa-bin/src/main.rs:24-35).  Pairs are assigned longest-processing-time-first by
  * n * ceil(m / 64); one host thread per entry of devices[0..ndevices) binds its device and runs one pa_batch_align over its

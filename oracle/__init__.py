@@ -311,6 +311,33 @@ def sweep_emu_align(a: bytes, b: bytes, params: AstarPa2ParamsC, trace: bool = T
     return rc, cost.value, s, stats.as_dict(), info.tolist()
 
 
+_alib = None
+
+
+def apa2_emu_align(a: bytes, b: bytes, params: AstarPa2ParamsC):
+    """The product's per-pair A*PA2 program (apa2_logic.hpp: what ONE wavefront runs per pair in the batched mode) over the CPU
+    oracle kernels.  -> (rc, cost, cigar, stats, info); rc 0 = ran, 1 = not supported, 2 = handed back (info[0] = status);
+    info[1] = fixed_j_range scans, info[2] = scans where the reference's jumping probes did not end on the first / last row."""
+    global _alib
+    if _alib is None:
+        build()
+        L = C.CDLL(str(_DIR / "_build" / "libpa_apa2_emu.so"))
+        L.pa_apa2_emu_align.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(AstarPa2ParamsC), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_void_p), C.POINTER(AstarPa2StatsC), C.c_void_p]
+        L.pa_apa2_emu_align.restype = C.c_int
+        _alib = L
+    cost = C.c_int32(0)
+    cig = C.c_void_p(None)
+    stats = AstarPa2StatsC()
+    info = np.zeros(8, np.int32)
+    rc = _alib.pa_apa2_emu_align(_buf(a), len(a), _buf(b), len(b), C.byref(params), C.byref(cost), C.byref(cig), C.byref(stats), _p(info))
+    s = None
+    if cig.value:
+        s = C.string_at(cig.value).decode()
+        engine_lib().pa_cpu_free(cig)
+    return rc, cost.value, s, stats.as_dict(), info.tolist()
+
+
 def cpu_align_blocks(a: bytes, b: bytes, params: AstarPa2ParamsC):
     """The blocks of the engine's last completed pass (traceback mode, before the trace): (cost, f_max, [dict per block]).
     v of a block = list of (p, m) words covering rows [js, je)."""

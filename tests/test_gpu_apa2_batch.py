@@ -1,0 +1,126 @@
+"""Batched A*PA2 on the GPU (pa_batch_create_params / pa_batch_align / pa_batch_pair_stats): ONE wavefront runs a pair's whole band
+search (csrc/apa2_logic.hpp over the gfx950 backend of csrc/apa2_kernel.hpp), the traceback kernel walks the banded blocks of
+the successful pass.  For every pair the cost, the CIGAR string and all twelve statistics must equal what the host engine over
+the CPU oracle kernels returns for the same parameters (`oracle.cpu_align`) -- i.e. what a loop over pa_align returns."""
+import random
+
+import numpy as np
+import pytest
+
+from tests.test_sweep_emu import KEYS, variants
+from tests.util_seq import PA_TEST_PAIRS, gen_pair, rand_seq
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import astar_pairwise_aligner_amd as pa
+
+    pa.require_gpu()
+    return pa
+
+
+def check(pa, oracle, pairs, oc, fallbacks=None, verify_only_sample=None):
+    from tests.test_gpu_engine import gpu_params
+
+    batch = pa.Batch(pairs, params=gpu_params(pa, oc))
+    costs, cigars, fwd_ms, trace_ms = batch.align()
+    stats = batch.pair_stats()
+    idx = range(len(pairs)) if verify_only_sample is None else verify_only_sample
+    for i in idx:
+        a, b = pairs[i]
+        want_cost, want_cigar, want_stats = oracle.cpu_align(a, b, oc)
+        assert costs[i] == want_cost, (i, len(a), len(b))
+        assert cigars[i] == want_cigar, (i, len(a), len(b), cigars[i][:80], want_cigar[:80])
+        assert {k: stats[i][k] for k in KEYS} == {k: want_stats[k] for k in KEYS}, (i, len(a), len(b))
+    if fallbacks is not None:
+        assert batch.trace_fallbacks() == fallbacks
+    costs2, cigars2, _, _ = batch.align()  # idempotent on resident inputs
+    assert np.array_equal(costs, costs2) and cigars == cigars2
+    batch.close()
+    return costs, cigars, fwd_ms, trace_ms
+
+
+def test_block_boundary_sizes(pa, oracle):
+    pairs = []
+    for n in (1, 2, 31, 32, 33, 63, 64, 65, 255, 256, 257, 511, 512, 513, 769, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 8191):
+        for e in (0.0, 0.05, 0.4, 1.0):
+            pairs.append(gen_pair(n, e, seed=n * 7 + int(e * 100)))
+    costs, _, _, _ = check(pa, oracle, pairs, oracle.params_simple(), fallbacks=0)
+    for (a, b), c in zip(pairs, costs):
+        assert c == oracle.levenshtein(a, b)
+
+
+def test_pa_test_pairs_and_degenerate_inputs(pa, oracle):
+    """Empty sequences are handed to the host engine (counted as fallbacks); the reference's literal pairs run on the device."""
+    pairs = [p for p in PA_TEST_PAIRS] + [(b"", b""), (b"ACGT", b""), (b"", b"ACGTA"), (b"A", b"A"), (b"A", b"C")]
+    check(pa, oracle, pairs, oracle.params_simple())
+
+
+@pytest.mark.parametrize("name", ["simple", "dijkstra", "sh12", "sh5", "gap_nosparseh", "gap_nodt", "gap_startgap", "gap_startzero_f15", "linear"])
+def test_variants_multi_strip(pa, oracle, name):
+    """Several passes, bands of several 2048-row strips."""
+    oc = variants(oracle)[name]
+    pairs = [gen_pair(n, e, seed) for n, e, seed in [(300, 0.05, 1), (3000, 0.1, 3), (10000, 0.15, 4), (30000, 0.2, 6), (20000, 0.3, 5)]]
+    costs, cigars, _, _ = check(pa, oracle, pairs, oc)
+    for (a, b), c, cg in zip(pairs, costs, cigars):
+        assert oracle.cigar_verify(cg, a, b) == c
+
+
+def test_indels_and_unequal_lengths(pa, oracle):
+    a = rand_seq(3000, seed=5)
+    pairs = [
+        (a, a[:1000] + a[1400:]),                       # 400-column deletion
+        (a[:1000] + a[1400:], a),                       # 400-row insertion
+        (a, a[:700] + rand_seq(300, seed=6) + a[700:]),  # foreign insert
+        (rand_seq(700, seed=1), rand_seq(2300, seed=2)),  # unrelated, tall
+        (rand_seq(2300, seed=3), rand_seq(70, seed=4)),   # unrelated, wide
+        (a, a),
+        (a[500:], a),                                   # the alignment starts with 500 insertions
+        (a, a[500:]),                                   # ... with 500 deletions (walks the top row)
+    ]
+    check(pa, oracle, pairs, oracle.params_simple())
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_pairs_all_variants(pa, oracle, seed):
+    rng = random.Random(seed)
+    vs = variants(oracle)
+    for name in vs:
+        pairs = []
+        for _ in range(24):
+            n = rng.choice([rng.randint(1, 600), rng.randint(600, 4000), rng.randint(4000, 14000)])
+            e = rng.choice([0.0, 0.01, 0.05, 0.1, 0.2, 0.4, 0.8])
+            s = rng.randint(1, 10**6)
+            a, b = gen_pair(n, e, s)
+            mode = rng.random()
+            if mode < 0.25 and n > 50:  # a long indel
+                cut = rng.randint(0, len(b) - 1)
+                ln = rng.randint(1, max(1, min(3000, len(b) // 2)))
+                b = b[:cut] + b[cut + ln:] if rng.random() < 0.5 else b[:cut] + rand_seq(ln, s + 1) + b[cut:]
+                b = b or b"A"
+            elif mode < 0.3:
+                b = rand_seq(rng.randint(1, n + 50), s + 2)  # unrelated
+            pairs.append((a, b))
+        check(pa, oracle, pairs, vs[name])
+
+
+def test_c4_like_mixed_divergence(pa, oracle):
+    """BASELINE C4's shape at a size the CPU engine checks in seconds: 10 kbp pairs, 1-15 % mixed divergence."""
+    pairs = [gen_pair(10000, e, seed=100 + k) for k, e in enumerate([0.01, 0.05, 0.10, 0.15] * 16)]
+    check(pa, oracle, pairs, oracle.params_simple(), fallbacks=0)
+
+
+def test_c3_like_100kbp(pa, oracle):
+    """BASELINE C3's pair (100 kbp, 5 %) and three neighbours through the batched path."""
+    pairs = [gen_pair(100000, e, seed=7 + k) for k, e in enumerate([0.05, 0.01, 0.10, 0.05])]
+    check(pa, oracle, pairs, oracle.params_simple(), fallbacks=0)
+
+
+def test_unsupported_parameters_are_refused(pa, oracle):
+    from tests.test_gpu_engine import gpu_params
+
+    for oc in (oracle.params_full(), oracle.params_nw()):
+        with pytest.raises(pa.PaError):
+            pa.Batch([gen_pair(500, 0.1, 1)], params=gpu_params(pa, oc))

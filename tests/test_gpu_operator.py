@@ -159,6 +159,35 @@ def test_batch_shapes(pa, oracle, monkeypatch, k, mode):
     batch.close()
 
 
+@pytest.mark.parametrize("k", [1, 2, 4, 8])
+@pytest.mark.parametrize("mode", ["chain", "seq"])
+def test_batch_shapes_low_complexity_first_column(pa, oracle, monkeypatch, k, mode):
+    """The first character of `a` does not occur in the first rows of `b` (several lanes deep): every lane must see column 0's
+    own eq word.  (Random sequences hide a wrong eq there: a[0] almost surely matches somewhere in lane 0's rows, after which
+    the horizontal delta is -1 all the way down whatever eq says.)  With eq words prefetched from LDS (k = 4, 8) lanes >= 1
+    once took the eq word of 'A' for column 0."""
+    monkeypatch.setenv("PA_STRIP_K", str(k))
+    monkeypatch.setenv("PA_BATCH_MODE", mode)
+    pairs = []
+    for first, fill in ((b"C", b"A"), (b"G", b"T"), (b"T", b"C"), (b"A", b"G")):
+        for depth in (300, 700, 2048 * k + 300):
+            y = rand_seq(900, seed=depth + k)
+            pairs.append((first + y, fill * depth + y))
+            pairs.append((first * 3 + y, fill * depth + first + y))
+    batch = pa.Batch(pairs)
+    costs, _ = batch.run()
+    for (a, b), c in zip(pairs, costs):
+        want = oracle.levenshtein(a, b) if len(a) * len(b) < 4_000_000 else oracle.nw_cost(a, b, True)
+        assert c == want, (a[:4], b[:4], len(a), len(b))
+    batch.close()
+    tb = pa.Batch(pairs, trace=True)  # the checkpointing variants of the same kernels
+    costs2, cigars, _, _ = tb.align()
+    assert np.array_equal(costs, costs2)
+    for (a, b), c, cg in zip(pairs, costs2, cigars):
+        assert oracle.cigar_verify(cg, a, b) == c
+    tb.close()
+
+
 @pytest.mark.parametrize("mode", ["chain", "seq"])
 @pytest.mark.parametrize("k", [0, 1, 2, 4, 8])
 @pytest.mark.parametrize("hint", [0.0, 0.02, 0.3])

@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "pa_pairs_read", "pa_pairs_count", "pa_pairs_get", "pa_pairs_free", "pa_write_results_csv", "pa_align_file",
     "pa_align", "pa_batch_align_multi", "pa_batch_create_trace_params",
     "pa_bp_ctx_create", "pa_bp_ctx_compute", "pa_bp_ctx_fill", "pa_bp_ctx_destroy",
-    "pa_batch_create_params", "pa_batch_pair_stats",
+    "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools",
 ]
 
 _lib = None
@@ -52,6 +52,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     if not path.exists():
         raise PaError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
     L = C.CDLL(str(path))
+    L.pa_runtime_hints.restype = C.c_int
+    L.pa_runtime_hints()  # this package is the application here: more hardware queues, before the first HIP call
     vp, sz = C.c_void_p, C.c_size_t
     L.pa_last_error.restype = C.c_char_p
     L.pa_device_count.restype = C.c_int
@@ -105,6 +107,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_write_results_csv.restype = C.c_int
     L.pa_batch_align_multi.argtypes = [vp, vp, vp, vp, sz, C.POINTER(C.c_int), C.c_int, vp, vp]
     L.pa_batch_align_multi.restype = C.c_int
+    L.pa_batch_align_multi_params.argtypes = [vp, vp, vp, vp, sz, C.POINTER(C.c_int), C.c_int, vp, vp, vp, vp]
+    L.pa_batch_align_multi_params.restype = C.c_int
     L.pa_align_file.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(sz)]
     L.pa_align_file.restype = C.c_int
     for name in ("astarpa2_simple", "astarpa2_full", "astarpa"):
@@ -269,8 +273,9 @@ class OperatorContext:
             pass
 
 
-def align_multi(pairs: list[tuple[bytes, bytes]], devices: list[int], trace: bool = True):
-    """pa_batch_align_multi: shard `pairs` over `devices` (one host thread each, inside the library) -> (costs, CIGARs or None)."""
+def align_multi(pairs: list[tuple[bytes, bytes]], devices: list[int], trace: bool = True, params=None, stats: bool = False):
+    """pa_batch_align_multi[_params]: a work queue of chunks of `pairs` served by one host thread per entry of `devices` (inside the
+    library) -> (costs, CIGARs or None[, per-pair statistics]).  params: an AstarPa2Params of the `simple` family -> batched A*PA2."""
     L = load()
     n = len(pairs)
     ap = (C.c_void_p * n)(*[C.cast(C.c_char_p(a), C.c_void_p) for a, _ in pairs])
@@ -280,19 +285,31 @@ def align_multi(pairs: list[tuple[bytes, bytes]], devices: list[int], trace: boo
     dev = (C.c_int * len(devices))(*devices)
     out = np.zeros(n, np.int32)
     cig = (C.c_void_p * n)() if trace else None
-    rc = L.pa_batch_align_multi(ap, al, bp, bl, n, dev, len(devices), _p(out), cig)
+    st = None
+    if params is not None:
+        from .aligner import _StatsC
+
+        cp = params._to_c()
+        st = (_StatsC * max(n, 1))() if stats else None
+        rc = L.pa_batch_align_multi_params(ap, al, bp, bl, n, dev, len(devices), C.byref(cp), _p(out), cig, st)
+    else:
+        rc = L.pa_batch_align_multi(ap, al, bp, bl, n, dev, len(devices), _p(out), cig)
     if rc == -1:
         raise ValueError("sequence contains a character outside ACGT")
     if rc != 0:
         raise PaError(f"pa_batch_align_multi rc={rc}: {last_error()}")
-    if not trace:
-        return out, None
-    try:
-        cigars = [C.string_at(cig[i]).decode() if cig[i] else "" for i in range(n)]
-    finally:
-        for i in range(n):
-            if cig[i]:
-                L.astarpa_free_cigar(C.c_void_p(cig[i]))
+    cigars = None
+    if trace:
+        try:
+            cigars = [C.string_at(cig[i]).decode() if cig[i] else "" for i in range(n)]
+        finally:
+            for i in range(n):
+                if cig[i]:
+                    L.astarpa_free_cigar(C.c_void_p(cig[i]))
+    if st is not None:
+        from .aligner import _StatsC
+
+        return out, cigars, [{k: getattr(st[i], k) for k, _ in _StatsC._fields_} for i in range(n)]
     return out, cigars
 
 

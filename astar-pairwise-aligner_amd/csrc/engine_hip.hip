@@ -410,8 +410,12 @@ struct HipBackend {
 };
 
 // One backend per host thread and device, reused from call to call.
-static HipBackend& pooled_backend() {
+static std::unique_ptr<HipBackend>& pooled_backend_slot() {
     static thread_local std::unique_ptr<HipBackend> tl;
+    return tl;
+}
+static HipBackend& pooled_backend() {
+    std::unique_ptr<HipBackend>& tl = pooled_backend_slot();
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!tl || (tl->device >= 0 && tl->device != dev)) tl = std::make_unique<HipBackend>();
@@ -497,8 +501,12 @@ struct SweepPool {
         return h_pin;
     }
 };
-static SweepPool& sweep_pool() {
+static std::unique_ptr<SweepPool>& sweep_pool_slot() {
     static thread_local std::unique_ptr<SweepPool> tl;
+    return tl;
+}
+static SweepPool& sweep_pool() {
+    std::unique_ptr<SweepPool>& tl = sweep_pool_slot();
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!tl || tl->device != dev) {
@@ -532,7 +540,7 @@ struct HipSweepLauncher {
     SweepSlot& slot_of(int seq) { return pool.slots[seq % SweepPool::kSlots]; }
     // (a pass's records must outlive its successor, which reads them: one slot more than passes in flight)
     // Passes in flight run on separate streams, and streams only run side by side on separate hardware queues: the ROCm runtime
-    // multiplexes all streams of a process over GPU_MAX_HW_QUEUES of them (default 4; pa_sweep_runtime_hints below asks for 16
+    // multiplexes all streams of a process over GPU_MAX_HW_QUEUES of them (default 4; pa_runtime_hints() below asks for 16
     // when the library is loaded before the runtime starts).  A pass queued BEHIND a later one would only cost time, never
     // correctness: passes are submitted in order and wait for their predecessors only.
     // Every pass in flight is a RUNNING kernel (it polls its predecessor) on a stream of its own, and the GPU serves only so many
@@ -652,6 +660,9 @@ struct HipSweepLauncher {
         if (pv && (pv == &sl || pv->seq != prev_seq)) hip_fail("sweep slot of the previous pass was reused");
         const bool pv_running = pv && pv->live;  // still in flight: read its records as they appear; else only its merged array
         const BlockRec* merged_in = pv ? pv->d_merged.as<BlockRec>() : pool.d_merged0.as<BlockRec>();
+        // tags carry 12 bits of pass id (sweep_logic.hpp blk_tag) and the tagged buffers are cleared between pairs only: a pair that
+        // needs more passes than that (LinearSearch with a small delta) goes to the host-driven engine instead of aliasing tags
+        if (pool.pass_id >= 4000) throw SweepFallback("pass ids exhausted within one pair", -4);
         pool.pass_id += 1;
         sl.seq = seq;
         sl.pass = pool.pass_id;
@@ -826,9 +837,22 @@ struct HipSweepLauncher {
     }
 };
 
-// Runs when the library is loaded: more hardware queues for the pipelined passes (no effect if the application has set the
-// variable itself or has started the HIP runtime already).
-__attribute__((constructor)) static void pa_sweep_runtime_hints() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// More hardware queues for the pipelined passes.  NOT done behind the application's back when the library is loaded (a library that
+// edits the process environment at dlopen surprises every other HIP user in the process and races with their getenv): the
+// application calls this once, before anything starts the HIP runtime, or exports the variable itself.  Returns 1 if it set the
+// variable, 0 if it was set already (left alone).
+extern "C" int pa_runtime_hints(void) {
+    if (std::getenv("GPU_MAX_HW_QUEUES")) return 0;
+    return setenv("GPU_MAX_HW_QUEUES", "16", 0) == 0 ? 1 : 0;
+}
+
+// pa_align and the drop-in symbols keep their device buffers, pinned staging and streams in per-thread pools that only grow (one
+// 10 Mbp call leaves gigabytes behind): this returns the calling thread's pools to the driver.  The next call builds them again.
+extern "C" void pa_release_pools(void) {
+    (void)hipDeviceSynchronize();
+    sweep_pool_slot().reset();
+    pooled_backend_slot().reset();
+}
 
 // The engine's bookkeeping without any kernel work (used where the numbers come from a fused GPU pass).
 struct StatsOnlyBackend {
@@ -939,7 +963,18 @@ using namespace pa;
 struct pa_bp_ctx {
     HipBackend be;
     engine::BlockParams bp;
+    int device = -1;  // the device its buffers and its stream live on
 };
+// A handle launches on the device it was created on: a call from a thread whose current device is another one is refused instead of
+// launching there with pointers of this one.
+static bool ctx_device_ok(const pa_bp_ctx* c, const char* what) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != c->device) {
+        set_error("%s: the handle belongs to device %d, this thread's current device is %d (pa_set_device first)", what, c->device, cur);
+        return false;
+    }
+    return true;
+}
 
 extern "C" pa_bp_ctx* pa_bp_ctx_create(const uint8_t* a, size_t n, const uint8_t* b, size_t m) {
     if (n > (size_t)(1u << 30) || m > (size_t)(1u << 30)) {
@@ -953,6 +988,7 @@ extern "C" pa_bp_ctx* pa_bp_ctx_create(const uint8_t* a, size_t n, const uint8_t
     }
     c->be.bind(a, n, b, m);
     if (!c->be.ok) return nullptr;
+    (void)hipGetDevice(&c->device);
     try {
         c->be.enable_h_row();
     } catch (const engine::EnginePanic&) {
@@ -966,6 +1002,7 @@ extern "C" int pa_bp_ctx_compute(pa_bp_ctx* c, int32_t i0, int32_t i1, size_t w0
         set_error("pa_bp_ctx_compute: bad arguments");
         return PA_E_ARG;
     }
+    if (!ctx_device_ok(c, "pa_bp_ctx_compute")) return PA_E_ARG;
     static_assert(sizeof(engine::V) == 16, "V is (p: u64, m: u64)");
     try {
         const engine::Cost s = c->be.compute(i0, i1, w0, w1, reinterpret_cast<engine::V*>(v), (engine::HMode)h_mode, c->bp);
@@ -981,6 +1018,7 @@ extern "C" int pa_bp_ctx_fill(pa_bp_ctx* c, int32_t i0, int32_t i1, size_t w0, s
         set_error("pa_bp_ctx_fill: bad arguments");
         return PA_E_ARG;
     }
+    if (!ctx_device_ok(c, "pa_bp_ctx_fill")) return PA_E_ARG;
     try {
         std::vector<int8_t> hb((size_t)(i1 - i0) + 1, 0);
         c->be.fill(i0, i1, w0, w1, reinterpret_cast<engine::V*>(v), reinterpret_cast<engine::V*>(values), hb.data(), c->bp);

@@ -12,6 +12,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -177,13 +178,17 @@ extern "C" int pa_align_file(const char* input_path, const char* output_path, si
 }
 
 // Many-pair mode over several GPUs from ONE process (the reference aligns pairs one after another,
-// pa-bin/src/main.rs:24-35, so they shard with no data-path exchange).  Pairs are assigned longest-processing-time-first by
-// n * ceil(m / 64) (the same plan as sharding.py plan_shards); one host thread per entry of `devices` selects its device
-// (pa_set_device is per thread), runs one pa_batch_align (or the cost-only batch when cigar_out is NULL) over its shard and
-// scatters the results back.  A device may be listed more than once (two shards in flight on one GPU).
-extern "C" int pa_batch_align_multi(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len,
-                                    size_t pairs, const int* devices, int ndevices, int32_t* cost_out, char** cigar_out) {
-    if (ndevices <= 0 || !devices || !cost_out || (pairs && (!a || !b || !a_len || !b_len))) {
+// pa-bin/src/main.rs:24-35, so they shard with no data-path exchange): a WORK QUEUE.  The pairs are sorted by estimated work
+// (heaviest first), cut into chunks, and one host thread per entry of `devices` binds its device (pa_set_device is per thread) and
+// pulls chunk after chunk from one atomic counter: pa_batch_create* + pa_batch_align (or the cost-only batch when cigar_out is NULL)
+// per chunk, results scattered to the pairs' own indices.  The estimate only orders the queue -- the balance is dynamic, which is
+// what band-limited alignment needs (the work of a pair depends on its divergence, which nobody knows beforehand).  A device may
+// be listed more than once (two chunks in flight on one GPU: the upload of one overlaps the kernels of the other).
+// `params` != NULL: the batched A*PA2 of pa_batch_create_params (the `simple` preset and its relatives).
+static int batch_align_queue(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len, size_t pairs,
+                             const int* devices, int ndevices, int32_t* cost_out, char** cigar_out, const pa_astarpa2_params* params,
+                             pa_astarpa2_stats* stats_out) {
+    if (ndevices <= 0 || !devices || !cost_out || (pairs && (!a || !b || !a_len || !b_len)) || (stats_out && !params)) {
         pa::set_error("pa_batch_align_multi: bad arguments");
         return PA_E_ARG;
     }
@@ -195,31 +200,33 @@ extern "C" int pa_batch_align_multi(const uint8_t* const* a, const size_t* a_len
         }
     if (cigar_out)
         for (size_t i = 0; i < pairs; ++i) cigar_out[i] = nullptr;
-    // longest-processing-time-first, ties by index: deterministic
+    // heaviest first, ties by index: deterministic queue order.  Full DP: n * ceil(m / 64) word updates; band-limited: the band of a
+    // pair grows with its length too (n * sqrt-ish), the plain length orders those well enough.
     std::vector<size_t> order(pairs);
     std::vector<uint64_t> work(pairs);
     for (size_t i = 0; i < pairs; ++i) {
         order[i] = i;
-        work[i] = (uint64_t)a_len[i] * ((b_len[i] + 63) / 64) + 1;
+        work[i] = params ? (uint64_t)a_len[i] + b_len[i] + 1 : (uint64_t)a_len[i] * ((b_len[i] + 63) / 64) + 1;
     }
     std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return work[x] != work[y] ? work[x] > work[y] : x < y; });
-    std::vector<std::vector<size_t>> shard((size_t)ndevices);
-    std::vector<uint64_t> load((size_t)ndevices, 0);
-    for (size_t i : order) {
-        size_t r = 0;
-        for (size_t k = 1; k < (size_t)ndevices; ++k)
-            if (load[k] < load[r]) r = k;
-        shard[r].push_back(i);
-        load[r] += work[i];
-    }
+    // chunks: about eight per device, at least 256 pairs each (a chunk must still fill a GPU), one per device when there are few pairs
+    size_t chunk = pairs / ((size_t)ndevices * 8) + 1;
+    if (chunk < 256) chunk = 256;
+    if (chunk * (size_t)ndevices > pairs) chunk = (pairs + (size_t)ndevices - 1) / (size_t)ndevices;
+    if (chunk == 0) chunk = 1;
+    if (const char* e = std::getenv("PA_MULTI_CHUNK")) chunk = std::max<size_t>(1, (size_t)std::atoll(e));  // (tests)
+    const size_t nchunks = (pairs + chunk - 1) / chunk;
+    std::atomic<size_t> next{0};
+    std::atomic<bool> failed{false};
     std::vector<int> rcs((size_t)ndevices, 0);
     std::vector<std::string> errs((size_t)ndevices);
     auto worker = [&](int r) {
-        std::vector<size_t>& mine = shard[(size_t)r];
-        std::sort(mine.begin(), mine.end());
-        if (mine.empty()) return;
         int rc = pa_set_device(devices[r]);
-        if (rc == 0) {
+        while (rc == 0 && !failed.load(std::memory_order_relaxed)) {
+            const size_t c = next.fetch_add(1, std::memory_order_relaxed);
+            if (c >= nchunks) break;
+            std::vector<size_t> mine(order.begin() + c * chunk, order.begin() + std::min(pairs, (c + 1) * chunk));
+            std::sort(mine.begin(), mine.end());
             const size_t k = mine.size();
             std::vector<const uint8_t*> ap(k), bp(k);
             std::vector<size_t> al(k), bl(k);
@@ -231,20 +238,27 @@ extern "C" int pa_batch_align_multi(const uint8_t* const* a, const size_t* a_len
             }
             std::vector<int32_t> costs(k, 0);
             std::vector<char*> cigars(cigar_out ? k : 0, nullptr);
-            pa_batch* plan = cigar_out ? pa_batch_create_trace(ap.data(), al.data(), bp.data(), bl.data(), k)
-                                       : pa_batch_create(ap.data(), al.data(), bp.data(), bl.data(), k);
+            std::vector<pa_astarpa2_stats> st(stats_out ? k : 0);
+            pa_batch* plan = params ? pa_batch_create_params(ap.data(), al.data(), bp.data(), bl.data(), k, params)
+                             : cigar_out ? pa_batch_create_trace(ap.data(), al.data(), bp.data(), bl.data(), k)
+                                         : pa_batch_create(ap.data(), al.data(), bp.data(), bl.data(), k);
             if (!plan) rc = PA_E_HIP;
             else {
-                rc = cigar_out ? pa_batch_align(plan, costs.data(), cigars.data(), nullptr, nullptr) : pa_batch_run(plan, costs.data(), nullptr);
+                rc = (cigar_out || params) ? pa_batch_align(plan, costs.data(), cigar_out ? cigars.data() : nullptr, nullptr, nullptr) : pa_batch_run(plan, costs.data(), nullptr);
+                if (rc == 0 && stats_out) rc = pa_batch_pair_stats(plan, st.data());
                 pa_batch_destroy(plan);
             }
             if (rc == 0)
                 for (size_t j = 0; j < k; ++j) {
                     cost_out[mine[j]] = costs[j];
                     if (cigar_out) cigar_out[mine[j]] = cigars[j];
+                    if (stats_out) stats_out[mine[j]] = st[j];
                 }
+            else
+                for (char* g : cigars) std::free(g);
         }
         if (rc != 0) {
+            failed.store(true, std::memory_order_relaxed);
             rcs[(size_t)r] = rc;
             errs[(size_t)r] = pa_last_error();  // (the error text is per thread)
         }
@@ -253,7 +267,7 @@ extern "C" int pa_batch_align_multi(const uint8_t* const* a, const size_t* a_len
     for (int r = 1; r < ndevices; ++r) threads.emplace_back(worker, r);
     int cur = 0;
     (void)hipGetDevice(&cur);
-    worker(0);  // the calling thread takes the first shard
+    worker(0);  // the calling thread is the first worker
     (void)pa_set_device(cur);
     for (std::thread& t : threads) t.join();
     for (int r = 0; r < ndevices; ++r)
@@ -263,8 +277,23 @@ extern "C" int pa_batch_align_multi(const uint8_t* const* a, const size_t* a_len
                     std::free(cigar_out[i]);
                     cigar_out[i] = nullptr;
                 }
-            pa::set_error("pa_batch_align_multi: shard %d (device %d): %s", r, devices[r], errs[(size_t)r].c_str());
+            pa::set_error("pa_batch_align_multi: worker %d (device %d): %s", r, devices[r], errs[(size_t)r].c_str());
             return rcs[(size_t)r];
         }
     return 0;
+}
+
+extern "C" int pa_batch_align_multi(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len,
+                                    size_t pairs, const int* devices, int ndevices, int32_t* cost_out, char** cigar_out) {
+    return batch_align_queue(a, a_len, b, b_len, pairs, devices, ndevices, cost_out, cigar_out, nullptr, nullptr);
+}
+
+extern "C" int pa_batch_align_multi_params(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len,
+                                           size_t pairs, const int* devices, int ndevices, const pa_astarpa2_params* params, int32_t* cost_out,
+                                           char** cigar_out, pa_astarpa2_stats* stats_out) {
+    if (!params) {
+        pa::set_error("pa_batch_align_multi_params: params is NULL");
+        return PA_E_ARG;
+    }
+    return batch_align_queue(a, a_len, b, b_len, pairs, devices, ndevices, cost_out, cigar_out, params, stats_out);
 }

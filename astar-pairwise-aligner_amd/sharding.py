@@ -1,22 +1,47 @@
 """Batched many-pair mode across the GPUs of one node.
 
-Pairs are independent units (the reference aligns them one after another, pa-bin/src/main.rs:24-35), so the
-path shards with NO data-path collective: every rank (one process per GPU) aligns its own subset and the
-only exchange is one small tensor gather of the costs (plus one padded byte gather of the CIGAR text) at the end -- `torch.distributed` over RCCL on GPUs,
-gloo in the CPU tests.  The single-pair path stays on one GPU ("replicas only").
+Pairs are independent units (the reference aligns them one after another, pa-bin/src/main.rs:24-35), so the path shards with NO
+data-path collective: every rank (one process per GPU) aligns chunks of pairs on its own GPU, and the only exchange is the result
+gather at the end -- `torch.distributed` over RCCL on GPUs, gloo in the CPU tests.  The single-pair path stays on one GPU
+("replicas only").
+
+Work distribution is a QUEUE, not a static plan: the pairs are sorted by estimated work (heaviest first) and cut into chunks; a rank
+that is free takes the next chunk by bumping ONE counter in the process group's key-value store (the rendezvous TCPStore every
+torch.distributed job already has: an atomic `add`).  The estimate only orders the queue; the balance is dynamic, which is what
+band-limited alignment needs -- the work of a pair depends on its divergence, which nobody knows beforehand.  Without a store the
+chunks are dealt out longest-processing-time-first (`plan_shards`).
+
+Results: by default every rank ends with the full, ordered result (two tensor all-gathers: a fixed-size header per rank, then the
+padded rows); with `all_ranks=False` they are gathered to rank 0 only and the other ranks return None.
 """
 from __future__ import annotations
 
+import itertools
 from typing import Callable, Sequence
 
+_call_counter = itertools.count()
 
-def work_estimate(a_len: int, b_len: int) -> int:
-    """Word updates of the full DP: n * ceil(m/64)."""
-    return a_len * ((b_len + 63) // 64) + 1
+
+def work_estimate(a_len: int, b_len: int, band_words: int | None = None) -> int:
+    """Word updates of the full DP: n * ceil(m/64); with `band_words` the band's words per column instead."""
+    w = (b_len + 63) // 64
+    if band_words is not None:
+        w = min(w, max(1, band_words))
+    return a_len * w + 1
+
+
+def band_words_hint(a_len: int, b_len: int, divergence: float) -> int:
+    """Words per column of an A*PA2 band for an expected edit rate (band doubling ends at the first power-of-two multiple of 256
+    that holds the cost; the band is about that many rows high)."""
+    cost = abs(a_len - b_len) + divergence * max(a_len, b_len)
+    f = 256
+    while f < cost:
+        f *= 2
+    return f // 64 + 2
 
 
 def plan_shards(work: Sequence[int], world: int) -> list[list[int]]:
-    """Longest-processing-time-first assignment of pair indices to ranks (deterministic)."""
+    """Longest-processing-time-first assignment of indices to ranks (deterministic); the static fallback of the queue."""
     order = sorted(range(len(work)), key=lambda i: (-work[i], i))
     load = [0] * world
     shards: list[list[int]] = [[] for _ in range(world)]
@@ -27,6 +52,20 @@ def plan_shards(work: Sequence[int], world: int) -> list[list[int]]:
     for s in shards:
         s.sort()
     return shards
+
+
+def plan_chunks(work: Sequence[int], world: int, min_chunk: int = 256, per_rank: int = 8) -> list[list[int]]:
+    """The queue: indices sorted by work (heaviest first, ties by index), cut into chunks of about len / (world * per_rank) pairs,
+    at least `min_chunk` (a chunk must still fill a GPU), one chunk per rank when there are few pairs."""
+    n = len(work)
+    if n == 0:
+        return []
+    order = sorted(range(n), key=lambda i: (-work[i], i))
+    chunk = max(min_chunk, n // (world * per_rank) + 1)
+    if chunk * world > n:
+        chunk = (n + world - 1) // world
+    chunk = max(chunk, 1)
+    return [sorted(order[k:k + chunk]) for k in range(0, n, chunk)]
 
 
 def default_compute(pairs):
@@ -57,19 +96,53 @@ def default_align(pairs):
     return [(int(c), g) for c, g in zip(costs, cigars)]
 
 
-def sharded_align(pairs: Sequence[tuple[bytes, bytes]], compute: Callable | None = None, group=None) -> list[tuple[int, str]]:
-    """(cost, CIGAR) of every pair; same sharding as `sharded_costs`.  The exchange: one fixed-size gather of (cost, CIGAR length)
-    and one padded byte gather of the CIGAR text -- tensors, not pickled objects."""
-    return _sharded(pairs, compute or default_align, group, True)
+def astarpa2_align(params):
+    """-> a compute function: (cost, CIGAR) of `pairs` by the batched A*PA2 of pa_batch_create_params (band-limited; the `simple`
+    preset and its relatives)."""
+
+    def run(pairs):
+        from . import capi
+
+        if not pairs:
+            return []
+        batch = capi.Batch(list(pairs), params=params)
+        try:
+            costs, cigars, _, _ = batch.align()
+        finally:
+            batch.close()
+        return [(int(c), g) for c, g in zip(costs, cigars)]
+
+    return run
 
 
-def sharded_costs(pairs: Sequence[tuple[bytes, bytes]], compute: Callable | None = None, group=None) -> list[int]:
-    """Edit distance of every pair, computed by the ranks of the default (or given) process group.
-    Every rank passes the same `pairs`; every rank returns the full, ordered result."""
-    return _sharded(pairs, compute or default_compute, group, False)
+def sharded_align(pairs: Sequence[tuple[bytes, bytes]], compute: Callable | None = None, group=None, all_ranks: bool = True,
+                  work: Sequence[int] | None = None, min_chunk: int = 256):
+    """(cost, CIGAR) of every pair.  Every rank passes the same `pairs` (any indexable sequence: only the pairs of the chunks a rank
+    takes are read once `work` is given).  The exchange: a fixed-size header gather and one padded row gather -- tensors, not pickled
+    objects."""
+    return _sharded(pairs, compute or default_align, group, True, all_ranks, work, min_chunk)
 
 
-def _sharded(pairs, compute, group, with_cigar):
+def sharded_costs(pairs: Sequence[tuple[bytes, bytes]], compute: Callable | None = None, group=None, all_ranks: bool = True,
+                  work: Sequence[int] | None = None, min_chunk: int = 256):
+    """Edit distance of every pair, computed by the ranks of the default (or given) process group."""
+    return _sharded(pairs, compute or default_compute, group, False, all_ranks, work, min_chunk)
+
+
+def _queue_store(dist, group):
+    """The key-value store behind the process group (atomic add), or None."""
+    try:
+        from torch.distributed import distributed_c10d as c10d
+
+        if group is not None and group is not dist.group.WORLD:
+            return None  # (sub-groups: the static plan; their ranks would need a key space of their own)
+        return c10d._get_default_store()
+    except Exception:
+        return None
+
+
+def _sharded(pairs, compute, group, with_cigar, all_ranks, work, min_chunk):
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -77,46 +150,97 @@ def _sharded(pairs, compute, group, with_cigar):
         local = compute(list(pairs))
         return [(int(c), str(g)) for c, g in local] if with_cigar else [int(c) for c in local]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    shards = plan_shards([work_estimate(len(a), len(b)) for a, b in pairs], world)  # the same plan on every rank
-    mine = shards[rank]
-    local = list(compute([pairs[i] for i in mine]))
+    call_id = next(_call_counter)  # (collective calls happen in the same order on every rank)
+    if work is None:
+        work = [work_estimate(len(a), len(b)) for a, b in pairs]
+    chunks = plan_chunks(work, world, min_chunk=min_chunk)  # the same queue on every rank
+    store = _queue_store(dist, group)
+    # ---- pull chunks until the queue is empty ----
+    mine: list[int] = []      # pair indices in the order computed
+    local: list = []
+    taken: list[int] = []
+    if store is not None:
+        key = f"pa_work_queue_{call_id}"
+        while True:
+            c = int(store.add(key, 1)) - 1
+            if c >= len(chunks):
+                break
+            taken.append(c)
+            res = list(compute([pairs[i] for i in chunks[c]]))
+            mine.extend(chunks[c])
+            local.extend(res)
+    else:
+        static = plan_shards([sum(work[i] for i in ch) for ch in chunks], world)[rank]
+        for c in static:
+            taken.append(c)
+            res = list(compute([pairs[i] for i in chunks[c]]))
+            mine.extend(chunks[c])
+            local.extend(res)
+    sharded_last_chunks[:] = taken  # (tests / reporting: which chunks this rank took)
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    cap = max(len(sh) for sh in shards)
-    # (1) costs and CIGAR lengths: [cap, 2] int32 per rank, one all_gather
-    head = torch.zeros((cap, 2), dtype=torch.int32)
-    texts = []
-    for k, x in enumerate(local):
-        if with_cigar:
-            t = str(x[1]).encode()
-            texts.append(t)
-            head[k, 0], head[k, 1] = int(x[0]), len(t)
-        else:
-            head[k, 0] = int(x)
-    head = head.to(dev)
-    heads = torch.empty((world * cap, 2), dtype=torch.int32, device=dev)  # (the concatenated form: gloo accepts no other)
-    dist.all_gather_into_tensor(heads, head, group=group)
-    heads = heads.cpu().view(world, cap, 2)
-    costs = [0] * len(pairs)
-    for r in range(world):
-        for k, i in enumerate(shards[r]):
-            costs[i] = int(heads[r, k, 0])
-    if not with_cigar:
-        return costs
-    # (2) the CIGAR text of each rank as one padded byte row, one all_gather
-    width = max(1, int(heads[:, :, 1].sum(dim=1).max()))
-    row = torch.zeros(width, dtype=torch.uint8)
+    # ---- (1) how much every rank has: [pairs, text bytes] per rank, one tiny all_gather ----
+    texts = [str(x[1]).encode() for x in local] if with_cigar else []
     blob = b"".join(texts)
+    cnt = torch.tensor([len(mine), len(blob)], dtype=torch.int64, device=dev)
+    cnts = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(cnts, cnt, group=group)
+    cnts = cnts.cpu().view(world, 2)
+    cap = max(1, int(cnts[:, 0].max()))
+    width = max(1, int(cnts[:, 1].max()))
+    # ---- (2) per rank one padded int32 row block [cap, 3] = (pair index, cost, CIGAR length) and one padded byte row ----
+    head = torch.zeros((cap, 3), dtype=torch.int32)
+    if mine:
+        arr = np.zeros((len(mine), 3), np.int32)
+        arr[:, 0] = mine
+        arr[:, 1] = [int(x[0]) if with_cigar else int(x) for x in local]
+        if with_cigar:
+            arr[:, 2] = [len(t) for t in texts]
+        head[: len(mine)] = torch.from_numpy(arr)
+    row = torch.zeros(width, dtype=torch.uint8)
     if blob:
         row[: len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
-    rows = torch.empty(world * width, dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(rows, row.to(dev), group=group)
-    rows = rows.cpu().view(world, width).numpy()
-    out = [(0, "")] * len(pairs)
+    head, row = head.to(dev), row.to(dev)
+    root = 0
+    i_collect = all_ranks or rank == root
+    if all_ranks:
+        heads = torch.empty((world * cap, 3), dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(heads, head, group=group)
+        rows = None
+        if with_cigar:
+            rows = torch.empty(world * width, dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(rows, row, group=group)
+    else:
+        groot = dist.get_global_rank(group, root) if group is not None else root
+        hl = [torch.empty_like(head) for _ in range(world)] if rank == root else None
+        dist.gather(head, hl, dst=groot, group=group)
+        heads = torch.cat(hl) if rank == root else None
+        rows = None
+        if with_cigar:
+            rl = [torch.empty_like(row) for _ in range(world)] if rank == root else None
+            dist.gather(row, rl, dst=groot, group=group)
+            rows = torch.cat(rl) if rank == root else None
+    if not i_collect:
+        return None
+    heads = heads.cpu().view(world, cap, 3).numpy()
+    n = len(pairs)
+    costs = [0] * n
+    out = [(0, "")] * n
+    seen = 0
+    raw_rows = rows.cpu().view(world, width).numpy() if with_cigar else None
     for r in range(world):
+        k_r = int(cnts[r, 0])
         off = 0
-        raw = rows[r].tobytes()
-        for k, i in enumerate(shards[r]):
-            ln = int(heads[r, k, 1])
-            out[i] = (costs[i], raw[off:off + ln].decode())
-            off += ln
-    return out
+        raw = raw_rows[r].tobytes() if with_cigar else b""
+        for k in range(k_r):
+            i, c, ln = int(heads[r, k, 0]), int(heads[r, k, 1]), int(heads[r, k, 2])
+            costs[i] = c
+            if with_cigar:
+                out[i] = (c, raw[off:off + ln].decode())
+                off += ln
+            seen += 1
+    if seen != n:
+        raise RuntimeError(f"sharded run returned {seen} results for {n} pairs")
+    return out if with_cigar else costs
+
+
+sharded_last_chunks: list[int] = []

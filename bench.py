@@ -55,6 +55,8 @@ def parse_args():
     ap.add_argument("--c4-pairs", type=int, default=10_000)
     ap.add_argument("--no-engine", action="store_true", help="skip the single-pair A*PA2 legs (C3, drop-in loop)")
     ap.add_argument("--no-c5", action="store_true", help="skip the 10 Mbp A*PA2 leg")
+    ap.add_argument("--no-apa2", action="store_true", help="skip the batched A*PA2 legs (c4_astarpa2_simple, c3_batch_*)")
+    ap.add_argument("--c3-batch", type=int, nargs="*", default=[512, 4096], help="batch sizes of the 100 kbp batched A*PA2 leg")
     ap.add_argument("--no-c4-sharded", action="store_true", help="skip the C4 strong-scaling leg (sharded_align over all ranks)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
@@ -299,6 +301,59 @@ def main():
             bd.close()
         except Exception as e:  # (reporting only)
             out["c4_batch_align"]["dt_trace_kernel_ms"] = f"failed: {e}"
+
+    # ---- batched A*PA2 (pa_batch_create_params): AstarPa2Params::simple() for many pairs, ONE wavefront per pair runs the whole band
+    #      search, the device traceback walks the banded blocks.  Cost, CIGAR and statistics are what a loop over pa_align returns
+    #      (tests/test_gpu_apa2_batch.py); here the rates, and a sample checked against the CPU-kernel engine ----
+    if not args.no_apa2 and world == 1:
+        import oracle as _orc
+
+        divs = (0.01, 0.05, 0.10, 0.15)
+
+        def apa2_leg(ps, what, sample):
+            t = time.perf_counter()
+            ba = pa.Batch(ps, params=pa.AstarPa2Params.simple())
+            t_create = time.perf_counter() - t
+            ba.align()
+            best = (1e9, 0.0, 0.0, 0.0)
+            for _ in range(3):
+                t = time.perf_counter()
+                cs, gs, f_ms, t_ms = ba.align()
+                dt = time.perf_counter() - t
+                if dt < best[0]:
+                    best = (dt, f_ms, t_ms, ba.last_c_abi_ms)
+            sts = ba.pair_stats()
+            for i in sample:  # plumbing check on a sample (the parity tests compare every pair)
+                wc, wg, ws = _orc.cpu_align(*ps[i], _orc.params_simple())
+                assert (int(cs[i]), gs[i]) == (wc, wg) and sts[i]["computed_lanes"] == ws["computed_lanes"], f"batched A*PA2 differs from the CPU-kernel engine on pair {i}"
+            lanes = float(sum(x["computed_lanes"] for x in sts))
+            leg = {
+                "workload": what,
+                "pairs_per_sec": round(len(ps) / best[0], 1),
+                "ms": round(best[0] * 1e3, 3),
+                "c_abi_ms": round(best[3], 3),
+                "c_abi_pairs_per_sec": round(len(ps) / (best[3] * 1e-3), 1),
+                "forward_kernel_ms": round(best[1], 3),
+                "trace_kernel_ms": round(best[2], 3),
+                "create_ms": round(t_create * 1e3, 1),
+                "computed_lanes": lanes,                      # 64-row words x 256-column blocks actually computed (BlockStats)
+                "band_fraction_of_matrix": round(lanes * 64 * 256 / ba.stats()["cells"], 4),
+                "band_gcups_forward": round(lanes * 64 * 256 / (best[1] * 1e-3) / 1e9, 1),
+                "mean_f_max_tries": round(sum(x["f_max_tries"] for x in sts) / len(sts), 2),
+                "host_engine_fallbacks": ba.trace_fallbacks(),
+                "kernel": "pa::apa2::apa2_kernel + pa::trace_kernel<true>",
+            }
+            ba.close()
+            return leg
+
+        c4a = [generate_pair(10_000, divs[i % 4], seed=1_000_000 + i) for i in range(args.c4_pairs)]
+        out["c4_astarpa2_simple"] = apa2_leg(c4a, f"C4: {args.c4_pairs} independent 10 kbp pairs, 1/5/10/15 % divergence, A*PA2 `simple` (band doubling, GapCost, DT-trace): "
+                                             "cost + CIGAR + statistics of every pair, strings delivered to the host", range(0, min(args.c4_pairs, 40), 1))
+        del c4a
+        for n3 in args.c3_batch:
+            c3a = [generate_pair(100_000, 0.05, seed=3_000_000 + i) for i in range(n3)]
+            out[f"c3_batch_{n3}"] = apa2_leg(c3a, f"C3 batched: {n3} independent 100 kbp pairs, 5 % divergence, A*PA2 `simple` with traceback", range(0, min(n3, 2)))
+            del c3a
 
     # ---- PCIe-inclusive rate of the headline workload: host buffers -> device layout -> one pass (never `value`) ----
     if world == 1:

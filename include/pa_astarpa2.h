@@ -67,6 +67,16 @@ void pa_params_batch_align(pa_astarpa2_params* p);
 int pa_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params* params,
              int trace, int32_t* cost_out, char** cigar_out, pa_astarpa2_stats* stats_out);
 
+/* Optional, once, BEFORE anything starts the HIP runtime in this process (torch, another library, the first pa_* call): asks the
+ * runtime for 16 hardware queues (GPU_MAX_HW_QUEUES, default 4) unless the variable is set already, so that the pipelined passes
+ * of one pa_align call -- each on its own stream -- run side by side (C3 `simple`: 14.5 ms with, ~20 ms without).  Exporting the
+ * variable does the same.  The library never touches the environment by itself.  Returns 1 if it set the variable, else 0. */
+int pa_runtime_hints(void);
+
+/* pa_align and the astarpa-c symbols keep device buffers, pinned staging and streams in per-thread pools that only grow (after one
+ * 10 Mbp alignment: gigabytes).  This frees the calling thread's pools; the next call builds them again. */
+void pa_release_pools(void);
+
 #ifdef __cplusplus
 }
 #endif

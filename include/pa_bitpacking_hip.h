@@ -154,12 +154,17 @@ pa_batch* pa_batch_create_params(const uint8_t* const* a, const size_t* a_len, c
 int pa_batch_pair_stats(const pa_batch* plan, struct pa_astarpa2_stats* stats_out);
 
 /* Many-pair mode over several GPUs from ONE process (independent pairs shard with no data-path exchange; the
- * reference runs them one after another, pa-bin/src/main.rs:24-35).  Pairs are assigned longest-processing-time-first by
- * n * ceil(m / 64); one host thread per entry of devices[0..ndevices) binds its device and runs one pa_batch_align over its
- * shard (the cost-only batch when cigar_out is NULL); results land at the pairs' original indices.  A device may be listed
- * twice (two shards in flight on one GPU).  One process per GPU with torch.distributed (sharding.py) is the other recipe. */
+ * reference runs them one after another, pa-bin/src/main.rs:24-35): a WORK QUEUE.  The pairs are sorted by estimated work
+ * (heaviest first) and cut into chunks; one host thread per entry of devices[0..ndevices) binds its device and pulls chunk after
+ * chunk from one atomic counter, each chunk one pa_batch_align (the cost-only batch when cigar_out is NULL); results land at the
+ * pairs' original indices.  The balance is dynamic: nobody has to know beforehand how much work a pair is.  A device may be listed
+ * twice (two chunks in flight on one GPU).  One process per GPU with torch.distributed (sharding.py) is the other recipe.
+ * _params: the batched A*PA2 of pa_batch_create_params for every chunk; stats_out (optional) receives every pair's statistics. */
 int pa_batch_align_multi(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len, size_t pairs,
                          const int* devices, int ndevices, int32_t* cost_out, char** cigar_out);
+int pa_batch_align_multi_params(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len, size_t pairs,
+                                const int* devices, int ndevices, const struct pa_astarpa2_params* params, int32_t* cost_out,
+                                char** cigar_out, struct pa_astarpa2_stats* stats_out);
 
 /* ---- pa-bin's data formats (pa-bin/src/lib.rs:67-114, pa-bin/src/main.rs:24-35) ------------------------- */
 /* Input: `.seq` (line pairs, '>' then '<' markers), `.txt` (plain line pairs), `.fna`/`.fa`/`.fasta` (records taken two at

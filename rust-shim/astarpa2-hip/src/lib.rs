@@ -82,6 +82,16 @@ extern "C" {
     pub fn pa_batch_destroy(plan: *mut core::ffi::c_void);
     pub fn pa_batch_align_multi(a: *const *const u8, a_len: *const usize, b: *const *const u8, b_len: *const usize, pairs: usize,
                                 devices: *const i32, ndevices: i32, cost_out: *mut i32, cigar_out: *mut *mut c_char) -> i32;
+    // batched A*PA2 (the `simple` preset and its relatives): one wavefront runs a pair's whole band search; cost, CIGAR and
+    // statistics are what a loop over `align_with_stats` returns
+    pub fn pa_batch_create_params(a: *const *const u8, a_len: *const usize, b: *const *const u8, b_len: *const usize, pairs: usize,
+                                  params: *const PaAstarPa2Params) -> *mut core::ffi::c_void;
+    pub fn pa_batch_pair_stats(plan: *const core::ffi::c_void, stats_out: *mut PaAstarPa2Stats) -> i32;
+    pub fn pa_batch_align_multi_params(a: *const *const u8, a_len: *const usize, b: *const *const u8, b_len: *const usize, pairs: usize,
+                                       devices: *const i32, ndevices: i32, params: *const PaAstarPa2Params, cost_out: *mut i32,
+                                       cigar_out: *mut *mut c_char, stats_out: *mut PaAstarPa2Stats) -> i32;
+    pub fn pa_runtime_hints() -> i32;
+    pub fn pa_release_pools();
 }
 
 /// The text form of `Cigar::to_string` (count omitted when 1; `=`, `X`, `I`, `D`; astarpa-c/example.cpp:16 `"=I4=X="`).
@@ -151,6 +161,39 @@ impl HipAstarPa2 {
             parse_cigar(&s)
         });
         (cost, cigar, stats)
+    }
+}
+
+impl HipAstarPa2 {
+    /// The loop of pa-bin (`for (a, b) in pairs { aligner.align(a, b) }`, pa-bin/src/main.rs:24-35) as ONE call: every pair's band
+    /// search runs on the GPU side by side (`pa_batch_create_params` + `pa_batch_align`); parameters outside the `simple` family
+    /// (and `trace == false`) fall back to the loop.
+    pub fn align_many(&mut self, pairs: &[(Seq, Seq)]) -> Vec<(Cost, Option<Cigar>, PaAstarPa2Stats)> {
+        let n = pairs.len();
+        let ap: Vec<*const u8> = pairs.iter().map(|p| p.0.as_ptr()).collect();
+        let bp: Vec<*const u8> = pairs.iter().map(|p| p.1.as_ptr()).collect();
+        let al: Vec<usize> = pairs.iter().map(|p| p.0.len()).collect();
+        let bl: Vec<usize> = pairs.iter().map(|p| p.1.len()).collect();
+        let plan = if self.trace { unsafe { pa_batch_create_params(ap.as_ptr(), al.as_ptr(), bp.as_ptr(), bl.as_ptr(), n, &self.params) } } else { std::ptr::null_mut() };
+        if plan.is_null() {
+            return pairs.iter().map(|(a, b)| self.align_with_stats(a, b)).collect();
+        }
+        let mut costs = vec![0i32; n];
+        let mut ptrs: Vec<*mut c_char> = vec![std::ptr::null_mut(); n];
+        let mut stats = vec![PaAstarPa2Stats::default(); n];
+        let rc = unsafe { pa_batch_align(plan, costs.as_mut_ptr(), ptrs.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut()) };
+        let rc2 = if rc == 0 { unsafe { pa_batch_pair_stats(plan, stats.as_mut_ptr()) } } else { rc };
+        unsafe { pa_batch_destroy(plan) };
+        if rc2 != 0 {
+            panic!("pa_batch_align failed ({}): {}", rc2, unsafe { std::ffi::CStr::from_ptr(pa_last_error()) }.to_string_lossy());
+        }
+        (0..n)
+            .map(|i| {
+                let s = unsafe { std::ffi::CStr::from_ptr(ptrs[i]) }.to_str().unwrap().to_owned();
+                unsafe { astarpa_free_cigar(ptrs[i] as *mut u8) };
+                (costs[i], Some(parse_cigar(&s)), stats[i])
+            })
+            .collect()
     }
 }
 

@@ -80,3 +80,82 @@ pub fn fill(a: &[Bits], b: &[Bits], h: &mut [(u64, u64)], v: &mut [V], _exact_en
     }
     r
 }
+
+/// `HMode` of the block engine (`astarpa2/src/blocks.rs:665-671`), as the C ABI numbers it.
+#[derive(Clone, Copy, PartialEq, Eq, Debug)]
+#[repr(i32)]
+pub enum HMode {
+    None = 0,
+    Input = 1,
+    Update = 2,
+    Output = 3,
+}
+
+/// What `Blocks` keeps next to its `Vec<Block>` when the kernels run on the GPU: one device-resident context per pair.  The
+/// sequences, their profile and the persistent row of horizontal deltas (`Blocks::h`, blocks.rs:103-105) live in HBM between the
+/// block calls of one alignment; a call moves only the `v` words of its rectangle.
+///
+/// In the reference, `Blocks::new` (blocks.rs:110-128) builds the `BitProfile` and allocates `h`; with this shim it creates a
+/// `HipBlocksCtx` instead, and the free function `compute_block` (blocks.rs:686-748) / the `fill` call of `fill_with_blocks`
+/// (blocks.rs:627-648) become the two methods below -- same arguments (`i_range`, `v_range`, `v`, `HMode`), same return value.
+pub struct HipBlocksCtx {
+    raw: *mut core::ffi::c_void,
+}
+
+impl HipBlocksCtx {
+    /// `BitProfile::build(a, b)` + the allocation of `h` (blocks.rs:112-123), on the device.
+    pub fn new(a: &[u8], b: &[u8]) -> Self {
+        let raw = unsafe { pa_bp_ctx_create(a.as_ptr(), a.len(), b.as_ptr(), b.len()) };
+        assert!(!raw.is_null(), "pa_bp_ctx_create: {}", last_error()); // the reference panics on a non-ACGT base as well
+        HipBlocksCtx { raw }
+    }
+
+    /// `compute_block(params, a, b, h, i_range, v_range, v, mode, ..)` (blocks.rs:686-748): columns `(i_range.0, i_range.1]` of the
+    /// matrix (characters `a[i_range.0 .. i_range.1)`), 64-row words `v_range` of `b`; `v` holds exactly those words and is updated
+    /// in place; returns the sum of the bottom-row deltas.  `HMode::Input / Update` read the stored row, `Update / Output` store the
+    /// bottom row back (blocks.rs:728-747).
+    pub fn compute_block(&mut self, i_range: (i32, i32), v_range: std::ops::Range<usize>, v: &mut [V], mode: HMode) -> Cost {
+        assert_eq!(v.len(), v_range.len());
+        let mut sum: i32 = 0;
+        let rc = unsafe {
+            pa_bp_ctx_compute(self.raw, i_range.0, i_range.1, v_range.start, v_range.end, v.as_mut_ptr() as *mut u64, mode as i32, &mut sum)
+        };
+        assert!(rc == 0, "pa_bp_ctx_compute: {}", last_error());
+        sum
+    }
+
+    /// The `pa_bitpacking::simd::fill` call of `fill_with_blocks` (blocks.rs:627-648): top row `+1`, `values[i][j]` = `V` of word
+    /// `v_range.start + j` after column `i_range.0 + i + 1`; `h_bottom[i]` (if given) = the bottom-row delta of that column.  The
+    /// stored row is not touched.
+    pub fn fill_block(&mut self, i_range: (i32, i32), v_range: std::ops::Range<usize>, v: &mut [V], values: &mut [Vec<V>],
+                      h_bottom: Option<&mut [i8]>) {
+        let (n, w) = ((i_range.1 - i_range.0) as usize, v_range.len());
+        assert_eq!(v.len(), w);
+        assert_eq!(values.len(), n);
+        let mut flat = vec![V::zero(); n * w];
+        let hb = match h_bottom {
+            Some(h) => {
+                assert_eq!(h.len(), n);
+                h.as_mut_ptr()
+            }
+            None => std::ptr::null_mut(),
+        };
+        let rc = unsafe {
+            pa_bp_ctx_fill(self.raw, i_range.0, i_range.1, v_range.start, v_range.end, v.as_mut_ptr() as *mut u64, flat.as_mut_ptr() as *mut u64, hb)
+        };
+        assert!(rc == 0, "pa_bp_ctx_fill: {}", last_error());
+        for (i, vv) in values.iter_mut().enumerate() {
+            vv.clear();
+            vv.extend_from_slice(&flat[i * w..(i + 1) * w]);
+        }
+    }
+}
+
+impl Drop for HipBlocksCtx {
+    fn drop(&mut self) {
+        unsafe { pa_bp_ctx_destroy(self.raw) }
+    }
+}
+
+// A context belongs to the thread (and the device) that created it (`pa_set_device` is per thread).
+// (no `Send` / `Sync`: raw pointer)

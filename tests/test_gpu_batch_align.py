@@ -152,6 +152,29 @@ def test_two_shards_in_one_process_on_one_device(pa, oracle):
         pa.align_multi(pairs, [0, 99])
 
 
+def test_work_queue_of_chunks_over_devices(pa, oracle, monkeypatch):
+    """pa_batch_align_multi[_params] is a queue: chunks of pairs pulled by the device threads.  Forced down to 5 pairs per chunk so
+    that every thread takes many; full-DP traced, cost-only, and the batched A*PA2 (with statistics) -- all equal to one batch."""
+    from tests.test_sweep_emu import KEYS
+
+    monkeypatch.setenv("PA_MULTI_CHUNK", "5")
+    pairs = [gen_pair(n, e, seed=n + int(100 * e)) for n in (300, 5000, 10_000, 3000, 2049, 777, 1500, 64, 9000) for e in (0.02, 0.1, 0.2)]
+    pairs += [(b"", b"ACGT"), (b"ACGT", b"")]
+    single = pa.Batch(pairs, trace=True)
+    want_costs, want_cigars, _, _ = single.align()
+    single.close()
+    costs, cigars = pa.align_multi(pairs, [0, 0, 0])
+    assert costs.tolist() == want_costs.tolist() and cigars == want_cigars
+    prm = pa.AstarPa2Params.simple()
+    sb = pa.Batch(pairs, params=prm)
+    a_costs, a_cigars, _, _ = sb.align()
+    a_stats = sb.pair_stats()
+    sb.close()
+    costs, cigars, stats = pa.align_multi(pairs, [0, 0], params=prm, stats=True)
+    assert costs.tolist() == a_costs.tolist() == want_costs.tolist() and cigars == a_cigars
+    assert [{k: s[k] for k in KEYS} for s in stats] == [{k: s[k] for k in KEYS} for s in a_stats]
+
+
 def test_concurrent_host_threads_through_the_c_abi(pa, oracle):
     """Python threads calling different entry points at once (ctypes releases the GIL): pa_align through the sweep, a cost-only
     batch and a traced batch, all on device 0."""

@@ -155,6 +155,37 @@ def test_c_layout_program(tmp_path):
     assert lines[3] == "pa_bp_compute sum=%d cost=2" % int(lines[3].split("sum=")[1].split()[0])
 
 
+def test_c_ctx_program(tmp_path, oracle):
+    """tests/c_abi/ctx_check.c: the device-resident operator handles driven from plain C the way a host engine calls them -- create,
+    an Output / Input / Update chain over three column blocks, fill, destroy -- against pa_bp_compute on the whole rectangle."""
+    import os
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    libdir = root / "astar-pairwise-aligner_amd"
+    gcc = shutil.which("gcc") or shutil.which("cc")
+    if gcc is None or not (libdir / "libastarpa_c_hip.so").exists():
+        pytest.skip("no C compiler or library")
+    exe = tmp_path / "ctx_check"
+    subprocess.run([gcc, str(root / "tests" / "c_abi" / "ctx_check.c"), "-I", str(root / "include"), "-L", str(libdir),
+                    "-lastarpa_c_hip", "-Wl,-rpath," + str(libdir), "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, LD_LIBRARY_PATH=str(libdir) + ":" + os.environ.get("LD_LIBRARY_PATH", "")))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("ctx_check ok cost=")
+    # the same pair, generated the same way, through the oracle
+    s, a = 12345, bytearray()
+    for _ in range(600):
+        s = (s * 1103515245 + 12345) & 0xFFFFFFFF
+        a.append(b"ACGT"[(s >> 16) & 3])
+    b = bytearray(a[j] if j < 600 else 65 for j in range(500))
+    for j in range(7, 500, 23):
+        b[j] = ord("C") if b[j] == ord("A") else ord("A")
+    assert int(r.stdout.split("=")[1]) == oracle.levenshtein(bytes(a), bytes(b))
+
+
 def test_c_abi_is_reentrant_across_threads(pa, oracle):
     """astarpa-c is stateless and re-entrant: several host threads align different pairs at the same time."""
     import threading

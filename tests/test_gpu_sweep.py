@@ -133,6 +133,19 @@ def test_c5_10mbp_doubling_band(pa, oracle):
     assert dt < 8.0, dt
 
 
+def test_linear_search_more_passes_than_tag_bits(pa, oracle):
+    """LinearSearch with delta = 1 on a divergent pair needs more passes than the 12-bit pass id of the sweep's tagged words holds
+    (plus the speculative launches): the sweep must hand the pair to the host-driven engine instead of reading another pass's
+    records through aliased tags.  Cost, CIGAR and statistics as ever."""
+    oc = oracle.make_params(domain="astar", heuristic="gap", doubling="linear", start="h0", delta=1.0, block_width=256, sparse=True,
+                            incremental_doubling=False, dt_trace=True, max_g=40, fr_drop=10, sparse_h=True)
+    a, b = gen_pair(14000, 0.45, 11)
+    cost, cigar, stats = both(pa, oracle, a, b, oc)
+    assert stats["f_max_tries"] > 4100
+    a, b = gen_pair(3000, 0.1, 12)  # and the pool is usable afterwards
+    both(pa, oracle, a, b, oracle.params_simple())
+
+
 @pytest.mark.parametrize("k", ["1", "2", "3"])
 def test_giving_up_speculative_passes_changes_nothing(pa, oracle, monkeypatch, k):
     """tests/test_sweep_emu.py::test_giving_up_speculative_passes_changes_nothing on the device: after every k-th pass the

@@ -35,16 +35,21 @@ def _worker(rank, world, port, q):
         calls.append(len(sub))
         return [oracle.levenshtein(a, b) for a, b in sub]
 
-    out = sharded_costs(pairs, compute=compute)
+    out = sharded_costs(pairs, compute=compute, min_chunk=3)  # a queue of nine chunks, pulled by whoever is free
     want = [oracle.levenshtein(a, b) for a, b in pairs]
+    # gathered to rank 0 only: the other rank gets None
+    out0 = sharded_costs(pairs, compute=lambda sub: [oracle.levenshtein(a, b) for a, b in sub], all_ranks=False, min_chunk=5)
+    ok_root = (out0 == want) if rank == 0 else (out0 is None)
     # the traceback variant gathers (cost, CIGAR): per-rank compute = the engine over the CPU oracle kernels
     from astar_pairwise_aligner_amd.sharding import sharded_align
 
     prm = oracle.make_params(domain="full", heuristic="none", doubling="none", block_width=256, sparse=True,
                              incremental_doubling=False, dt_trace=False)
-    al = sharded_align(pairs[:9], compute=lambda sub: [oracle.cpu_align(a, b, prm)[:2] for a, b in sub])
+    al = sharded_align(pairs[:9], compute=lambda sub: [oracle.cpu_align(a, b, prm)[:2] for a, b in sub], min_chunk=2)
     ok_al = all(c == w and oracle.cigar_verify(g, a, b) == c for (c, g), w, (a, b) in zip(al, want, pairs))
-    q.put((rank, out == want and ok_al, calls))
+    al0 = sharded_align(pairs[:9], compute=lambda sub: [oracle.cpu_align(a, b, prm)[:2] for a, b in sub], min_chunk=2, all_ranks=False)
+    ok_al0 = (al0 == al) if rank == 0 else (al0 is None)
+    q.put((rank, out == want and ok_al and ok_root and ok_al0, calls))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -63,8 +68,75 @@ def test_sharded_costs_two_ranks_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
-    sizes = sorted(c[0] for _, _, c in res)
-    assert sum(sizes) == 25 and sizes[0] >= 8  # both ranks got a real share
+    assert sum(sum(c) for _, _, c in res) == 25  # every pair computed exactly once, in chunks of at most 3
+    assert all(x <= 3 for _, _, c in res for x in c)
+
+
+def _skew_worker(rank, world, port, q):
+    """Uneven work the estimate cannot see (the band of a pair depends on its divergence): one kind of pair costs 15x the other."""
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import time
+
+    import torch.distributed as dist
+
+    from astar_pairwise_aligner_amd.sharding import sharded_costs
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # 96 pairs of equal length; the first 48 are "15 % divergent" (15 ms each), the rest "1 %" (1 ms): a static plan by length gives
+    # every rank the same number of pairs whatever they cost -- and here rank 1 is also slower by half (a busy GPU)
+    pairs = [(bytes([65 + (i % 4)]) * 50, b"A" * 50) for i in range(96)]
+    busy = [0.0]
+
+    def compute(sub):
+        t = time.perf_counter()
+        cost = sum(0.015 if i < 48 else 0.001 for i in current[0])
+        time.sleep(cost * (1.5 if rank == 1 else 1.0))
+        busy[0] += time.perf_counter() - t
+        return [0] * len(sub)
+
+    # the compute hook does not get indices: wrap the sequence so that the chunk's indices are known
+    class Tracked:
+        def __len__(self):
+            return len(pairs)
+
+        def __getitem__(self, i):
+            current[0].append(i)
+            return pairs[i]
+
+        def __iter__(self):
+            return iter(pairs)
+
+    current = [[]]
+
+    def compute_tracked(sub):
+        r = compute(sub)
+        current[0] = []
+        return r
+
+    out = sharded_costs(Tracked(), compute=compute_tracked, min_chunk=4, work=[1] * 96)
+    q.put((rank, out == [0] * 96, busy[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_work_queue_balances_what_the_estimate_cannot_see():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_skew_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    t = sorted(b for _, _, b in res)
+    assert t[1] <= 1.25 * t[0] + 0.08, t  # busy times within 25 % (+ one chunk of slack); a static split by length: 1.5x apart
 
 
 def test_plan_shards_balanced_and_deterministic():

@@ -53,6 +53,7 @@ def load(build_if_stale: bool = True) -> C.CDLL:
         raise PaError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
     L = C.CDLL(str(path))
     L.pa_runtime_hints.restype = C.c_int
+    L.pa_release_pools.restype = None
     L.pa_runtime_hints()  # this package is the application here: more hardware queues, before the first HIP call
     vp, sz = C.c_void_p, C.c_size_t
     L.pa_last_error.restype = C.c_char_p

@@ -47,12 +47,14 @@ struct DevBackend {
     uint32_t* err;
     uint32_t* dbg;  // diagnostics: host-mapped progress markers, or nullptr
     int lane;
+    bool k1_only = false;  // experiments: K = 1 strips only (PA_APA2_K1)
 
     __device__ __forceinline__ DevBackend(const PairJob& j, const HeurParams& h, uint32_t* e, uint32_t* d) : job(j), hp(h), err(e), dbg(d) { lane = (int)(threadIdx.x & 63); }
     __device__ __forceinline__ void mark(int slot_, uint32_t value) const {
         if (dbg && lane == 0) __hip_atomic_store(dbg + slot_, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 
+    __device__ __forceinline__ int32_t uniform(int32_t x) const { return (int32_t)rfl((uint32_t)x); }  // back to a scalar register
     __device__ __forceinline__ bool failed() const { return rfl(__hip_atomic_load((const PA_GLOBAL uint32_t*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != PA_ERR_NONE; }
 
     __device__ __forceinline__ gu32 slot(int32_t k) const { return (gu32)job.col + (size_t)k * (size_t)job.col_stride * 4; }
@@ -133,36 +135,47 @@ struct DevBackend {
             dst[(size_t)wi * 4 + 3] = x3;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        const int32_t S = (words + 31) >> 5;
-        for (int32_t st = 0; st < S; ++st) {
+        // Strips top to bottom.  Height by what is left of the band: up to 32 words one K = 1 strip (half a wave for up to 16), up to
+        // 64 words one K = 2 strip, beyond that K = 4 strips of 128 words -- 23 / 17.5 / 14.75 VALU instructions per 2048 cells, and
+        // every strip pays its 64 steps of skew only once (strip_kernel.hpp).
+        int32_t done = 0;
+        for (int32_t st = 0; done < words; ++st) {
             mark(6, (uint32_t)st);
+            const int32_t left = words - done;
+            const int32_t kk = (left > 64 && !k1_only) ? 4 : ((left > 32 && !k1_only) ? 2 : 1);
+            const int32_t take = left < 32 * kk ? left : 32 * kk;
+            const bool last = done + take >= words;
             StripJob j;
             j.a_codes = job.a_codes;
             j.b_prof = job.b_prof;
             j.v = job.col + (size_t)k * (size_t)job.col_stride * 4;
             j.hin_gran = st > 0 ? job.gran + (size_t)((st - 1) & 1) * 8 : nullptr;
             j.hin_arr = nullptr;
-            j.hout_gran = st + 1 < S ? job.gran + (size_t)(st & 1) * 8 : nullptr;
+            j.hout_gran = last ? nullptr : job.gran + (size_t)(st & 1) * 8;
             j.hout_arr = nullptr;
             j.values = nullptr;
-            j.sum_out = st + 1 < S ? nullptr : job.sum;
+            j.sum_out = last ? job.sum : nullptr;
             j.n = i1 - i0;
-            j.word0 = w0 + 32 * st;
-            j.nlanes = 2 * (words - 32 * st < 32 ? words - 32 * st : 32);
+            j.word0 = w0 + done;
+            j.nlanes = 2 * take;
             j.fill_stride = 0;
             j.fill_word0 = 0;
-            j.exact_tail = st + 1 < S ? 1 : 0;
+            j.exact_tail = last ? 0 : 1;
             j.flags = 0;
             j.col0 = i0;
             j.tail_rows = -1;
-            j.k = 1;
+            j.k = kk;
             j.ckpt = nullptr;
             j.ckpt_stride = 0;
             j.hin_n = 0;
             j.vsum_out = nullptr;
-            if (j.nlanes <= 32) run_strip<1, false, false, false, true, false, true>(j, err);
-            else run_strip<1, false, false, false, true>(j, err);
+            // (a strip that is not the last one is full, the last one does not need an exact bottom row: NOPASS)
+            if (kk == 4) run_strip<4, false, false, false, true, false, false, true>(j, err);
+            else if (kk == 2) run_strip<2, false, false, false, true, false, false, true>(j, err);
+            else if (j.nlanes <= 32) run_strip<1, false, false, false, true, false, true, true>(j, err);
+            else run_strip<1, false, false, false, true, false, false, true>(j, err);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            done += take;
         }
         return (int32_t)rfl((uint32_t)*(const PA_GLOBAL int32_t*)job.sum);
     }
@@ -234,8 +247,8 @@ struct DevBackend {
 };
 
 // Pairs are claimed by ticket in the order of `order` (heaviest first); a block is four independent wavefronts.
-__global__ __launch_bounds__(64 * kStripBlockWaves) void apa2_kernel(const PairJob* __restrict__ jobs, const int32_t* __restrict__ order, int npairs,
-                                                                    SearchParams sp, uint32_t* ticket, uint32_t* err, uint32_t* dbg) {
+__global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_kernel(const PairJob* __restrict__ jobs, const int32_t* __restrict__ order, int npairs,
+                                                                    SearchParams sp, uint32_t* ticket, uint32_t* err, uint32_t* dbg, int k1_only) {
     const int lane = (int)(threadIdx.x & 63);
     for (;;) {
         // The ticket, WITHOUT a lane-dependent branch: with `if (lane == 0) t = atomicAdd(..)` here and `if (lane == 0) store` at the
@@ -253,6 +266,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves) void apa2_kernel(const PairJ
         hp.m = job.m;
         hp.sh_h = job.sh_h;
         DevBackend be(job, hp, err, dbg);
+        be.k1_only = k1_only != 0;
         be.mark(7, (uint32_t)pair + 1u);
         PairProg<DevBackend> prog(be, hp, sp);
         PairResult res;

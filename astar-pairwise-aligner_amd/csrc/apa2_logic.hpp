@@ -19,6 +19,7 @@
 //   bool scan_first(k, rec, i, f_max, lo, hi, &j)               first row j in [lo, hi] with index(j) + h(i, j) <= f_max
 //   bool scan_last(k, rec, i, f_max, lo, hi, &j)                last such row
 //   bool failed()                                               the backend met an error (device: the strips' error word)
+//   int32_t uniform(x)                                          x, known to be wavefront-uniform (device: back into a scalar register)
 //   void mark(slot, value)                                      diagnostics: progress markers (a no-op unless a debug buffer is set)
 // The two scans replace the probing loops of domain.rs:306-328: with `sparse_h` the reference jumps ceil((f - f_max) / 2) rows
 // after a failed probe; f changes by at most 2 per row (g by 1, the heuristic by at most 1), so a jump never skips a row with
@@ -233,7 +234,7 @@ struct PairProg {
     PA_HD int32_t next_bound(int32_t s, int32_t offset) const {
         if (sp.doubling == kDoublingLinear) return s + sp.delta;
         const float x = ceilf(sp.factor * (float)(s - offset));  // band.rs:138, f32 arithmetic
-        const int32_t c = (int32_t)x;
+        const int32_t c = be.uniform((int32_t)x);               // (the float unit is a vector unit: keep the bound scalar)
         return (c > 1 ? c : 1) + offset;
     }
 

@@ -940,12 +940,23 @@ int align_hip(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, co
             return PA_E_INTERNAL;
         }
     }
+    // Cost only, for the parameters the sweep serves: the sweep computes the band of the TRACED mode (its answer is the distance
+    // itself, its statistics those of the traced band; include/pa_astarpa2.h).  A pair it hands back gets the same: the host-driven
+    // engine in traced mode with the CIGAR dropped -- not the reference's cost-only single-block mode (blocks.rs:252-277), whose
+    // fixed range is the union over all columns (a triangle of the matrix) and which this restatement has seen end on an upper
+    // bound.  PA_ENGINE_NO_SWEEP (tests, diagnostics) still runs that mode as restated.
+    const bool traced_for_cost = !trace && !no_sweep && !self_check && sweep::sweep_supported(p, a_len, b_len);
     try {
-        r = engine::cost_or_align(p, be, trace, self_check);
+        r = engine::cost_or_align(p, be, trace || traced_for_cost, self_check);
     } catch (const engine::EnginePanic& e) {
         if (be.err) return be.err;
         set_error("astarpa2 engine panic: %s", e.what());
         return PA_E_INTERNAL;
+    }
+    if (traced_for_cost) {
+        r.has_cigar = false;
+        r.cigar = engine::Cigar();
+        r.stats.trace_stats = engine::TraceStats();
     }
     if (cost_out) *cost_out = r.cost;
     if (cigar_out) *cigar_out = r.has_cigar ? r.cigar.to_string() : std::string();

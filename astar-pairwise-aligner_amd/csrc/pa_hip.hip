@@ -1599,7 +1599,7 @@ static int batch_forward(pa_batch* p) {
                 dbg = (uint32_t*)hp;
             }
             hipLaunchKernelGGL(apa2::apa2_kernel, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, p->d_pjobs.as<apa2::PairJob>(), p->d_order.as<int32_t>(),
-                               (int)p->pairs, p->sp, p->d_misc.as<uint32_t>(), p->d_misc.as<uint32_t>() + 1, dbg);
+                               (int)p->pairs, p->sp, p->d_misc.as<uint32_t>(), p->d_misc.as<uint32_t>() + 1, dbg, getenv("PA_APA2_K1") ? 1 : 0);
             if (!hip_ok(hipGetLastError(), "apa2_kernel launch")) return PA_E_HIP;
             if (dbg) {  // diagnostics: the forward pass alone, progress markers and first results on stderr
                 std::fprintf(stderr, "[apa2] forward launched: grid %d, pairs %zu\n", grid, p->pairs);

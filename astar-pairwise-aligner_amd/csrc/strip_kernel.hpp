@@ -370,7 +370,9 @@ __device__ __attribute__((noinline)) void pace_top_strip(const uint32_t* counter
 // LDSEQ: eq words come from the wavefront's LDS slice at byte offset `lds_wave` (LdsEq<K>::kWaveBytes, aligned to its size).
 // HALF (K = 1 and nlanes <= 32 only): the strip occupies lanes 32..63, the pipeline is 32 steps deep instead of 64, so the
 // strip takes C + 1 chunks instead of C + 2 -- 10 % of a 256-column block of the engine, of a traceback re-fill.
-template <int K, bool FILL, bool SCATTER, bool CKPT = false, bool LOCAL = false, bool LDSEQ = false, bool HALF = false>
+// NOPASS: the caller never asks for an exact bottom row of a partial strip (job.exact_tail is 0 whenever nlanes < 64 K): the
+// pass-through chunk variants are not compiled (half the unrolled code of the strip; apa2_kernel.hpp holds four strip heights).
+template <int K, bool FILL, bool SCATTER, bool CKPT = false, bool LOCAL = false, bool LDSEQ = false, bool HALF = false, bool NOPASS = false>
 __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, uint32_t lds_wave = 0) {
     static_assert(!LDSEQ || (K >= 4 && !SCATTER && !FILL), "LDSEQ: tall cost-only strips");
     static_assert(!HALF || (K == 1 && !CKPT && !LDSEQ), "HALF: short K = 1 strips without checkpoints");
@@ -441,7 +443,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
     const int cj = plane & 15;
     const bool upper = (plane & 16) != 0;          // lanes 16..31 build columns 16..31 of the chunk
     const uint32_t sh = 2u * (uint32_t)cj;
-    const bool exact_tail = job.exact_tail != 0 && job.nlanes < (HALF ? 32 : 64) * K;
+    const bool exact_tail = !NOPASS && job.exact_tail != 0 && job.nlanes < (HALF ? 32 : 64) * K;
 
     // Per-chunk inputs.  The packed sequence is read with SCALAR loads (constant address space -> s_load, tracked by
     // lgkmcnt, so it never waits behind the granule stores); the granule and the optional top-row bytes are vector

@@ -191,7 +191,7 @@ def main():
             "cost_checksum": checksum,
         },
         "roofline": {
-            "bound": "hbm",  # the contract's roofline; the kernel's real bound is VALU issue, see valu_roofline
+            "bound": "hbm",  # the contract's roofline object prices HBM; what binds this kernel is VALU issue: `binding_roofline`
             "achieved": round(achieved_gbs, 4),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -219,6 +219,9 @@ def main():
         },
         "batch_shape": {"k": shape["k"], "sequential": shape["sequential"]},
     }
+    # what actually binds the dominant kernel, in the roofline object's own form (frac = achieved / peak)
+    out["binding_roofline"] = {"bound": "valu_issue", "achieved": out["valu_roofline"]["achieved"], "peak": out["valu_roofline"]["peak"],
+                               "unit": out["valu_roofline"]["unit"], "frac": out["valu_roofline"]["frac"], "kernel": shape["kernel"]}
     if c4_sharded is not None:
         out["c4_sharded"] = c4_sharded
 
@@ -474,6 +477,45 @@ def main():
         out["speedup_vs_cpu_1core"] = round(value / out["cpu_baseline"]["value"], 1)
         if "single_pair" in out:  # the literal C2 configuration ("single pair") against the same 1-core baseline
             out["single_pair_speedup_vs_cpu_1core"] = round(out["single_pair"]["gcups"] / out["cpu_baseline"]["value"], 1)
+
+        # ---- the same CPU kernels on EVERY host core: independent pairs, one per thread at a time (ctypes
+        #      releases the GIL) -- what the host this GPU sits in could do by itself.  Bounded samples; reporting only. ----
+        try:
+            cores = os.cpu_count() or 1
+            cpu_model = ""
+            try:
+                for ln in open("/proc/cpuinfo"):
+                    if ln.startswith("model name"):
+                        cpu_model = ln.split(":", 1)[1].strip()
+                        break
+            except OSError:
+                pass
+            nb = {"cores": cores, "cpu": cpu_model, "kind": "port"}
+            # (a) full DP, cost only (the headline workload): every thread runs whole 100 kbp pairs
+            per_thread = max(1, int(min(args.cpu_seconds, 6.0) * out["cpu_baseline"]["value"] * 1e9 / (args.n * args.n)))
+            jobs = [pairs[i % len(pairs)] for i in range(cores * per_thread)]
+            t = time.perf_counter()
+            got_cpu = oracle.cpu_many(jobs, None, cores)
+            dtc = time.perf_counter() - t
+            assert got_cpu[: len(pairs)] == [int(c) for c in costs[: len(got_cpu)]][: len(pairs)], "all-core CPU baseline disagrees with the GPU costs"
+            nb["full_dp_gcups"] = round(sum(len(a) * len(b) for a, b in jobs) / dtc / 1e9, 1)
+            nb["full_dp_sample"] = f"{len(jobs)} pairs of {args.n} bp over {cores} threads inside the oracle library (one atomic work counter)"
+            nb["gpu_over_all_cores_full_dp"] = round(value / nb["full_dp_gcups"], 1)
+            # (b) C4 through A*PA2 `simple` with traceback (the CPU-kernel engine)
+            divs = (0.01, 0.05, 0.10, 0.15)
+            c4j = [generate_pair(10_000, divs[i % 4], seed=1_000_000 + i) for i in range(max(400, cores * 40))]
+            t = time.perf_counter()
+            oracle.cpu_many(c4j, oracle.params_simple(), cores)
+            dtc = time.perf_counter() - t
+            nb["c4_astarpa2_simple_pairs_per_sec"] = round(len(c4j) / dtc, 1)
+            nb["c4_sample"] = f"{len(c4j)} of the C4 pairs over {cores} threads (cost + CIGAR each)"
+            if "c4_astarpa2_simple" in out:
+                nb["gpu_over_all_cores_c4_astarpa2"] = round(out["c4_astarpa2_simple"]["pairs_per_sec"] / nb["c4_astarpa2_simple_pairs_per_sec"], 1)
+            if "dropin_loop" in out and isinstance(out["dropin_loop"].get("pairs_per_sec"), float):
+                nb["dropin_loop_over_all_cores"] = round(out["dropin_loop"]["pairs_per_sec"] / nb["c4_astarpa2_simple_pairs_per_sec"], 3)
+            out["cpu_baseline_nproc"] = nb
+        except Exception as e:  # (reporting only)
+            out["cpu_baseline_nproc"] = {"error": str(e)}
 
     # PMC-derived HBM traffic of the dominant kernel (separate rocprofv3 --pmc passes, tools/pmc_run.sh; committed
     # summary in profiles/pmc_latest.json).  Traffic is per strip wave, so it scales with the batch.

@@ -254,6 +254,24 @@ def cpu_align(a: bytes, b: bytes, params: AstarPa2ParamsC, trace: bool = True, s
     return cost.value, s, stats.as_dict()
 
 
+def cpu_many(pairs, params: AstarPa2ParamsC | None, nthreads: int) -> list[int]:
+    """Costs of `pairs` computed on `nthreads` host threads inside the oracle library (one atomic work counter, no Python between
+    the calls): params None = full DP cost-only (the AVX2 strip port), else the CPU-kernel engine with traceback."""
+    L = engine_lib()
+    L.pa_cpu_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.pa_cpu_many.restype = C.c_int
+    n = len(pairs)
+    ap = (C.c_void_p * n)(*[C.cast(C.c_char_p(a), C.c_void_p) for a, _ in pairs])
+    bp = (C.c_void_p * n)(*[C.cast(C.c_char_p(b), C.c_void_p) for _, b in pairs])
+    al = (C.c_size_t * n)(*[len(a) for a, _ in pairs])
+    bl = (C.c_size_t * n)(*[len(b) for _, b in pairs])
+    out = np.zeros(n, np.int32)
+    rc = L.pa_cpu_many(ap, al, bp, bl, n, C.byref(params) if params is not None else None, 0 if params is None else 1, nthreads, _p(out))
+    if rc != 0:
+        raise RuntimeError(f"pa_cpu_many rc={rc}")
+    return out.tolist()
+
+
 def sh_h(a: bytes, b: bytes, k: int) -> list[int]:
     """SH heuristic h(i) for i = 0..len(a) as the engine computes it (test hook)."""
     L = engine_lib()

@@ -124,3 +124,40 @@ extern "C" int pa_cpu_align_blocks(const uint8_t* a, size_t a_len, const uint8_t
     }
     return overflow ? -6 : nblocks;
 }
+
+// ---- the CPU baselines on every host core (bench.py `cpu_baseline_nproc`) ------------------------------------------------
+// Independent pairs pulled from one atomic counter by `nthreads` std::threads: no Python between the calls, so the number is
+// what the host's cores do with the oracle kernels, not what a thread pool of an interpreter lets through.
+#include <atomic>
+#include <thread>
+
+// mode 0: full DP, cost only (pa_or_nw_cost, the AVX2 strip port); mode 1: A*PA2 with `params` and traceback (the CPU-kernel engine).
+// costs[i] receives the cost of pair i.  Returns 0, or the first error code.
+extern "C" int pa_cpu_many(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len, size_t pairs,
+                           const pa_astarpa2_params* params, int mode, int nthreads, int32_t* costs) {
+    if (nthreads < 1) nthreads = 1;
+    if (mode == 1 && (!params || !params_valid(*params))) return -4;
+    std::atomic<size_t> next{0};
+    std::atomic<int> err{0};
+    auto work = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= pairs || err.load(std::memory_order_relaxed)) return;
+            if (mode == 0) {
+                costs[i] = pa_or_nw_cost(a[i], a_len[i], b[i], b_len[i], 1);
+            } else {
+                int32_t c = 0;
+                char* cg = nullptr;
+                const int rc = pa_cpu_align(a[i], a_len[i], b[i], b_len[i], params, 1, 0, &c, &cg, nullptr);
+                std::free(cg);
+                if (rc != 0) err.store(rc, std::memory_order_relaxed);
+                costs[i] = c;
+            }
+        }
+    };
+    std::vector<std::thread> ts;
+    for (int t = 1; t < nthreads; ++t) ts.emplace_back(work);
+    work();
+    for (auto& t : ts) t.join();
+    return err.load();
+}

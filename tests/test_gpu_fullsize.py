@@ -97,6 +97,50 @@ def test_c4_full_10000_pairs_with_traceback(pa, oracle):
     assert np.array_equal(np.asarray(costs), np.asarray(plain))
 
 
+def test_c4_full_10000_pairs_astarpa2_simple(pa, oracle):
+    """C4 through the batched A*PA2 (pa_batch_create_params, AstarPa2Params::simple()): ONE wavefront runs each pair's band search.
+    For EVERY one of the 10 000 pairs the cost, the CIGAR string and all twelve statistics equal the host engine over the CPU
+    oracle kernels -- what a loop over pa_align / astarpa2_simple returns; no pair fell back to the host."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from tests.test_sweep_emu import KEYS
+
+    divs = (0.01, 0.05, 0.10, 0.15)
+    pairs = [gen_pair(10_000, divs[i % 4], seed=2_000_000 + i) for i in range(10_000)]
+    batch = pa.Batch(pairs, params=pa.AstarPa2Params.simple())
+    costs, cigars, _, _ = batch.align()
+    stats = batch.pair_stats()
+    assert batch.trace_fallbacks() == 0
+    batch.close()
+    prm = oracle.params_simple()
+    with ThreadPoolExecutor(max_workers=16) as ex:  # (ctypes releases the GIL: the CPU engine runs on several cores)
+        want = list(ex.map(lambda p: oracle.cpu_align(p[0], p[1], prm), pairs))
+    for i, (w, c, cg, st) in enumerate(zip(want, costs, cigars, stats)):
+        assert (int(c), cg) == (w[0], w[1]), i
+        assert {k: st[k] for k in KEYS} == {k: w[2][k] for k in KEYS}, i
+
+
+def test_c3_batch_512_pairs_astarpa2_simple(pa, oracle):
+    """512 pairs of 100 kbp at 5 % (BASELINE C3's pair, many of them) through the batched A*PA2: cost, CIGAR string and all twelve
+    statistics of every pair equal the host engine over the CPU oracle kernels."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from tests.test_sweep_emu import KEYS
+
+    pairs = [gen_pair(100_000, 0.05, seed=3_000_000 + i) for i in range(512)]
+    batch = pa.Batch(pairs, params=pa.AstarPa2Params.simple())
+    costs, cigars, _, _ = batch.align()
+    stats = batch.pair_stats()
+    assert batch.trace_fallbacks() == 0
+    batch.close()
+    prm = oracle.params_simple()
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        want = list(ex.map(lambda p: oracle.cpu_align(p[0], p[1], prm), pairs))
+    for i, (w, c, cg, st) in enumerate(zip(want, costs, cigars, stats)):
+        assert (int(c), cg) == (w[0], w[1]), i
+        assert {k: st[k] for k in KEYS} == {k: w[2][k] for k in KEYS}, i
+
+
 def test_c4_properties_suffix_and_substitutions(pa):
     a = rand_seq(50_000, seed=77)
     suffix = rand_seq(1234, seed=78)

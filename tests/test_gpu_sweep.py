@@ -117,20 +117,41 @@ def test_1mbp_with_traceback(pa, oracle):
 
 def test_c5_10mbp_doubling_band(pa, oracle):
     """BASELINE C5: one 10 Mbp x 10 Mbp pair, 5 %, A*PA2 `simple` (GapCost band doubling), traceback off, through pa_align.
-    The cost equals the GapGap-banded batch (an independent kernel and band rule); no sanity violation; seconds, not minutes."""
+    Cost and block statistics equal tests/golden/c5.json -- the host engine over the CPU oracle kernels in traced mode (seven minutes
+    of one core, tests/golden/make_c5.py): the sweep computes the traced band also when no CIGAR is asked for (include/pa_astarpa2.h).
+    The cost also equals the GapGap-banded batch (an independent kernel and band rule).  (Wall-clock bounds live in bench.py.)"""
+    import json
+    from pathlib import Path
+
     from tests.test_gpu_engine import gpu_params
 
+    gold = json.loads((Path(__file__).resolve().parent / "golden" / "c5.json").read_text())["trace_on"]
     a, b = gen_pair(10_000_000, 0.05, 1)
     al = gpu_params(pa, oracle.params_simple()).make_aligner(False)
-    t = time.time()
     cost, cigar, stats = al.align_with_stats(a, b)
-    dt = time.time() - t
     assert cigar is None
-    assert cost == 480_033
-    assert stats["sanity_violations"] == 0 and stats["f_max_tries"] == 12
+    assert cost == gold["cost"] == 480_033
+    for k in ("f_max_tries", "num_blocks", "num_incremental_blocks", "computed_lanes", "unique_lanes", "sanity_violations"):
+        assert stats[k] == gold[k], k
     costs, _ = pa.Batch([(a, b)], band=0.05).run()
     assert int(costs[0]) == cost
-    assert dt < 8.0, dt
+
+
+def test_c5_10mbp_with_traceback(pa, oracle):
+    """C5 with the traceback on: cost, all twelve statistics and the CIGAR (length and SHA-256) of tests/golden/c5.json."""
+    import hashlib
+    import json
+    from pathlib import Path
+
+    from tests.test_gpu_engine import gpu_params
+
+    gold = json.loads((Path(__file__).resolve().parent / "golden" / "c5.json").read_text())["trace_on"]
+    a, b = gen_pair(10_000_000, 0.05, 1)
+    cost, cigar, stats = gpu_params(pa, oracle.params_simple()).make_aligner(True).align_with_stats(a, b)
+    assert cost == gold["cost"]
+    assert {k: stats[k] for k in KEYS} == {k: gold[k] for k in KEYS}
+    assert len(cigar) == gold["cigar_len"] and hashlib.sha256(cigar.encode()).hexdigest() == gold["cigar_sha256"]
+    pa.capi.load().pa_release_pools()  # (gigabytes of pooled device buffers)
 
 
 def test_linear_search_more_passes_than_tag_bits(pa, oracle):

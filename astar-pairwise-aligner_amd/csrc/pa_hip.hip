@@ -231,7 +231,7 @@ StripPlan strip_plan(int w, int k, bool sequential) {
     p.full = w / wps;
     const int r = w - p.full * wps;
     if (r == 0) return p;
-    const int max_tail1 = !sequential ? 0 : (k == 2 ? 1 : (k == 4 ? 2 : (k == 8 ? 3 : 0)));
+    const int max_tail1 = !sequential ? 0 : (k == 2 ? 1 : (k == 4 ? 2 : (k >= 8 ? 3 : 0)));
     const int t1 = (r + kWordsPerStrip - 1) / kWordsPerStrip;
     if (t1 <= max_tail1) p.tail1 = t1;
     else p.full += 1;
@@ -397,6 +397,7 @@ bool launch_pairs(const StripJob* d_jobs, const int32_t* d_first, int npairs, ui
         if (k == 2) return launch_pairs_k<2, false>(d_jobs, d_first, npairs, e, s, grid, lds);
         if (k == 4) return launch_pairs_k<4, false>(d_jobs, d_first, npairs, e, s, grid, lds);
         if (k == 8) return launch_pairs_k<8, false>(d_jobs, d_first, npairs, e, s, grid, lds);
+        if (k == 16) return launch_pairs_k<16, false>(d_jobs, d_first, npairs, e, s, grid, 0);
     } else {
         if (k == 1) return launch_pairs_k<1, true>(d_jobs, d_first, npairs, e, s, grid, lds);
         if (k == 2) return launch_pairs_k<2, true>(d_jobs, d_first, npairs, e, s, grid, lds);
@@ -1019,6 +1020,13 @@ static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, s
         if (k == 1 || k == 2 || k == 4 || k == 8) env_k = k;
     }
     if (const char* e = getenv("PA_BATCH_MODE")) env_mode = !strcmp(e, "seq") ? 2 : (!strcmp(e, "chain") ? 1 : 0);
+    if (getenv("PA_STRIP_K") && atoi(getenv("PA_STRIP_K")) == 16) {  // experiment (profiles/README.md round 3): one wavefront per pair, 16 subwords per lane
+        BatchShape sh16;
+        sh16.k = 16;
+        sh16.sequential = true;
+        sh16.block_waves = kStripBlockWaves;
+        return sh16;
+    }
     BatchShape best_shape;
     double best = -1;
     for (int t = 0; t < 4; ++t) {

@@ -150,7 +150,7 @@ __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin
 // extracts) to the LDS port, which issues beside the VALU: 107 -> 89 VALU instructions per K = 8 step.
 template <int K>
 struct LdsEq {
-    static constexpr int kCodeShift = K >= 8 ? 11 : 10;  // one code's eq words of all 64 lanes: 64 * 4K bytes
+    static constexpr int kCodeShift = K >= 16 ? 12 : (K >= 8 ? 11 : 10);  // one code's eq words of all 64 lanes: 64 * 4K bytes
     static constexpr uint32_t kCodeMask = 3u << kCodeShift;
     static constexpr uint32_t kWaveBytes = 4u * 64u * 4u * (uint32_t)K;
 };
@@ -857,8 +857,9 @@ __global__ __launch_bounds__(64) void rect_chain_kernel(ChainArgs r) {
 // a 4096-pair batch is exactly four per SIMD, three would leave a quarter of it for a second, mostly empty round.
 // LDSEQ (K >= 4): the launch provides kStripBlockWaves * LdsEq<K>::kWaveBytes of dynamic LDS, the kernel's only LDS, so the
 // slices start at offset 0 and are aligned to their size.
+// (K = 16, an experiment of round 3: 256 VGPRs, two wavefronts per SIMD, 16 KB of LDS per wavefront)
 template <int K, bool CKPT = false, bool LDSEQ = false>
-__global__ __launch_bounds__(64 * kStripBlockWaves, 4) void pair_kernel(const StripJob* __restrict__ jobs,
+__global__ __launch_bounds__(64 * kStripBlockWaves, K >= 16 ? 2 : 4) void pair_kernel(const StripJob* __restrict__ jobs,
                                                                       const int32_t* __restrict__ first, int npairs,
                                                                       uint32_t* err) {
     const int p = (int)rfl((uint32_t)(blockIdx.x * kStripBlockWaves + (threadIdx.x >> 6)));

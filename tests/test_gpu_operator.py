@@ -188,6 +188,29 @@ def test_batch_shapes_low_complexity_first_column(pa, oracle, monkeypatch, k, mo
     tb.close()
 
 
+def test_batch_shape_k16_experiment(pa, oracle, monkeypatch):
+    """PA_STRIP_K=16 (one wavefront per pair, 16 subwords = 512 rows per lane, eq words from LDS; an experiment recorded in
+    profiles/README.md): same costs on ragged sizes around its lane / strip boundaries and on low-complexity first columns."""
+    monkeypatch.setenv("PA_STRIP_K", "16")
+    monkeypatch.setenv("PA_BATCH_MODE", "seq")
+    rows = 2048 * 16
+    pairs = list(PA_TEST_PAIRS)
+    for n in (1, 33, 511, 512, 513, 2049, rows - 1, rows, rows + 1, rows + 2048 + 70, 2 * rows + 100):
+        pairs.append(gen_pair(n, 0.1, seed=n * 7 + 16))
+    pairs.append((rand_seq(700, seed=1), rand_seq(rows + 130, seed=2)))
+    for first, fill in ((b"C", b"A"), (b"G", b"T")):
+        y = rand_seq(900, seed=5)
+        pairs.append((first + y, fill * 1500 + y))
+    pairs += [(b"", b""), (b"ACGT", b""), (b"", b"ACGTA")]
+    batch = pa.Batch(pairs)
+    assert batch.shape()["k"] == 16
+    costs, _ = batch.run()
+    for (a, b), c in zip(pairs, costs):
+        want = oracle.levenshtein(a, b) if len(a) * len(b) < 4_000_000 else oracle.nw_cost(a, b, True)
+        assert c == want, (len(a), len(b))
+    batch.close()
+
+
 @pytest.mark.parametrize("mode", ["chain", "seq"])
 @pytest.mark.parametrize("k", [0, 1, 2, 4, 8])
 @pytest.mark.parametrize("hint", [0.0, 0.02, 0.3])

@@ -245,8 +245,15 @@ class OperatorContext:
         if not self._h:
             raise PaError(last_error())
 
+    @staticmethod
+    def _check_v(v: np.ndarray, w0: int, w1: int) -> None:
+        """The library reads and writes 16 * (w1 - w0) bytes at v: refuse anything that is not exactly that, in place."""
+        if not isinstance(v, np.ndarray) or v.dtype != np.uint64 or v.shape != (w1 - w0, 2) or not v.flags["C_CONTIGUOUS"] or not v.flags["WRITEABLE"]:
+            raise ValueError(f"v must be a writable C-contiguous uint64 array of shape ({w1 - w0}, 2)")
+
     def compute(self, i0: int, i1: int, w0: int, w1: int, v: np.ndarray, h_mode: int = 0) -> int:
         """v: uint64[w1 - w0, 2] (p, m), updated in place; returns the sum of the bottom-row deltas."""
+        self._check_v(v, w0, w1)
         s = C.c_int32(0)
         rc = load().pa_bp_ctx_compute(self._h, i0, i1, w0, w1, _p(v), h_mode, C.byref(s))
         if rc != 0:
@@ -255,6 +262,7 @@ class OperatorContext:
 
     def fill(self, i0: int, i1: int, w0: int, w1: int, v: np.ndarray):
         """-> (values uint64[i1 - i0, w1 - w0, 2], bottom-row deltas int8[i1 - i0]); v updated in place."""
+        self._check_v(v, w0, w1)
         values = np.zeros((i1 - i0, w1 - w0, 2), np.uint64)
         hb = np.zeros(max(i1 - i0, 1), np.int8)
         rc = load().pa_bp_ctx_fill(self._h, i0, i1, w0, w1, _p(v), _p(values), _p(hb))
@@ -279,6 +287,10 @@ def align_multi(pairs: list[tuple[bytes, bytes]], devices: list[int], trace: boo
     library) -> (costs, CIGARs or None[, per-pair statistics]).  params: an AstarPa2Params of the `simple` family -> batched A*PA2."""
     L = load()
     n = len(pairs)
+    if not devices or any(not isinstance(d, int) for d in devices):
+        raise ValueError("devices must be a non-empty list of device indices")
+    if any(not isinstance(a, bytes) or not isinstance(b, bytes) for a, b in pairs):
+        raise ValueError("pairs must be (bytes, bytes) tuples")
     ap = (C.c_void_p * n)(*[C.cast(C.c_char_p(a), C.c_void_p) for a, _ in pairs])
     bp = (C.c_void_p * n)(*[C.cast(C.c_char_p(b), C.c_void_p) for _, b in pairs])
     al = (C.c_size_t * n)(*[len(a) for a, _ in pairs])

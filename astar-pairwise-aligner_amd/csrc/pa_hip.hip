@@ -1713,6 +1713,12 @@ static int banded_finish(pa_batch* p, std::vector<int32_t>& sums, int32_t* cost_
 
 extern "C" int pa_batch_run(pa_batch* p, int32_t* cost_out, float* kernel_ms) {
     if (!p) return PA_E_ARG;
+    if (p->astar) {  // batched A*PA2, costs only: the band search without the traceback kernels (the distance over the traced band)
+        float fwd = 0.f;
+        const int rc = pa_batch_align(p, cost_out, nullptr, &fwd, nullptr);
+        if (kernel_ms) *kernel_ms = fwd;
+        return rc;
+    }
     hipStream_t s = p->stream;
     if (const int rc = batch_forward(p)) return rc;
     // (4) read back: bottom sums and each pair's last v word (for the rows beyond |b| in the last word)
@@ -1798,8 +1804,9 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
     if (cigar_out)
         for (size_t i = 0; i < P; ++i) cigar_out[i] = nullptr;
     if (const int rc = batch_forward(p)) return rc;
-    // traceback: one wavefront per pair
-    if (P) {
+    // traceback: one wavefront per pair (batched A*PA2 without CIGARs asked for: none, the costs come from the forward pass)
+    const bool cost_only_astar = p->astar && !cigar_out;
+    if (P && !cost_only_astar) {
         const int grid = (int)((P + kStripBlockWaves - 1) / kStripBlockWaves);
         if (p->dt_max_g > 0)
             hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(64 * kStripBlockWaves), kStripBlockWaves * sizeof(DtLds), s, p->d_tjobs.as<TraceJob>(), (int)P,
@@ -1848,6 +1855,11 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
             st.unique_lanes = r.unique_lanes;
             st.f_max_tries = r.f_max_tries;
             st.sanity_violations = r.sanity_violations;
+            if (cost_only_astar) {  // no traceback ran: the cost is the forward pass's, a pair it handed back goes to the host engine
+                costs[i] = r.cost;
+                lens[i] = r.status != apa2::kOk ? kTraceFailed : 0u;
+                continue;
+            }
             st.dt_trace_tries = ts[8 * i + 0];
             st.dt_trace_success = ts[8 * i + 1];
             st.dt_trace_fallback = ts[8 * i + 2];
@@ -1860,7 +1872,7 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
     std::vector<uint32_t> tlens(P, 0);
     std::vector<uint64_t> dst_off(P, 0);
     const uint8_t* packed = nullptr;
-    if (P) {
+    if (P && !cost_only_astar) {
         hipLaunchKernelGGL(format_cigar_kernel, dim3((unsigned)P), dim3(64), 0, s, p->d_cigar.as<uint32_t>(), p->d_cig_src_off.as<uint64_t>(),
                            p->d_cigar_len.as<uint32_t>(), p->d_text.as<uint8_t>(), p->d_text_len.as<uint32_t>());
         if (!hip_ok(hipGetLastError(), "format_cigar_kernel") ||
@@ -1932,7 +1944,7 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
             return fail_out(i, PA_E_HIP);
         int32_t c = 0;
         pa_astarpa2_stats fst{};
-        const int rc = align_hip(ba.data(), p->n[i], bb.data(), p->m[i], fallback, true, false, &c, &text, &fst);
+        const int rc = align_hip(ba.data(), p->n[i], bb.data(), p->m[i], fallback, !cost_only_astar, false, &c, &text, &fst);
         if (rc != 0) return fail_out(i, rc);
         if (p->astar) {
             p->pair_stats[i] = fst;

@@ -118,6 +118,24 @@ def test_c3_like_100kbp(pa, oracle):
     check(pa, oracle, pairs, oracle.params_simple(), fallbacks=0)
 
 
+def test_cost_only_run(pa, oracle):
+    """pa_batch_run on an A*PA2 batch: the band search without the traceback kernels; costs = distances, block statistics those of
+    the traced band, trace statistics zero; empty sequences through the host engine."""
+    pairs = [gen_pair(n, e, seed=n) for n, e in ((300, 0.05), (5000, 0.1), (20000, 0.2), (777, 0.0))] + [(b"", b"ACG"), (b"ACGT", b"")]
+    batch = pa.Batch(pairs, params=pa.AstarPa2Params.simple())
+    costs, ms = batch.run()
+    stats = batch.pair_stats()
+    for (a, b), c, st in zip(pairs, costs, stats):
+        assert c == oracle.levenshtein(a, b)
+        if a and b:
+            want = oracle.cpu_align(a, b, oracle.params_simple())[2]
+            assert all(st[k] == want[k] for k in ("num_blocks", "num_incremental_blocks", "computed_lanes", "unique_lanes", "f_max_tries", "sanity_violations"))
+            assert all(st[k] == 0 for k in ("dt_trace_tries", "dt_trace_success", "dt_trace_fallback", "fill_tries", "fill_success", "fill_fallback"))
+    costs2, cigars, _, _ = batch.align()  # and the traced call on the same batch afterwards
+    assert costs2.tolist() == costs.tolist() and all(oracle.cigar_verify(g, a, b) == c for (a, b), c, g in zip(pairs, costs2, cigars))
+    batch.close()
+
+
 def test_unsupported_parameters_are_refused(pa, oracle):
     from tests.test_gpu_engine import gpu_params
 

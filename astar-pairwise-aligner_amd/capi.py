@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "pa_pairs_read", "pa_pairs_count", "pa_pairs_get", "pa_pairs_free", "pa_write_results_csv", "pa_align_file",
     "pa_align", "pa_batch_align_multi", "pa_batch_create_trace_params",
     "pa_bp_ctx_create", "pa_bp_ctx_compute", "pa_bp_ctx_fill", "pa_bp_ctx_destroy",
-    "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools",
+    "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools", "pa_align_file_params",
 ]
 
 _lib = None
@@ -112,6 +112,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_batch_align_multi_params.restype = C.c_int
     L.pa_align_file.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(sz)]
     L.pa_align_file.restype = C.c_int
+    L.pa_align_file_params.argtypes = [C.c_char_p, C.c_char_p, vp, C.POINTER(sz)]
+    L.pa_align_file_params.restype = C.c_int
     for name in ("astarpa2_simple", "astarpa2_full", "astarpa"):
         if hasattr(L, name):
             f = getattr(L, name)
@@ -222,10 +224,15 @@ def read_pairs(path: str) -> list[tuple[bytes, bytes]]:
         L.pa_pairs_free(h)
 
 
-def align_file(input_path: str, output_path: str) -> int:
-    """pa-bin's main loop on the GPU: every pair of the input gets one "{cost},{cigar}" line.  Returns the pair count."""
+def align_file(input_path: str, output_path: str, params=None) -> int:
+    """pa-bin's main loop on the GPU: every pair of the input gets one "{cost},{cigar}" line.  Returns the pair count.
+    params: an AstarPa2Params (pa_align_file_params: batched A*PA2 for the `simple` family, a loop over pa_align otherwise)."""
     n = C.c_size_t(0)
-    rc = load().pa_align_file(str(input_path).encode(), str(output_path).encode(), C.byref(n))
+    if params is not None:
+        cp = params._to_c()
+        rc = load().pa_align_file_params(str(input_path).encode(), str(output_path).encode(), C.byref(cp), C.byref(n))
+    else:
+        rc = load().pa_align_file(str(input_path).encode(), str(output_path).encode(), C.byref(n))
     if rc == -1:
         raise ValueError("sequence contains a character outside ACGT")
     if rc != 0:

@@ -215,7 +215,26 @@ static int batch_align_queue(const uint8_t* const* a, const size_t* a_len, const
     if (chunk * (size_t)ndevices > pairs) chunk = (pairs + (size_t)ndevices - 1) / (size_t)ndevices;
     if (chunk == 0) chunk = 1;
     if (const char* e = std::getenv("PA_MULTI_CHUNK")) chunk = std::max<size_t>(1, (size_t)std::atoll(e));  // (tests)
-    const size_t nchunks = (pairs + chunk - 1) / chunk;
+    // ... and no chunk's block-column store (traced batches: one V column per 256 columns of a, full height) beyond ~24 GB
+    const double kChunkBytes = 24e9;
+    std::vector<size_t> bounds{0};
+    {
+        double bytes = 0;
+        size_t cnt = 0;
+        for (size_t k = 0; k < pairs; ++k) {
+            const size_t i = order[k];
+            const double need = (cigar_out || params) ? ((double)a_len[i] / 256.0 + 2.0) * (double)((b_len[i] + 63) / 64) * 16.0 : 0.0;
+            if (cnt > 0 && (cnt >= chunk || bytes + need > kChunkBytes)) {
+                bounds.push_back(k);
+                bytes = 0;
+                cnt = 0;
+            }
+            bytes += need;
+            cnt += 1;
+        }
+        bounds.push_back(pairs);
+    }
+    const size_t nchunks = bounds.size() - 1;
     std::atomic<size_t> next{0};
     std::atomic<bool> failed{false};
     std::vector<int> rcs((size_t)ndevices, 0);
@@ -225,7 +244,7 @@ static int batch_align_queue(const uint8_t* const* a, const size_t* a_len, const
         while (rc == 0 && !failed.load(std::memory_order_relaxed)) {
             const size_t c = next.fetch_add(1, std::memory_order_relaxed);
             if (c >= nchunks) break;
-            std::vector<size_t> mine(order.begin() + c * chunk, order.begin() + std::min(pairs, (c + 1) * chunk));
+            std::vector<size_t> mine(order.begin() + bounds[c], order.begin() + bounds[c + 1]);
             std::sort(mine.begin(), mine.end());
             const size_t k = mine.size();
             std::vector<const uint8_t*> ap(k), bp(k);
@@ -281,6 +300,42 @@ static int batch_align_queue(const uint8_t* const* a, const size_t* a_len, const
             return rcs[(size_t)r];
         }
     return 0;
+}
+
+// pa-bin's loop with an aligner's parameters (`pa-bin --aligner astarpa2 ...`, pa-bin/src/main.rs:24-35): parameters of the batched
+// A*PA2 family run as batches on the current device (chunks of bounded memory), anything else as a loop over pa_align.
+extern "C" int pa_align_file_params(const char* input_path, const char* output_path, const pa_astarpa2_params* params, size_t* pairs_out) {
+    if (!params) return pa_align_file(input_path, output_path, pairs_out);
+    std::unique_ptr<pa_pairs, void (*)(pa_pairs*)> in(pa_pairs_read(input_path), pa_pairs_free);
+    if (!in) return PA_E_ARG;
+    const size_t n = in->a.size();
+    if (pairs_out) *pairs_out = n;
+    std::vector<const uint8_t*> ap(n), bp(n);
+    std::vector<size_t> al(n), bl(n);
+    for (size_t i = 0; i < n; ++i) {
+        ap[i] = reinterpret_cast<const uint8_t*>(in->a[i].data());
+        bp[i] = reinterpret_cast<const uint8_t*>(in->b[i].data());
+        al[i] = in->a[i].size();
+        bl[i] = in->b[i].size();
+    }
+    std::vector<int32_t> costs(n, 0);
+    std::vector<char*> cigars(n, nullptr);
+    int rc = 0;
+    if (n) {
+        // does the batched program take these parameters?  (a probe batch of one pair; NULL = no)
+        pa_batch* probe = pa_batch_create_params(ap.data(), al.data(), bp.data(), bl.data(), 1, params);
+        if (probe) {
+            pa_batch_destroy(probe);
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            rc = batch_align_queue(ap.data(), al.data(), bp.data(), bl.data(), n, &dev, 1, costs.data(), cigars.data(), params, nullptr);
+        } else {
+            for (size_t i = 0; i < n && rc == 0; ++i) rc = pa_align(ap[i], al[i], bp[i], bl[i], params, 1, &costs[i], &cigars[i], nullptr);
+        }
+    }
+    if (rc == 0 && output_path) rc = pa_write_results_csv(output_path, costs.data(), cigars.data(), n);
+    for (char* c : cigars) std::free(c);
+    return rc;
 }
 
 extern "C" int pa_batch_align_multi(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len,

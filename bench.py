@@ -145,8 +145,8 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dts = float(tt.item())
         c4_sharded = {
-            "workload": f"C4 strong scaling: {args.c4_pairs} x 10 kbp pairs (1/5/10/15 %), global alignment with traceback, LPT-sharded over {world} GPU(s), "
-                        "every rank ends with all (cost, CIGAR) results",
+            "workload": f"C4 strong scaling: {args.c4_pairs} x 10 kbp pairs (1/5/10/15 %), global alignment with traceback, over {world} GPU(s), "
+                        "chunks pulled from a queue (one counter in the process group's store), every rank ends with all (cost, CIGAR) results",
             "pairs_per_sec": round(args.c4_pairs / dts, 1),
             "ms": round(dts * 1e3, 2),
             "n_gpus": world,
@@ -154,6 +154,29 @@ def main():
             "cost_checksum": int(sum(c for c, _ in res)),
             "cigar_bytes": int(sum(len(g) for _, g in res)),
         }
+        # the same queue with band-limited work per pair (batched A*PA2 `simple`): what the work of a pair is depends on its divergence
+        try:
+            from astar_pairwise_aligner_amd.sharding import astarpa2_align
+
+            run_a = astarpa2_align(pa.AstarPa2Params.simple())
+            sharded_align(c4s[: 64 * world], compute=run_a)
+            barrier()
+            t0a = time.perf_counter()
+            res_a = sharded_align(c4s, compute=run_a)
+            barrier()
+            dta = time.perf_counter() - t0a
+            if dist is not None:
+                tt = torch.tensor([dta], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dta = float(tt.item())
+            assert [c for c, _ in res_a] == [c for c, _ in res], "sharded A*PA2 costs differ from the sharded full DP"
+            c4_sharded["astarpa2_simple"] = {"pairs_per_sec": round(args.c4_pairs / dta, 1), "ms": round(dta * 1e3, 2),
+                                             "cigar_bytes": int(sum(len(g) for _, g in res_a))}
+            del res_a
+        except AssertionError:
+            raise
+        except Exception as e:  # (reporting only)
+            c4_sharded["astarpa2_simple"] = {"error": str(e)}
         del res, c4s
 
     if rank != 0:
@@ -305,59 +328,6 @@ def main():
         except Exception as e:  # (reporting only)
             out["c4_batch_align"]["dt_trace_kernel_ms"] = f"failed: {e}"
 
-    # ---- batched A*PA2 (pa_batch_create_params): AstarPa2Params::simple() for many pairs, ONE wavefront per pair runs the whole band
-    #      search, the device traceback walks the banded blocks.  Cost, CIGAR and statistics are what a loop over pa_align returns
-    #      (tests/test_gpu_apa2_batch.py); here the rates, and a sample checked against the CPU-kernel engine ----
-    if not args.no_apa2 and world == 1:
-        import oracle as _orc
-
-        divs = (0.01, 0.05, 0.10, 0.15)
-
-        def apa2_leg(ps, what, sample):
-            t = time.perf_counter()
-            ba = pa.Batch(ps, params=pa.AstarPa2Params.simple())
-            t_create = time.perf_counter() - t
-            ba.align()
-            best = (1e9, 0.0, 0.0, 0.0)
-            for _ in range(3):
-                t = time.perf_counter()
-                cs, gs, f_ms, t_ms = ba.align()
-                dt = time.perf_counter() - t
-                if dt < best[0]:
-                    best = (dt, f_ms, t_ms, ba.last_c_abi_ms)
-            sts = ba.pair_stats()
-            for i in sample:  # plumbing check on a sample (the parity tests compare every pair)
-                wc, wg, ws = _orc.cpu_align(*ps[i], _orc.params_simple())
-                assert (int(cs[i]), gs[i]) == (wc, wg) and sts[i]["computed_lanes"] == ws["computed_lanes"], f"batched A*PA2 differs from the CPU-kernel engine on pair {i}"
-            lanes = float(sum(x["computed_lanes"] for x in sts))
-            leg = {
-                "workload": what,
-                "pairs_per_sec": round(len(ps) / best[0], 1),
-                "ms": round(best[0] * 1e3, 3),
-                "c_abi_ms": round(best[3], 3),
-                "c_abi_pairs_per_sec": round(len(ps) / (best[3] * 1e-3), 1),
-                "forward_kernel_ms": round(best[1], 3),
-                "trace_kernel_ms": round(best[2], 3),
-                "create_ms": round(t_create * 1e3, 1),
-                "computed_lanes": lanes,                      # 64-row words x 256-column blocks actually computed (BlockStats)
-                "band_fraction_of_matrix": round(lanes * 64 * 256 / ba.stats()["cells"], 4),
-                "band_gcups_forward": round(lanes * 64 * 256 / (best[1] * 1e-3) / 1e9, 1),
-                "mean_f_max_tries": round(sum(x["f_max_tries"] for x in sts) / len(sts), 2),
-                "host_engine_fallbacks": ba.trace_fallbacks(),
-                "kernel": "pa::apa2::apa2_kernel + pa::trace_kernel<true>",
-            }
-            ba.close()
-            return leg
-
-        c4a = [generate_pair(10_000, divs[i % 4], seed=1_000_000 + i) for i in range(args.c4_pairs)]
-        out["c4_astarpa2_simple"] = apa2_leg(c4a, f"C4: {args.c4_pairs} independent 10 kbp pairs, 1/5/10/15 % divergence, A*PA2 `simple` (band doubling, GapCost, DT-trace): "
-                                             "cost + CIGAR + statistics of every pair, strings delivered to the host", range(0, min(args.c4_pairs, 40), 1))
-        del c4a
-        for n3 in args.c3_batch:
-            c3a = [generate_pair(100_000, 0.05, seed=3_000_000 + i) for i in range(n3)]
-            out[f"c3_batch_{n3}"] = apa2_leg(c3a, f"C3 batched: {n3} independent 100 kbp pairs, 5 % divergence, A*PA2 `simple` with traceback", range(0, min(n3, 2)))
-            del c3a
-
     # ---- PCIe-inclusive rate of the headline workload: host buffers -> device layout -> one pass (never `value`) ----
     if world == 1:
         t = time.perf_counter()
@@ -449,6 +419,59 @@ def main():
                      "gcups_equivalent": round(len(a5) * len(b5) / dt5 / 1e9, 1),
                      "sanity_violations": int(s5["sanity_violations"])}
         del a5, b5
+
+    # ---- batched A*PA2 (pa_batch_create_params): AstarPa2Params::simple() for many pairs, ONE wavefront per pair runs the whole band
+    #      search, the device traceback walks the banded blocks.  Cost, CIGAR and statistics are what a loop over pa_align returns
+    #      (tests/test_gpu_apa2_batch.py); here the rates, and a sample checked against the CPU-kernel engine ----
+    if not args.no_apa2 and world == 1:
+        import oracle as _orc
+
+        divs = (0.01, 0.05, 0.10, 0.15)
+
+        def apa2_leg(ps, what, sample):
+            t = time.perf_counter()
+            ba = pa.Batch(ps, params=pa.AstarPa2Params.simple())
+            t_create = time.perf_counter() - t
+            ba.align()
+            best = (1e9, 0.0, 0.0, 0.0)
+            for _ in range(3):
+                t = time.perf_counter()
+                cs, gs, f_ms, t_ms = ba.align()
+                dt = time.perf_counter() - t
+                if dt < best[0]:
+                    best = (dt, f_ms, t_ms, ba.last_c_abi_ms)
+            sts = ba.pair_stats()
+            for i in sample:  # plumbing check on a sample (the parity tests compare every pair)
+                wc, wg, ws = _orc.cpu_align(*ps[i], _orc.params_simple())
+                assert (int(cs[i]), gs[i]) == (wc, wg) and sts[i]["computed_lanes"] == ws["computed_lanes"], f"batched A*PA2 differs from the CPU-kernel engine on pair {i}"
+            lanes = float(sum(x["computed_lanes"] for x in sts))
+            leg = {
+                "workload": what,
+                "pairs_per_sec": round(len(ps) / best[0], 1),
+                "ms": round(best[0] * 1e3, 3),
+                "c_abi_ms": round(best[3], 3),
+                "c_abi_pairs_per_sec": round(len(ps) / (best[3] * 1e-3), 1),
+                "forward_kernel_ms": round(best[1], 3),
+                "trace_kernel_ms": round(best[2], 3),
+                "create_ms": round(t_create * 1e3, 1),
+                "computed_lanes": lanes,                      # 64-row words x 256-column blocks actually computed (BlockStats)
+                "band_fraction_of_matrix": round(lanes * 64 * 256 / ba.stats()["cells"], 4),
+                "band_gcups_forward": round(lanes * 64 * 256 / (best[1] * 1e-3) / 1e9, 1),
+                "mean_f_max_tries": round(sum(x["f_max_tries"] for x in sts) / len(sts), 2),
+                "host_engine_fallbacks": ba.trace_fallbacks(),
+                "kernel": "pa::apa2::apa2_kernel + pa::trace_kernel<true>",
+            }
+            ba.close()
+            return leg
+
+        c4a = [generate_pair(10_000, divs[i % 4], seed=1_000_000 + i) for i in range(args.c4_pairs)]
+        out["c4_astarpa2_simple"] = apa2_leg(c4a, f"C4: {args.c4_pairs} independent 10 kbp pairs, 1/5/10/15 % divergence, A*PA2 `simple` (band doubling, GapCost, DT-trace): "
+                                             "cost + CIGAR + statistics of every pair, strings delivered to the host", range(0, min(args.c4_pairs, 40), 1))
+        del c4a
+        for n3 in args.c3_batch:
+            c3a = [generate_pair(100_000, 0.05, seed=3_000_000 + i) for i in range(n3)]
+            out[f"c3_batch_{n3}"] = apa2_leg(c3a, f"C3 batched: {n3} independent 100 kbp pairs, 5 % divergence, A*PA2 `simple` with traceback", range(0, min(n3, 2)))
+            del c3a
 
     # ---- CPU baseline: the AVX2 port of the reference's SIMD schedule, 1 core, bounded sample ----
     if not args.no_cpu_baseline:

@@ -179,6 +179,10 @@ void pa_pairs_free(pa_pairs* pairs);
 int pa_write_results_csv(const char* path, const int32_t* costs, const char* const* cigars, size_t n);
 /* pa-bin's main loop for a whole input at once: read, pa_batch_align every pair on the GPU, write the CSV. */
 int pa_align_file(const char* input_path, const char* output_path, size_t* pairs_out);
+/* The same with an aligner's parameters (pa-bin's `--aligner astarpa2 ...`): parameters of the batched A*PA2 family
+ * (pa_batch_create_params) run as batches on the current device, others as a loop over pa_align; NULL = pa_align_file. */
+struct pa_astarpa2_params;
+int pa_align_file_params(const char* input_path, const char* output_path, const struct pa_astarpa2_params* params, size_t* pairs_out);
 
 #ifdef __cplusplus
 }

@@ -71,3 +71,24 @@ def test_align_file_writes_cost_cigar_lines(pa, oracle, tmp_path):
         assert int(cost) == oracle.levenshtein(a, b)
         assert oracle.cigar_verify(cigar, a, b) == int(cost)
     assert lines[-1].startswith("2,")  # astarpa-c/example.c:8-29
+
+
+@pytest.mark.gpu
+def test_align_file_with_aligner_params(pa, oracle, tmp_path):
+    """pa_align_file_params: pa-bin's loop with an aligner's parameters -- `simple` through the batched A*PA2, `full` (outside the
+    batched family) through a loop over pa_align; every line is what the CPU-kernel engine returns for those parameters."""
+    from tests.util_seq import gen_pair
+
+    pa.require_gpu()
+    pairs = [gen_pair(n, 0.08, seed=n) for n in (50, 300, 1000, 2600, 7000)] + [(b"ACTCGCT", b"AACTCGTT")]
+    f = tmp_path / "in.seq"
+    f.write_text("".join(f">{a.decode()}\n<{b.decode()}\n" for a, b in pairs))
+    for prm, oprm in ((pa.AstarPa2Params.simple(), oracle.params_simple()), (pa.AstarPa2Params.full(), oracle.params_full())):
+        out = tmp_path / "out.csv"
+        assert pa.align_file(f, out, params=prm) == len(pairs)
+        lines = out.read_text().splitlines()
+        assert len(lines) == len(pairs)
+        for (a, b), line in zip(pairs, lines):
+            cost, cigar = line.split(",")
+            want = oracle.cpu_align(a, b, oprm)
+            assert (int(cost), cigar) == (want[0], want[1])

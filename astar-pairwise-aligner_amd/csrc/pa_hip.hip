@@ -1254,6 +1254,15 @@ static bool astar_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t* cons
 static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len, size_t pairs,
                               bool trace, float band_hint = -1.f, int dt_max_g = 0, int dt_fr_drop = 0, const pa_astarpa2_params* astar = nullptr) {
     if (!ensure_device()) return nullptr;
+    static const bool cprof = getenv("PA_ALIGN_PROFILE") != nullptr;  // diagnostics: where the creation time goes
+    auto cnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double c_mark = cnow();
+    auto cmark = [&](const char* what) {
+        if (!cprof) return;
+        const double t = cnow();
+        std::fprintf(stderr, "[pa_batch_create] %-28s %8.3f ms\n", what, t - c_mark);
+        c_mark = t;
+    };
     auto p = std::make_unique<pa_batch>();
     p->pairs = pairs;
     p->trace = trace;
@@ -1333,9 +1342,11 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
     if (!p->d_a.alloc(ta) || !p->d_b.alloc(tb) || !p->d_codes.alloc(tc * 4) || !p->d_prof.alloc(tp * 16) ||
         !p->d_v.alloc(tp * 16) || !p->d_gran.alloc(tg * 8) || !p->d_sums.alloc(std::max<size_t>(pairs * 4, 16)) || !p->d_misc.alloc(32))
         return nullptr;
+    cmark("host layout + hipMalloc");
     if (!hip_ok(hipStreamCreate(&p->stream), "hipStreamCreate") || !hip_ok(hipEventCreate(&p->ev0), "event") ||
         !hip_ok(hipEventCreate(&p->ev1), "event") || !hip_ok(hipEventCreate(&p->ev2), "event"))
         return nullptr;
+    cmark("stream + events");
     // Upload: the sequences are gathered into the device layout through two pinned staging buffers, so that the copy of one
     // chunk overlaps the gathering of the next and runs at link speed (a pageable H2D of 800 MB costs 5x as much).
     {
@@ -1387,6 +1398,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             if (done[k]) (void)hipEventDestroy(done[k]);
         if (!ok) return nullptr;
     }
+    cmark("upload of the sequences");
     // Jobs: pair-major, strips of a pair consecutive (ticket order == dependency order).
     p->last_job.assign(pairs, -1);
     std::vector<int32_t> first(pairs + 1, 0);
@@ -1504,6 +1516,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             p->jobs[j].flags |= kJobLog;
         }
     }
+    cmark("jobs + descriptors");
     if (!p->d_jobs.alloc(p->jobs.size() * sizeof(StripJob))) return nullptr;
     if (!p->jobs.empty() &&
         !hip_ok(hipMemcpyAsync(p->d_jobs.ptr, p->jobs.data(), p->jobs.size() * sizeof(StripJob), hipMemcpyHostToDevice, p->stream), "H2D jobs"))

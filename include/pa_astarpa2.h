@@ -66,8 +66,11 @@ void pa_params_batch_align(pa_astarpa2_params* p);
  * free() it or use astarpa_free_cigar).  Returns 0, or a PA_E_* code.  All DP rectangles run on the GPU.
  * trace == 0 with Domain::Astar, sparse blocks and no incremental doubling (`simple` and its relatives): the cost is the edit
  * distance, computed over the band of the TRACED mode, and the block statistics are those of the traced band (trace statistics 0).
- * The reference's own cost-only mode for these parameters (astarpa2/src/blocks.rs:252-277: ONE block whose fixed_j_range is the
- * union over all columns, i.e. a triangle of the matrix; no entry point or test of the reference uses it) is not reproduced. */
+ * The reference's own cost-only mode for these parameters (astarpa2/src/blocks.rs:252-277: ONE block updated in place, its
+ * fixed_j_range the union over all columns; no entry point or test of the reference uses it) is not reproduced: it RETURNS UPPER
+ * BOUNDS on some inputs -- two independent restatements of it (csrc/engine.hpp and tests/tools/cost_only_restatement.py, pure
+ * Python from the Rust text) both give 11353 for a pair whose distance is 11325, with the same passes and computed lanes
+ * (tests/test_cost_only_mode.py) -- whereas this library returns the distance. */
 int pa_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params* params,
              int trace, int32_t* cost_out, char** cigar_out, pa_astarpa2_stats* stats_out);
 

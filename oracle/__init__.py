@@ -26,9 +26,33 @@ H_DTYPE = np.dtype([("p", "<u8"), ("m", "<u8")])
 BITS_DTYPE = np.dtype([("b0", "<u8"), ("b1", "<u8")])
 
 
+_TARGETS = ("libpa_oracle.so", "libpa_engine_cpu.so", "libpa_sweep_emu.so", "libpa_apa2_emu.so")
+
+
+def _source_hash() -> str:
+    """Content hash of everything the oracle libraries are built from (file times do not survive the copy to a GPU box, and make would
+    rebuild the lot there -- a minute of g++ in front of the first GPU test)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = _DIR.parent / "astar-pairwise-aligner_amd" / "csrc"
+    files = sorted(list(_DIR.glob("*.c")) + list(_DIR.glob("*.cpp")) + list(_DIR.glob("*.h")) + list(_DIR.glob("*.hpp")) + [_DIR / "Makefile"] +
+                   [csrc / n for n in ("engine.hpp", "gcsh.hpp", "engine_capi.hpp", "sweep_logic.hpp", "sweep_wave.hpp", "sweep_host.hpp", "apa2_logic.hpp")] +
+                   [_DIR.parent / "include" / "pa_astarpa2.h"])
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()
+
+
 def build() -> Path:
-    """Compile the oracle with gcc/g++ (oracle/Makefile; make decides what is stale)."""
+    """Compile the oracle with gcc/g++ (oracle/Makefile).  Skipped when the libraries exist and were built from exactly these sources."""
+    stamp = _DIR / "_build" / ".source_hash"
+    cur = _source_hash()
+    if all((_DIR / "_build" / t).exists() for t in _TARGETS) and stamp.exists() and stamp.read_text().strip() == cur:
+        return _LIB_PATH
     subprocess.run(["make", "-C", str(_DIR), "-s"], check=True)
+    stamp.write_text(cur + "\n")
     return _LIB_PATH
 
 

@@ -118,6 +118,16 @@ def test_c3_like_100kbp(pa, oracle):
     check(pa, oracle, pairs, oracle.params_simple(), fallbacks=0)
 
 
+def test_one_1mbp_pair_next_to_short_ones(pa, oracle):
+    """A 1 Mbp pair (3907 blocks, bands of hundreds of words: K = 4 strips chained through the granule rows, multi-chunk prefix sums and
+    scans) in the same batch as short pairs; also very unequal lengths."""
+    pairs = [gen_pair(1_000_000, 0.03, seed=21), gen_pair(2000, 0.1, seed=22), (rand_seq(300, seed=23), rand_seq(40_000, seed=24)),
+             (rand_seq(40_000, seed=25), rand_seq(300, seed=26)), gen_pair(70_000, 0.25, seed=27)]
+    costs, cigars, _, _ = check(pa, oracle, pairs, oracle.params_simple())
+    for (a, b), c, cg in zip(pairs, costs, cigars):
+        assert oracle.cigar_verify(cg, a, b) == c
+
+
 def test_cost_only_run(pa, oracle):
     """pa_batch_run on an A*PA2 batch: the band search without the traceback kernels; costs = distances, block statistics those of
     the traced band, trace statistics zero; empty sequences through the host engine."""

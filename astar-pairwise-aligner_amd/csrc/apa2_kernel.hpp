@@ -48,6 +48,8 @@ struct DevBackend {
     uint32_t* dbg;  // diagnostics: host-mapped progress markers, or nullptr
     int lane;
     bool k1_only = false;  // experiments: K = 1 strips only (PA_APA2_K1)
+    mutable uint32_t strip_units = 0;  // modelled VALU instructions of the strips so far, in units of 32 (one per unrolled chunk step)
+    __device__ __forceinline__ uint64_t strip_instructions() const { return (uint64_t)strip_units << 5; }
 
     __device__ __forceinline__ DevBackend(const PairJob& j, const HeurParams& h, uint32_t* e, uint32_t* d) : job(j), hp(h), err(e), dbg(d) { lane = (int)(threadIdx.x & 63); }
     __device__ __forceinline__ void mark(int slot_, uint32_t value) const {
@@ -175,6 +177,8 @@ struct DevBackend {
             else if (j.nlanes <= 32) run_strip<1, false, false, false, true, false, true, true>(j, err);
             else run_strip<1, false, false, false, true, false, false, true>(j, err);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            // (run_strip: ceil(n / 32) + 2 chunks of 32 steps, one chunk less for the half-wave strip; 11 + 12 K instructions per step)
+            strip_units += (uint32_t)((((i1 - i0 + 31) >> 5) + ((kk == 1 && j.nlanes <= 32) ? 1 : 2)) * (11 + 12 * kk));
             done += take;
         }
         return (int32_t)rfl((uint32_t)*(const PA_GLOBAL int32_t*)job.sum);

@@ -20,6 +20,7 @@
 //   bool scan_last(k, rec, i, f_max, lo, hi, &j)                last such row
 //   bool failed()                                               the backend met an error (device: the strips' error word)
 //   int32_t uniform(x)                                          x, known to be wavefront-uniform (device: back into a scalar register)
+//   uint64_t strip_instructions()                               reporting: modelled VALU instructions of the DP strips so far
 //   void mark(slot, value)                                      diagnostics: progress markers (a no-op unless a debug buffer is set)
 // The two scans replace the probing loops of domain.rs:306-328: with `sparse_h` the reference jumps ceil((f - f_max) / 2) rows
 // after a failed probe; f changes by at most 2 per row (g by 1, the heuristic by at most 1), so a jump never skips a row with
@@ -80,7 +81,7 @@ struct PairResult {
     uint32_t pad0;
     uint64_t computed_lanes, unique_lanes;
     int32_t last_block_idx, blocks_len;
-    uint32_t pad1[2];
+    uint64_t strip_instr;  // VALU instructions of the DP strips this pair ran (model: steps x (11 + 12 K)); reporting only
 };
 static_assert(sizeof(PairResult) == 64, "PairResult layout");
 
@@ -295,7 +296,7 @@ struct PairProg {
         out->unique_lanes = unique_lanes;
         out->last_block_idx = last_block_idx;
         out->blocks_len = blocks_len;
-        out->pad1[0] = out->pad1[1] = 0;
+        out->strip_instr = be.strip_instructions();
     }
 };
 

@@ -982,6 +982,7 @@ struct pa_batch {
     apa2::SearchParams sp{};
     DeviceBuf d_rec, d_results, d_pjobs, d_order, d_tstats, d_sh;
     std::vector<pa_astarpa2_stats> pair_stats;  // of the last pa_batch_align
+    double apa2_strip_instr = 0;  // modelled VALU instructions of the DP strips of the last pa_batch_align (reporting)
     double cells = 0, word_updates = 0, algo_bytes = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1859,6 +1860,7 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
                   !hip_ok(hipMemcpy(ts.data(), p->d_tstats.ptr, P * 32, hipMemcpyDeviceToHost), "D2H trace stats")))
             return PA_E_HIP;
         p->pair_stats.assign(P, pa_astarpa2_stats{});
+        p->apa2_strip_instr = 0;
         for (size_t i = 0; i < P; ++i) {
             pa_astarpa2_stats& st = p->pair_stats[i];
             const apa2::PairResult& r = results[i];
@@ -1868,6 +1870,7 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
             st.unique_lanes = r.unique_lanes;
             st.f_max_tries = r.f_max_tries;
             st.sanity_violations = r.sanity_violations;
+            p->apa2_strip_instr += (double)r.strip_instr;
             if (cost_only_astar) {  // no traceback ran: the cost is the forward pass's, a pair it handed back goes to the host engine
                 costs[i] = r.cost;
                 lens[i] = r.status != apa2::kOk ? kTraceFailed : 0u;
@@ -2001,7 +2004,9 @@ extern "C" void pa_batch_stats(const pa_batch* p, double* cells, double* word_up
 extern "C" void pa_batch_shape(const pa_batch* p, int* k, int* sequential, double* valu_instructions) {
     if (k) *k = p->k;
     if (sequential) *sequential = p->sequential ? 1 : 0;
-    if (valu_instructions) {
+    if (valu_instructions && p->astar) {
+        *valu_instructions = p->apa2_strip_instr;  // of the last pa_batch_align: the DP strips alone (the band logic comes on top)
+    } else if (valu_instructions) {
         double t = 0;
         for (const StripJob& j : p->jobs) {
             const int kj = p->sequential ? j.k : p->k;

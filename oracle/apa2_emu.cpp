@@ -42,6 +42,7 @@ struct EmuBackend {
     bool failed() const { return false; }
     void mark(int, uint32_t) const {}
     int32_t uniform(int32_t x) const { return x; }
+    uint64_t strip_instructions() const { return 0; }
     BlockRec load_rec(int32_t k) const { return rec[(size_t)k]; }
     void store_rec(int32_t k, const BlockRec& r) { rec[(size_t)k] = r; }
     int32_t index(int32_t k, const BlockRec& r, int32_t j) const {  // block.rs:69-122 (from the top)

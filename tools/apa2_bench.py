@@ -21,10 +21,11 @@ def bench(pairs, label, reps=3):
         if dt < best[0]:
             best = (dt, f_ms, t_ms, bt.last_c_abi_ms)
     st = bt.pair_stats()
+    strip_instr = bt.shape()["valu_instructions"]
     lanes = sum(s["computed_lanes"] for s in st)
     print(f"{label}: {len(pairs)} pairs  create {t_create*1e3:.1f} ms  align {best[0]*1e3:.2f} ms (c abi {best[3]:.2f})  forward {best[1]:.2f} ms  trace {best[2]:.2f} ms  "
           f"=> {len(pairs)/best[0]:.0f} pairs/s ({len(pairs)/(best[3]*1e-3):.0f} at the C ABI)  computed lanes {lanes:.3e} = {lanes*256*64/(best[1]*1e-3)/1e9:.0f} band-GCUPS  "
-          f"fallbacks {bt.trace_fallbacks()}  tries {sum(s['f_max_tries'] for s in st)/len(st):.2f}", flush=True)
+          f"strip VALU instructions (model) {strip_instr:.3e} = {strip_instr/(best[1]*1e-3)/1e9:.0f} G/s  fallbacks {bt.trace_fallbacks()}  tries {sum(s['f_max_tries'] for s in st)/len(st):.2f}", flush=True)
     bt.close()
     return costs
 

@@ -48,6 +48,7 @@ struct DevBackend {
     uint32_t* dbg;  // diagnostics: host-mapped progress markers, or nullptr
     int lane;
     bool k1_only = false;  // experiments: K = 1 strips only (PA_APA2_K1)
+    uint32_t lds_eq = 0;   // byte offset of this wavefront's 4 KB LDS slice for the eq words of K = 4 strips (strip_kernel.hpp LdsEq)
     mutable uint32_t strip_units = 0;  // modelled VALU instructions of the strips so far, in units of 32 (one per unrolled chunk step)
     __device__ __forceinline__ uint64_t strip_instructions() const { return (uint64_t)strip_units << 5; }
 
@@ -138,13 +139,14 @@ struct DevBackend {
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         // Strips top to bottom.  Height by what is left of the band: up to 32 words one K = 1 strip (half a wave for up to 16), up to
-        // 64 words one K = 2 strip, beyond that K = 4 strips of 128 words -- 23 / 17.5 / 14.75 VALU instructions per 2048 cells, and
-        // every strip pays its 64 steps of skew only once (strip_kernel.hpp).
+        // 64 words K = 2, up to 96 words K = 3, beyond that K = 4 strips of 128 words -- 23 / 35 / 47 / 59 VALU instructions per step,
+        // i.e. 23 / 17.5 / 15.7 / 14.75 per 2048 cells of a FULL strip; a strip pays its 64 steps of skew only once (strip_kernel.hpp).
+        // (K = 3 is there for the 65..96-word bands of 100 kbp pairs, which a K = 4 strip would run three quarters empty.)
         int32_t done = 0;
         for (int32_t st = 0; done < words; ++st) {
             mark(6, (uint32_t)st);
             const int32_t left = words - done;
-            const int32_t kk = (left > 64 && !k1_only) ? 4 : ((left > 32 && !k1_only) ? 2 : 1);
+            const int32_t kk = k1_only ? 1 : (left > 96 ? 4 : (left > 64 ? 3 : (left > 32 ? 2 : 1)));
             const int32_t take = left < 32 * kk ? left : 32 * kk;
             const bool last = done + take >= words;
             StripJob j;
@@ -172,13 +174,14 @@ struct DevBackend {
             j.hin_n = 0;
             j.vsum_out = nullptr;
             // (a strip that is not the last one is full, the last one does not need an exact bottom row: NOPASS)
-            if (kk == 4) run_strip<4, false, false, false, true, false, false, true>(j, err);
+            if (kk == 4) run_strip<4, false, false, false, true, true, false, true>(j, err, lds_eq);  // eq words from LDS: 50 instead of 59 per step
+            else if (kk == 3) run_strip<3, false, false, false, true, false, false, true>(j, err);
             else if (kk == 2) run_strip<2, false, false, false, true, false, false, true>(j, err);
             else if (j.nlanes <= 32) run_strip<1, false, false, false, true, false, true, true>(j, err);
             else run_strip<1, false, false, false, true, false, false, true>(j, err);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             // (run_strip: ceil(n / 32) + 2 chunks of 32 steps, one chunk less for the half-wave strip; 11 + 12 K instructions per step)
-            strip_units += (uint32_t)((((i1 - i0 + 31) >> 5) + ((kk == 1 && j.nlanes <= 32) ? 1 : 2)) * (11 + 12 * kk));
+            strip_units += (uint32_t)((((i1 - i0 + 31) >> 5) + ((kk == 1 && j.nlanes <= 32) ? 1 : 2)) * (kk == 4 ? 50 : 11 + 12 * kk));
             done += take;
         }
         return (int32_t)rfl((uint32_t)*(const PA_GLOBAL int32_t*)job.sum);
@@ -254,6 +257,10 @@ struct DevBackend {
 __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_kernel(const PairJob* __restrict__ jobs, const int32_t* __restrict__ order, int npairs,
                                                                     SearchParams sp, uint32_t* ticket, uint32_t* err, uint32_t* dbg, int k1_only) {
     const int lane = (int)(threadIdx.x & 63);
+    // one 4 KB slice per wavefront for the eq words of K = 4 strips, aligned to its size (the strip ORs offsets into the address)
+    __shared__ __attribute__((aligned(4096))) uint32_t apa2_lds_eq[kStripBlockWaves][LdsEq<4>::kWaveBytes / 4];
+    typedef __attribute__((address_space(3))) uint32_t* lds_u32p;
+    const uint32_t lds_eq_off = (uint32_t)(uintptr_t)(lds_u32p)&apa2_lds_eq[rfl((uint32_t)(threadIdx.x >> 6))][0];
     for (;;) {
         // The ticket, WITHOUT a lane-dependent branch: with `if (lane == 0) t = atomicAdd(..)` here and `if (lane == 0) store` at the
         // end of the body, LLVM threads lanes 1..63 from the end of one iteration straight into the next with t = 0 known, so that
@@ -271,6 +278,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_kernel(const Pa
         hp.sh_h = job.sh_h;
         DevBackend be(job, hp, err, dbg);
         be.k1_only = k1_only != 0;
+        be.lds_eq = lds_eq_off;
         be.mark(7, (uint32_t)pair + 1u);
         PairProg<DevBackend> prog(be, hp, sp);
         PairResult res;

@@ -77,16 +77,14 @@ struct DevBackend {
         return r;
     }
     __device__ __forceinline__ void store_rec(int32_t k, const BlockRec& r) const {
-        PA_GLOBAL int32_t* p = (PA_GLOBAL int32_t*)job.rec + (size_t)k * 8;
-        int32_t x = r.js;
-        x = lane == 1 ? r.je : x;
-        x = lane == 2 ? r.ojs : x;
-        x = lane == 3 ? r.oje : x;
-        x = lane == 4 ? r.fs : x;
-        x = lane == 5 ? r.fe : x;
-        x = lane == 6 ? r.top_val : x;
-        x = lane == 7 ? r.bot_val : x;
-        if (lane < 8) p[lane] = x;
+        // every lane stores the same 32 bytes (one write per instruction): no lane-dependent select chain -- that one made the compiler
+        // keep the records in a stack array indexed by the lane, and whatever is loaded from there counts as divergent, which put
+        // the whole band logic on the vector unit
+        typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+        PA_GLOBAL i32x4* p = (PA_GLOBAL i32x4*)((PA_GLOBAL int32_t*)job.rec + (size_t)k * 8);
+        const i32x4 lo = {r.js, r.je, r.ojs, r.oje}, hi = {r.fs, r.fe, r.top_val, r.bot_val};
+        p[0] = lo;
+        p[1] = hi;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the same wavefront reads it back (ordering only)
     }
 

@@ -106,12 +106,16 @@ struct DtLds {
 };
 constexpr int32_t kDtInf = 0x7FFFFFFF;
 
-// The traceback of ONE pair by the calling wavefront (`L`: its LDS slice for the DT-trace, unused when DT is false).  Called by
-// trace_kernel below (one wavefront per pair) and by apa2_kernel.hpp, where the wavefront that ran a pair's band search walks its
-// blocks back right away.
 template <bool DT>
-__device__ __forceinline__ void trace_pair(const TraceJob& tj, DtLds& L, uint32_t* err) {
+// (wavefronts per SIMD asked of the register allocator, measured on C4: the DT variant 13.1 ms without the bound, 9.1 / 9.9 / 13.8 ms
+//  at 5 / 6 / 7; the re-fill variant 12.6 / 12.1 / 13.1 ms at 5 / 6 / 7)
+__global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kernel(const TraceJob* __restrict__ jobs, int npairs, uint32_t* err) {
+    const int pair = (int)rfl((uint32_t)(blockIdx.x * kStripBlockWaves + (threadIdx.x >> 6)));
+    if (pair >= npairs) return;
     const int lane = (int)(threadIdx.x & 63);
+    const TraceJob tj = jobs[pair];
+    extern __shared__ unsigned char pa_trace_lds[];
+    DtLds& L = *reinterpret_cast<DtLds*>(pa_trace_lds + (size_t)(threadIdx.x >> 6) * sizeof(DtLds));
     const gcu8 a = (gcu8)tj.a;
     const gcu8 b = (gcu8)tj.b;
     const gu32 cig = (gu32)tj.cigar;
@@ -601,18 +605,6 @@ __device__ __forceinline__ void trace_pair(const TraceJob& tj, DtLds& L, uint32_
         ts[4] = n_fill_ok;
         ts[5] = n_fill_fb;
     }
-}
-
-template <bool DT>
-// (wavefronts per SIMD asked of the register allocator, measured on C4: the DT variant 13.1 ms without the bound, 9.1 / 9.9 / 13.8 ms
-//  at 5 / 6 / 7; the re-fill variant 12.6 / 12.1 / 13.1 ms at 5 / 6 / 7)
-__global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kernel(const TraceJob* __restrict__ jobs, int npairs, uint32_t* err) {
-    const int pair = (int)rfl((uint32_t)(blockIdx.x * kStripBlockWaves + (threadIdx.x >> 6)));
-    if (pair >= npairs) return;
-    const TraceJob tj = jobs[pair];
-    extern __shared__ unsigned char pa_trace_lds[];
-    DtLds& L = *reinterpret_cast<DtLds*>(pa_trace_lds + (size_t)(threadIdx.x >> 6) * sizeof(DtLds));
-    trace_pair<DT>(tj, L, err);
 }
 
 }  // namespace pa

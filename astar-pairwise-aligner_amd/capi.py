@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "pa_pairs_read", "pa_pairs_count", "pa_pairs_get", "pa_pairs_free", "pa_write_results_csv", "pa_align_file",
     "pa_align", "pa_batch_align_multi", "pa_batch_create_trace_params",
     "pa_bp_ctx_create", "pa_bp_ctx_compute", "pa_bp_ctx_fill", "pa_bp_ctx_destroy",
-    "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools", "pa_align_file_params",
+    "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools", "pa_align_file_params", "pa_batch_params_supported",
 ]
 
 _lib = None

@@ -1562,6 +1562,11 @@ extern "C" pa_batch* pa_batch_create_trace_params(const uint8_t* const* a, const
     return batch_create(a, a_len, b, b_len, pairs, true, -1.f, tp.front.dt_trace ? (int)tp.front.max_g : 0, tp.front.dt_trace ? (int)tp.front.fr_drop : 0);
 }
 
+// 1 if pa_batch_create_params takes these parameters, 0 if they belong to pa_align (or are invalid).
+extern "C" int pa_batch_params_supported(const pa_astarpa2_params* params) {
+    return params && engine::params_valid(*params) && apa2_supported(engine::params_from_c(*params)) ? 1 : 0;
+}
+
 // A*PA2 for many pairs (the `simple` preset and its relatives): what a loop over pa_align(a, b, params, trace = 1) returns --
 // cost, CIGAR and statistics -- with every pair's whole band search run by one wavefront on the GPU.
 extern "C" pa_batch* pa_batch_create_params(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len,

@@ -322,10 +322,7 @@ extern "C" int pa_align_file_params(const char* input_path, const char* output_p
     std::vector<char*> cigars(n, nullptr);
     int rc = 0;
     if (n) {
-        // does the batched program take these parameters?  (a probe batch of one pair; NULL = no)
-        pa_batch* probe = pa_batch_create_params(ap.data(), al.data(), bp.data(), bl.data(), 1, params);
-        if (probe) {
-            pa_batch_destroy(probe);
+        if (pa_batch_params_supported(params)) {
             int dev = 0;
             (void)hipGetDevice(&dev);
             rc = batch_align_queue(ap.data(), al.data(), bp.data(), bl.data(), n, &dev, 1, costs.data(), cigars.data(), params, nullptr);
@@ -346,8 +343,8 @@ extern "C" int pa_batch_align_multi(const uint8_t* const* a, const size_t* a_len
 extern "C" int pa_batch_align_multi_params(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len,
                                            size_t pairs, const int* devices, int ndevices, const pa_astarpa2_params* params, int32_t* cost_out,
                                            char** cigar_out, pa_astarpa2_stats* stats_out) {
-    if (!params) {
-        pa::set_error("pa_batch_align_multi_params: params is NULL");
+    if (!params || !pa_batch_params_supported(params)) {
+        pa::set_error("pa_batch_align_multi_params: parameters outside the batched A*PA2 family (see pa_batch_create_params); use pa_align");
         return PA_E_ARG;
     }
     return batch_align_queue(a, a_len, b, b_len, pairs, devices, ndevices, cost_out, cigar_out, params, stats_out);

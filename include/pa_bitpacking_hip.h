@@ -154,6 +154,7 @@ struct pa_astarpa2_stats;
 pa_batch* pa_batch_create_params(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len,
                                  size_t pairs, const struct pa_astarpa2_params* params);
 int pa_batch_pair_stats(const pa_batch* plan, struct pa_astarpa2_stats* stats_out);
+int pa_batch_params_supported(const struct pa_astarpa2_params* params); /* 1: pa_batch_create_params takes them; 0: use pa_align */
 
 /* Many-pair mode over several GPUs from ONE process (independent pairs shard with no data-path exchange; the
  * reference runs them one after another, pa-bin/src/main.rs:24-35): a WORK QUEUE.  The pairs are sorted by estimated work

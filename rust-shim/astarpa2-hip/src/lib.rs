@@ -87,6 +87,7 @@ extern "C" {
     pub fn pa_batch_create_params(a: *const *const u8, a_len: *const usize, b: *const *const u8, b_len: *const usize, pairs: usize,
                                   params: *const PaAstarPa2Params) -> *mut core::ffi::c_void;
     pub fn pa_batch_pair_stats(plan: *const core::ffi::c_void, stats_out: *mut PaAstarPa2Stats) -> i32;
+    pub fn pa_batch_params_supported(params: *const PaAstarPa2Params) -> i32;
     pub fn pa_batch_align_multi_params(a: *const *const u8, a_len: *const usize, b: *const *const u8, b_len: *const usize, pairs: usize,
                                        devices: *const i32, ndevices: i32, params: *const PaAstarPa2Params, cost_out: *mut i32,
                                        cigar_out: *mut *mut c_char, stats_out: *mut PaAstarPa2Stats) -> i32;

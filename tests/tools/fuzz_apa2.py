@@ -40,6 +40,13 @@ while time.time() - t0 < budget:
             b = rand_seq(rng.randint(1, n + 50), s + 2)
         elif mode < 0.37:
             a, b = rng.choice([(b"", b), (a, b""), (b"", b"")])
+        elif mode < 0.45:  # low complexity: runs of one letter, b = a behind a foreign head
+            runs = []
+            while sum(len(r) for r in runs) < n:
+                runs.append(bytes([rng.choice(b"ACGT")]) * rng.randint(1, 700))
+            a = b"".join(runs)[:n]
+            b = bytes([rng.choice(b"ACGT")]) * rng.randint(0, 900) + a[rng.randint(0, min(n, 300)):]
+            b = b or b"A"
         pairs.append((a, b))
     bt = pa.Batch(pairs, params=gpu_params(pa, vs[name]))
     costs, cigars, _, _ = bt.align()

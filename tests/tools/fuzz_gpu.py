@@ -31,12 +31,25 @@ while time.time() - t0 < budget:
     npairs = int(rng.integers(1, 40))
     pairs = []
     for _ in range(npairs):
-        kind = rng.integers(0, 5)
+        kind = rng.integers(0, 6)
         n = int(rng.choice([rng.integers(0, 70), rng.integers(0, 3000), rng.integers(2000, 2048 * k + 3000)]))
         if kind <= 2:
             pairs.append(gen_pair(n, float(rng.choice([0.0, 0.02, 0.1, 0.3])), seed=int(rng.integers(1 << 30))))
         elif kind == 3:
             pairs.append((rand_seq(n, seed=int(rng.integers(1 << 30))), rand_seq(int(rng.integers(0, 4000)), seed=int(rng.integers(1 << 30)))))
+        elif kind == 5:
+            # low complexity: runs of one letter (the first rows of b may not hold a[0] at all: the first-column case that random
+            # sequences hide), b = a with a different head and a few edits
+            runs, letters = [], b"ACGT"
+            while sum(len(r) for r in runs) < max(n, 1):
+                runs.append(bytes([letters[int(rng.integers(0, 4))]]) * int(rng.integers(1, 700)))
+            a = b"".join(runs)[:max(n, 1)]
+            head = bytes([letters[int(rng.integers(0, 4))]]) * int(rng.integers(0, 900))
+            bb = bytearray(head + a[int(rng.integers(0, min(len(a), 300) + 1)):])
+            for _ in range(int(rng.integers(0, 20))):
+                if bb:
+                    bb[int(rng.integers(0, len(bb)))] = letters[int(rng.integers(0, 4))]
+            pairs.append((a, bytes(bb)))
         else:
             a = rand_seq(n, seed=int(rng.integers(1 << 30)))
             cut = int(rng.integers(0, n + 1))

@@ -150,9 +150,9 @@ __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin
 // extracts) to the LDS port, which issues beside the VALU: 107 -> 89 VALU instructions per K = 8 step.
 template <int K>
 struct LdsEq {
-    static constexpr int kCodeShift = K >= 16 ? 12 : (K >= 8 ? 11 : 10);  // one code's eq words of all 64 lanes: 64 * 4K bytes
+    static constexpr int kCodeShift = K > 8 ? 12 : (K > 4 ? 11 : 10);  // one code's eq words of all 64 lanes: 64 * 4K bytes, rounded up to a power of two
     static constexpr uint32_t kCodeMask = 3u << kCodeShift;
-    static constexpr uint32_t kWaveBytes = 4u * 64u * 4u * (uint32_t)K;
+    static constexpr uint32_t kWaveBytes = 4u << kCodeShift;
 };
 typedef uint32_t pa_u32x4 __attribute__((ext_vector_type(4)));
 typedef pa_u32x4 __attribute__((address_space(3))) pa_lds_u32x4;

@@ -140,6 +140,20 @@ def _buf(b: bytes):
     return C.cast(C.c_char_p(b), C.c_void_p)
 
 
+def _marshal_pairs(pairs):
+    """(a pointers, a lengths, b pointers, b lengths) for the `const uint8_t* const*` / `const size_t*` arguments.  c_char_p arrays
+    point straight into the bytes objects (the caller keeps `pairs` alive); building them is 40x cheaper than one ctypes cast per
+    sequence, which used to cost more than the GPU work of a 10 000-pair batch."""
+    n = len(pairs)
+    if any(not isinstance(a, bytes) or not isinstance(b, bytes) for a, b in pairs):
+        raise ValueError("pairs must be (bytes, bytes) tuples")
+    ap = (C.c_char_p * max(n, 1))(*[a for a, _ in pairs])
+    bp = (C.c_char_p * max(n, 1))(*[b for _, b in pairs])
+    al = np.fromiter((len(a) for a, _ in pairs), dtype=np.uint64, count=n) if n else np.zeros(1, np.uint64)
+    bl = np.fromiter((len(b) for _, b in pairs), dtype=np.uint64, count=n) if n else np.zeros(1, np.uint64)
+    return ap, _p(al), bp, _p(bl)
+
+
 def require_gpu() -> None:
     if load().pa_device_count() <= 0:
         raise PaError("no MI355X visible: the HIP path is required (no CPU fallback)")
@@ -296,12 +310,7 @@ def align_multi(pairs: list[tuple[bytes, bytes]], devices: list[int], trace: boo
     n = len(pairs)
     if not devices or any(not isinstance(d, int) for d in devices):
         raise ValueError("devices must be a non-empty list of device indices")
-    if any(not isinstance(a, bytes) or not isinstance(b, bytes) for a, b in pairs):
-        raise ValueError("pairs must be (bytes, bytes) tuples")
-    ap = (C.c_void_p * n)(*[C.cast(C.c_char_p(a), C.c_void_p) for a, _ in pairs])
-    bp = (C.c_void_p * n)(*[C.cast(C.c_char_p(b), C.c_void_p) for _, b in pairs])
-    al = (C.c_size_t * n)(*[len(a) for a, _ in pairs])
-    bl = (C.c_size_t * n)(*[len(b) for _, b in pairs])
+    ap, al, bp, bl = _marshal_pairs(pairs)
     dev = (C.c_int * len(devices))(*devices)
     out = np.zeros(n, np.int32)
     cig = (C.c_void_p * n)() if trace else None
@@ -345,10 +354,7 @@ class Batch:
         self._keep = pairs
         self.trace = trace
         n = len(pairs)
-        ap = (C.c_void_p * n)(*[C.cast(C.c_char_p(a), C.c_void_p) for a, _ in pairs])
-        bp = (C.c_void_p * n)(*[C.cast(C.c_char_p(b), C.c_void_p) for _, b in pairs])
-        al = (C.c_size_t * n)(*[len(a) for a, _ in pairs])
-        bl = (C.c_size_t * n)(*[len(b) for _, b in pairs])
+        ap, al, bp, bl = _marshal_pairs(pairs)
         self.astar = params is not None
         if band is not None and trace:
             raise ValueError("banded batches are cost-only")

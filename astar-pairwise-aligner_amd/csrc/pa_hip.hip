@@ -1803,11 +1803,64 @@ extern "C" void pa_params_batch_align(pa_astarpa2_params* out) {
     if (out) *out = traced_batch_params();
 }
 
+// A batched A*PA2 of a handful of LONG pairs is one lone wavefront per pair for the whole band search (about 50 ms for 100 kbp at 5 %),
+// while the single-pair engine spreads one pair's pass over many wavefronts (14.4 ms; two pairs 29 vs 47 ms, three 44 vs 48): up to kSmallRoutePairs pairs of at least
+// kSmallRouteLen bases go through that engine one after another.  Same parameter set, same host logic: cost, CIGAR string and statistics
+// are the ones the batch kernels produce (tests/test_gpu_apa2_batch.py compares both routes).  PA_BATCH_SMALL_ROUTE=0 switches it off.
+static constexpr size_t kSmallRoutePairs = 2, kSmallRouteLen = 32768;
+
+static bool small_route(const pa_batch* p, const char* const* cigar_out) {
+    static const char* env = getenv("PA_BATCH_SMALL_ROUTE");
+    if (env && env[0] == '0') return false;
+    if (!p->astar || !cigar_out || p->pairs == 0 || p->pairs > kSmallRoutePairs) return false;
+    for (size_t i = 0; i < p->pairs; ++i)
+        if (std::min(p->n[i], p->m[i]) < kSmallRouteLen) return false;
+    return true;
+}
+
+static int batch_align_small(pa_batch* p, int32_t* cost_out, char** cigar_out, float* forward_ms, float* trace_ms) {
+    const size_t P = p->pairs;
+    const auto t0 = std::chrono::steady_clock::now();
+    p->pair_stats.assign(P, pa_astarpa2_stats{});
+    p->apa2_strip_instr = 0;
+    for (size_t i = 0; i < P; ++i) cigar_out[i] = nullptr;
+    auto fail_out = [&](int code) {
+        for (size_t k = 0; k < P; ++k) {
+            std::free(cigar_out[k]);
+            cigar_out[k] = nullptr;
+        }
+        return code;
+    };
+    // one after another: two sweeps of long pairs at once get in each other's way (measured: 2 pairs 69 ms side by side, 29 ms in a row)
+    for (size_t i = 0; i < P; ++i) {
+        std::vector<uint8_t> ba(p->n[i]), bb(p->m[i]);
+        if (!hip_ok(hipMemcpy(ba.data(), p->d_a.as<uint8_t>() + p->a_off[i], p->n[i], hipMemcpyDeviceToHost), "D2H a") ||
+            !hip_ok(hipMemcpy(bb.data(), p->d_b.as<uint8_t>() + p->b_off[i], p->m[i], hipMemcpyDeviceToHost), "D2H b"))
+            return fail_out(PA_E_HIP);
+        std::string text;
+        int32_t c = 0;
+        int rc = align_hip(ba.data(), p->n[i], bb.data(), p->m[i], p->aparams_c, true, false, &c, &text, &p->pair_stats[i]);
+        if (rc == PA_E_TIMEOUT) rc = align_hip(ba.data(), p->n[i], bb.data(), p->m[i], p->aparams_c, true, false, &c, &text, &p->pair_stats[i]);
+        if (rc != 0) return fail_out(rc);
+        cost_out[i] = c;
+        cigar_out[i] = (char*)std::malloc(text.size() + 1);
+        if (!cigar_out[i]) {
+            set_error("out of memory");
+            return fail_out(PA_E_NOMEM);
+        }
+        std::memcpy(cigar_out[i], text.c_str(), text.size() + 1);
+    }
+    if (forward_ms) *forward_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (trace_ms) *trace_ms = 0.f;  // (the engine's traceback is inside the figure above)
+    return 0;
+}
+
 extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, float* forward_ms, float* trace_ms) {
     if (!p || !p->trace) {
         set_error("pa_batch_align needs a batch made by pa_batch_create_trace");
         return PA_E_ARG;
     }
+    if (small_route(p, cigar_out)) return batch_align_small(p, cost_out, cigar_out, forward_ms, trace_ms);
     hipStream_t s = p->stream;
     const size_t P = p->pairs;
     static const bool prof = getenv("PA_ALIGN_PROFILE") != nullptr;

@@ -149,7 +149,9 @@ size_t pa_batch_trace_fallbacks(const pa_batch* plan);
  * kernels hand back (an empty sequence, a re-fill taller than 8192 rows, a state the reference would panic on) is redone by
  * pa_align's engine transparently.  pa_batch_pair_stats: the statistics of every pair of the last pa_batch_align (timers 0).
  * pa_batch_run() on such a batch (or pa_batch_align with cigar_out == NULL) runs the band search without the traceback: the
- * costs alone -- the distances, over the band of the traced mode as pa_align(trace = 0) returns them (pa_astarpa2.h). */
+ * costs alone -- the distances, over the band of the traced mode as pa_align(trace = 0) returns them (pa_astarpa2.h).
+ * A batch of one or two pairs of >= 32 768 bases each is aligned by pa_align's engine instead (many wavefronts per pass: 14 ms
+ * against 47 ms for a 100 kbp pair; same results, forward_ms then covers the whole alignment); PA_BATCH_SMALL_ROUTE=0 disables. */
 struct pa_astarpa2_stats;
 pa_batch* pa_batch_create_params(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len,
                                  size_t pairs, const struct pa_astarpa2_params* params);

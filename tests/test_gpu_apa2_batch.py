@@ -152,3 +152,20 @@ def test_unsupported_parameters_are_refused(pa, oracle):
     for oc in (oracle.params_full(), oracle.params_nw()):
         with pytest.raises(pa.PaError):
             pa.Batch([gen_pair(500, 0.1, 1)], params=gpu_params(pa, oc))
+
+
+def test_few_long_pairs_take_the_single_pair_engine_and_agree_with_the_kernel_route(pa, oracle):
+    """One or two pairs of >= 32 768 bases go through the single-pair engine (many wavefronts per pass) instead of one lone
+    wavefront per pair; a third pair sends the same sequences through the batch kernels.  Both must give the CPU-kernel engine's
+    cost, CIGAR string and statistics."""
+    oc = oracle.params_simple()
+    long_pairs = [gen_pair(40_000, 0.04, seed=91), gen_pair(33_000, 0.11, seed=92), (rand_seq(36_000, 5), rand_seq(34_000, 6))]
+    c1, g1, ms1, _ = check(pa, oracle, long_pairs[:1], oc, fallbacks=0)
+    c2, g2, _, _ = check(pa, oracle, long_pairs[1:], oc, fallbacks=0)
+    c4, g4, _, _ = check(pa, oracle, long_pairs + [gen_pair(3000, 0.1, seed=93)], oc, fallbacks=0)
+    assert list(c2) == list(c4[1:3]) and g2 == g4[1:3] and c1[0] == c4[0] and g1[0] == g4[0]
+    from tests.test_gpu_engine import gpu_params
+
+    short = pa.Batch(long_pairs[:1] + [gen_pair(20_000, 0.05, seed=94)], params=gpu_params(pa, oc))  # one short pair: kernel route
+    short.align()
+    short.close()

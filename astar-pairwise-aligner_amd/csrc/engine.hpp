@@ -1242,7 +1242,9 @@ AlignResult cost_or_align(const AstarPa2Params& params, Backend& be, bool trace,
                                 },
                                 f, &nw.stats.sanity_violations);
             }
-            nw.stats.block_stats = blocks.stats;
+            // Only the BandDoubling arm hands the Blocks' own counters to the caller (lib.rs:158); after a LinearSearch the
+            // reference's block statistics stay at their defaults (lib.rs:132-140).  Found by oracle/astarpa2_restated.py.
+            if (params.doubling == DoublingKind::BandDoubling) nw.stats.block_stats = blocks.stats;
             break;
         }
     }

@@ -1922,10 +1922,12 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
         for (size_t i = 0; i < P; ++i) {
             pa_astarpa2_stats& st = p->pair_stats[i];
             const apa2::PairResult& r = results[i];
-            st.num_blocks = r.num_blocks;
-            st.num_incremental_blocks = r.num_incremental_blocks;
-            st.computed_lanes = r.computed_lanes;
-            st.unique_lanes = r.unique_lanes;
+            if (p->sp.doubling == apa2::kDoublingBand) {  // (the reference reports block counters after a band doubling only, lib.rs:158)
+                st.num_blocks = r.num_blocks;
+                st.num_incremental_blocks = r.num_incremental_blocks;
+                st.computed_lanes = r.computed_lanes;
+                st.unique_lanes = r.unique_lanes;
+            }
             st.f_max_tries = r.f_max_tries;
             st.sanity_violations = r.sanity_violations;
             p->apa2_strip_instr += (double)r.strip_instr;

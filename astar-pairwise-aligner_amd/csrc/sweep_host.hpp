@@ -392,6 +392,7 @@ class SweepAligner {
         out.has_cigar = r.second.has_value();
         if (r.second) out.cigar = std::move(*r.second);
         out.stats = stats;
+        if (params.doubling != DoublingKind::BandDoubling) out.stats.block_stats = BlockStats{};  // lib.rs:132-140 against 158
         return out;
     }
 };

@@ -48,6 +48,8 @@ typedef struct pa_astarpa2_params { /* AstarPa2Params, params.rs:8-42 */
 } pa_astarpa2_params;
 
 typedef struct pa_astarpa2_stats { /* AstarPa2Stats + BlockStats + TraceStats */
+    /* The four block counters are reported after a band doubling only: the reference copies them into its result in that arm of
+     * cost_or_align alone (astarpa2/src/lib.rs:158), so doubling = none (the nw preset) and the linear search return zeros here. */
     uint64_t num_blocks, num_incremental_blocks, computed_lanes, unique_lanes;
     uint64_t dt_trace_tries, dt_trace_success, dt_trace_fallback, fill_tries, fill_success, fill_fallback;
     uint64_t f_max_tries;

@@ -143,10 +143,12 @@ extern "C" int pa_apa2_emu_align(const uint8_t* a, size_t a_len, const uint8_t* 
     }
     if (res.status != kOk) return 2;
     AstarPa2Stats st;
-    st.block_stats.num_blocks = res.num_blocks;
-    st.block_stats.num_incremental_blocks = res.num_incremental_blocks;
-    st.block_stats.computed_lanes = res.computed_lanes;
-    st.block_stats.unique_lanes = res.unique_lanes;
+    if (sp.doubling == kDoublingBand) {  // lib.rs:158: the other arms of cost_or_align leave the block counters at zero
+        st.block_stats.num_blocks = res.num_blocks;
+        st.block_stats.num_incremental_blocks = res.num_incremental_blocks;
+        st.block_stats.computed_lanes = res.computed_lanes;
+        st.block_stats.unique_lanes = res.unique_lanes;
+    }
     st.f_max_tries = res.f_max_tries;
     st.sanity_violations = res.sanity_violations;
     std::string cig;

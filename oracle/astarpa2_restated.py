@@ -1,0 +1,643 @@
+"""oracle/astarpa2_restated.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A second, independent restatement of the reference's TRACED A*PA2 path for the `simple` family of parameter sets (Domain::Astar with
+the NoCost / GapCost / SH heuristic, band doubling from h0, sparse blocks, no incremental doubling, DT-trace on or off), written from
+the Rust text alone and sharing nothing with csrc/engine.hpp (the product's host logic, which oracle/engine_cpu.cpp instantiates over
+the CPU kernels) nor with any kernel of this repository: the DP of a block runs on Python big integers.
+
+    astarpa2/src/lib.rs:122-175          cost_or_align                      band.rs:11-24, 100-141   initial_values, exponential_search
+    astarpa2/src/domain.rs:90-246        j_range (Domain::Astar)            domain.rs:251-350        fixed_j_range
+    astarpa2/src/domain.rs:356-541       align_for_bounded_dist             ranges.rs:49-80          JRange rounding / union
+    astarpa2/src/block.rs:35-140         Block::default / first_col / index / get / get_diff
+    astarpa2/src/blocks.rs:146-199       Blocks::init / pop_last_block / reuse_next_block
+    astarpa2/src/blocks.rs:205-339       compute_next_block (the sparse traced arm without incremental doubling)
+    astarpa2/src/blocks.rs:545-660       last_block / next_block_j_range / set_last_block_fixed_j_range / fill_with_blocks
+    astarpa2/src/blocks.rs:686-769       compute_block (statistics, HMode::None) / init_v_with_overlap
+    astarpa2/src/blocks/trace.rs:16-143  Blocks::trace       trace.rs:145-228  parent       trace.rs:231-418  dt_trace_block
+    astarpa2/src/blocks/trace.rs:445-500 extend_left / extend_left_simd (the word-at-a-time loop only changes HOW the run is counted)
+    pa-bitpacking/src/myers.rs:27-55     compute_block (one Myers step; here on one integer as tall as the block)
+    pa-bitpacking/src/scalar.rs:405-425  fill (every column of a block kept)
+    pa-heuristic: GapCost h = |(n - i) - (m - j)|; SH with exact matches (sh.rs:47-106, matches/exact.rs, qgrams.rs:30-43)
+
+Purpose: the CIGAR strings and the twelve statistics of the `simple` family used to be pinned only by the reference's acceptance rules
+(cost = distance, CIGAR valid) plus engine.hpp agreeing with itself over two kernel back ends.  Two restatements that were written
+separately and agree on every field for thousands of random pairs (tests/test_restated_engine.py) leave a mis-reading of the Rust
+text as the only common failure, and that is what `parity: rule-pinned, twice restated` means in DESIGN.md 4.  The Rust binary
+itself cannot be built here (no toolchain), so this is still not a reference-generated pin.
+"""
+from __future__ import annotations
+
+import math
+import struct
+
+W = 64
+I_MAX = 2**31 - 1
+ONE = ((1 << W) - 1, 0)  # V::one(): every vertical difference +1
+
+
+def _f32(x: float) -> float:
+    return struct.unpack("f", struct.pack("f", x))[0]
+
+
+def _pc(x: int) -> int:
+    return bin(x).count("1")
+
+
+def _round_out(r):  # ranges.rs:71-73
+    return (r[0] // W * W, -(-r[1] // W) * W)
+
+
+def _union(x, y):
+    return (min(x[0], y[0]), max(x[1], y[1]))
+
+
+def _empty(r):
+    return r[0] > r[1]
+
+
+def sh_table(a: bytes, b: bytes, k: int):
+    """h(i) = number of seeds of a starting at >= i that have no exact match anywhere in b (seeds: consecutive k-mers from 0)."""
+    n = len(a)
+    bk = {b[j:j + k] for j in range(0, len(b) - k + 1)} if len(b) >= k else set()
+    nseeds = n // k
+    matched = [a[s * k:(s + 1) * k] in bk for s in range(nseeds)]
+    h = [0] * (n + 1)
+    unmatched, nxt = 0, nseeds - 1
+    for i in range(n, -1, -1):
+        if nxt >= 0 and i == nxt * k:
+            if not matched[nxt]:
+                unmatched += 1
+            nxt -= 1
+        h[i] = unmatched
+    return h
+
+
+class Block:
+    __slots__ = ("v", "i_range", "orig", "j_range", "fixed", "offset", "top", "bot")
+
+    def __init__(self):  # block.rs:35-49
+        self.v = []
+        self.i_range = (-1, 0)
+        self.orig = (-W, -W)
+        self.j_range = (-W, -W)
+        self.fixed = None
+        self.offset = 0
+        self.top = I_MAX
+        self.bot = I_MAX
+
+    def copy(self):
+        o = Block()
+        o.v, o.i_range, o.orig, o.j_range, o.fixed, o.offset, o.top, o.bot = list(self.v), self.i_range, self.orig, self.j_range, self.fixed, self.offset, self.top, self.bot
+        return o
+
+    def index(self, j):  # block.rs:69-121
+        js, je = self.j_range
+        assert js <= j, f"Cannot index block {self.i_range} with range {self.j_range} by {j}"
+        assert js - self.offset >= 0 and je - self.offset <= len(self.v) * W
+        if j > je:
+            return self.bot + (j - je)
+        v, off = self.v, self.offset
+        if j - js < je - j:
+            val, j0 = self.top, js
+            while j0 + W <= j:
+                p, m = v[(j0 - off) // W]
+                val += _pc(p) - _pc(m)
+                j0 += W
+            p, m = v[(j0 - off) // W]
+            mask = (1 << (j - j0)) - 1
+            return val + _pc(p & mask) - _pc(m & mask)
+        val, j1 = self.bot, je
+        while j1 - W > j:
+            p, m = v[(j1 - W - off) // W]
+            val -= _pc(p) - _pc(m)
+            j1 -= W
+        if j1 > j:
+            p, m = v[(j1 - W - off) // W]
+            mask = ((1 << W) - 1) ^ ((1 << (W - (j1 - j))) - 1)
+            val -= _pc(p & mask) - _pc(m & mask)
+        return val
+
+    def get(self, j):  # block.rs:125-130
+        if j < self.j_range[0] or j > self.j_range[1]:
+            return None
+        return self.index(j)
+
+    def get_diff(self, j):  # block.rs:133-144
+        if j < self.offset:
+            return None
+        idx = (j - self.offset) // W
+        if idx >= len(self.v):
+            return None
+        bit = (j - self.offset) % W
+        p, m = self.v[idx]
+        return ((p >> bit) & 1) - ((m >> bit) & 1)
+
+
+class Restated:
+    def __init__(self, a: bytes, b: bytes, heuristic: str = "gap", k: int = 12, sparse_h: bool = True, block_width: int = 256,
+                 dt_trace: bool = True, max_g: int = 40, fr_drop: int = 10, domain: str = "astar", sparse: bool = True,
+                 doubling: str = "band", start: str = "h0", factor: float = 2.0, delta: float = 1.0):
+        assert all(c in b"ACGT" for c in a) and all(c in b"ACGT" for c in b)
+        assert domain in ("astar", "full", "gap_start", "gap_gap") and doubling in ("band", "linear", "none") and start in ("zero", "gap", "h0")
+        self.a, self.b, self.n, self.m = a, b, len(a), len(b)
+        self.domain, self.sparse, self.doubling, self.start, self.factor, self.delta = domain, sparse, doubling, start, factor, delta
+        self.kind, self.sparse_h, self.bw = (heuristic if domain == "astar" else "none"), sparse_h, block_width
+        self.dt, self.max_g, self.fr_drop = dt_trace, max_g, fr_drop
+        self.sh = sh_table(a, b, k) if self.kind == "sh" else None
+        self.peq = {c: sum(1 << j for j in range(self.m) if b[j] == c) for c in set(a)}  # rows >= m never match (profile.rs:127-132)
+        # Blocks (blocks.rs:87-107)
+        self.blocks: list[Block] = []
+        self.last = 0
+        self.i_range = (-1, 0)
+        self.st = dict(num_blocks=0, num_incremental_blocks=0, computed_lanes=0, unique_lanes=0, f_max_tries=0, dt_trace_tries=0,
+                       dt_trace_success=0, dt_trace_fallback=0, fill_tries=0, fill_success=0, fill_fallback=0)
+
+    # ---- the heuristic ----
+    def h(self, i, j):
+        if self.kind == "gap":
+            return abs((self.n - i) - (self.m - j))
+        if self.kind == "sh":
+            return self.sh[i]
+        return 0
+
+    # ---- one Myers step per column on an integer `rows` bits tall (myers.rs:27-55; horizontal input +1 at the top row) ----
+    def _columns(self, i0, i1, w0, vwords, keep):
+        rows = len(vwords) * W
+        full = (1 << rows) - 1
+        vp = sum(p << (W * t) for t, (p, _) in enumerate(vwords))
+        vm = sum(m << (W * t) for t, (_, m) in enumerate(vwords))
+        topbit = 1 << (rows - 1)
+        m64 = (1 << W) - 1
+        hsum, cols, hvals = 0, [], []
+        for i in range(i0, i1):
+            eq = (self.peq.get(self.a[i], 0) >> (w0 * W)) & full
+            xv = eq | vm
+            xh = ((((eq & vp) + vp) & full) ^ vp) | eq
+            ph = vm | (full & ~(xh | vp))
+            mh = vp & xh
+            hout = (1 if ph & topbit else 0) - (1 if mh & topbit else 0)
+            hsum += hout
+            ph = ((ph << 1) | 1) & full
+            mh = (mh << 1) & full
+            vp = mh | (full & ~(xv | ph))
+            vm = ph & xv
+            if keep:
+                cols.append([((vp >> (W * t)) & m64, (vm >> (W * t)) & m64) for t in range(len(vwords))])
+                hvals.append(hout)
+        out = [((vp >> (W * t)) & m64, (vm >> (W * t)) & m64) for t in range(len(vwords))]
+        return hsum, out, cols, hvals
+
+    def compute_block(self, i_range, v_range, v):  # blocks.rs:686-748, HMode::None; returns the bottom row's sum, updates v
+        if i_range[1] - i_range[0] > 1:
+            self.st["computed_lanes"] += v_range[1] - v_range[0]
+            self.st["num_incremental_blocks"] += 1
+        if v_range[1] == v_range[0]:
+            return i_range[1] - i_range[0]  # (no words: the sum of the +1 inputs)
+        hsum, out, _, _ = self._columns(i_range[0], i_range[1], v_range[0], v, False)
+        v[:] = out
+        return hsum
+
+    # ---- Blocks ----
+    def last_block(self):
+        return self.blocks[self.last]
+
+    def next_block_j_range(self):  # blocks.rs:549-551
+        return self.blocks[self.last + 1].j_range if self.last + 1 < len(self.blocks) else None
+
+    def set_last_block_fixed_j_range(self, fixed):  # blocks.rs:554-568
+        bl = self.blocks[self.last]
+        bl.fixed = _union(bl.fixed, fixed) if (bl.fixed is not None and fixed is not None) else fixed
+
+    def init(self, initial):  # blocks.rs:146-179, trace mode
+        assert initial[0] == 0
+        self.last = 0
+        self.i_range = (-1, 0)
+        fixed = initial
+        if self.blocks:
+            initial = _union(initial, self.blocks[0].j_range)
+        initial = _round_out(initial)
+        bl = Block()  # Block::first_col (block.rs:53-66)
+        assert initial[0] == 0
+        bl.v = [ONE] * ((initial[1] - initial[0]) // W)
+        bl.i_range, bl.orig, bl.j_range, bl.fixed, bl.offset, bl.top, bl.bot = (-1, 0), fixed, initial, fixed, 0, 0, initial[1] - initial[0]
+        if not self.blocks:
+            self.blocks.append(bl)
+        else:
+            self.blocks[0] = bl
+
+    def pop_last_block(self):  # blocks.rs:182-185
+        r = self.blocks[self.last].i_range
+        assert self.i_range[1] == r[1]
+        self.i_range = (self.i_range[0], r[0])
+        self.last -= 1
+
+    def _push_i(self, r):
+        assert self.i_range[1] == r[0]
+        self.i_range = (self.i_range[0], r[1])
+
+    def reuse_next_block(self, i_range, j_range):  # blocks.rs:190-197
+        self._push_i(i_range)
+        self.last += 1
+        bl = self.blocks[self.last]
+        assert bl.i_range == i_range and bl.j_range == _round_out(j_range)
+
+    @staticmethod
+    def init_v_with_overlap(prev: Block, nxt: Block):  # blocks.rs:753-769
+        assert nxt.offset == nxt.j_range[0] and prev.offset == prev.j_range[0]
+        pv0 = prev.j_range[0] // W
+        v0, v1 = nxt.j_range[0] // W, nxt.j_range[1] // W
+        nxt.v = [ONE] * (v1 - v0)
+        o0, o1 = max(nxt.j_range[0], prev.j_range[0]) // W, min(nxt.j_range[1], prev.j_range[1]) // W
+        assert o0 <= o1, "ranges of consecutive blocks overlap"
+        nxt.v[o0 - v0:o1 - v0] = prev.v[o0 - pv0:o1 - pv0]
+
+    def compute_next_block(self, i_range, j_range):  # blocks.rs:205-339 (trace && sparse && !incremental_doubling)
+        self.st["num_blocks"] += 1
+        orig = j_range
+        jr = _round_out(j_range)
+        v_range = (jr[0] // W, jr[1] // W)
+        self.st["unique_lanes"] += v_range[1] - v_range[0]
+        if self.last + 1 < len(self.blocks):
+            old = self.blocks[self.last + 1].j_range
+            assert jr[0] <= old[0] and old[1] <= jr[1], "j_range must grow"
+            self.st["unique_lanes"] -= (old[1] - old[0]) // W
+        if not self.sparse:  # trace && !sparse: every column of the block is kept (blocks.rs:231-240)
+            self.fill_with_blocks(i_range, orig)
+            return
+        self._push_i(i_range)
+        prev_top = self.last_block().index(jr[0])
+        prev_bot = self.last_block().index(jr[1])
+        if self.last + 1 == len(self.blocks):
+            self.blocks.append(Block())
+        else:
+            assert self.blocks[self.last + 1].i_range == i_range
+        prev, nxt = self.blocks[self.last], self.blocks[self.last + 1]
+        self.last += 1
+        # the block is overwritten in place: its v memory and -- note -- its fixed_j_range survive (blocks.rs:303-316)
+        nxt.i_range, nxt.orig, nxt.j_range, nxt.offset = i_range, orig, jr, jr[0]
+        nxt.top = prev_top + (i_range[1] - i_range[0])
+        nxt.bot = prev_bot
+        self.init_v_with_overlap(prev, nxt)
+        nxt.bot += self.compute_block(i_range, v_range, nxt.v)
+
+    def fill_with_blocks(self, i_range, original_j_range):  # blocks.rs:571-660
+        jr = _round_out(original_j_range)
+        self._push_i(i_range)
+        v_range = (jr[0] // W, jr[1] // W)
+        prev = self.blocks[self.last]
+        assert prev.i_range[1] == i_range[0]
+        nb = Block()
+        nb.i_range, nb.orig, nb.j_range, nb.offset, nb.fixed = (i_range[0], i_range[0]), original_j_range, jr, jr[0], None
+        nb.top, nb.bot = prev.index(jr[0]), 0
+        self.init_v_with_overlap(prev, nb)
+        bot = prev.index(jr[1])
+        _, _, cols, hvals = self._columns(i_range[0], i_range[1], v_range[0], nb.v, True) if v_range[1] > v_range[0] else (0, [], [[] for _ in range(i_range[0], i_range[1])], [1] * (i_range[1] - i_range[0]))
+        for t, i in enumerate(range(i_range[0], i_range[1])):
+            nb.i_range = (i, i + 1)
+            nb.top += 1
+            self.last += 1
+            bl = nb.copy()
+            bl.v = cols[t]
+            bot += hvals[t]
+            bl.bot = bot
+            if self.last == len(self.blocks):
+                self.blocks.append(bl)
+            else:
+                self.blocks[self.last] = bl
+
+    # ---- domain.rs:90-246 ----
+    def j_range(self, i_range, f_max, prev: Block, old_range):
+        is_, ie = i_range
+        if f_max is None or self.domain == "full":
+            rng = (0, self.m)
+            if f_max is None:
+                return rng
+        elif self.domain == "gap_start":  # unit costs: f_max insertions / deletions at most
+            rng = (is_ + 1 - f_max, ie + f_max)
+        elif self.domain == "gap_gap":
+            d = self.m - self.n
+            sres = f_max - abs(self.n - self.m)
+            extra = int(sres / 2)  # i32 division truncates towards zero
+            rng = (is_ + 1 + min(d, 0) - extra, ie + max(d, 0) + extra)
+        if self.domain != "astar":
+            if old_range is not None:
+                rng = _union(rng, old_range)
+            return (max(rng[0], 0), min(rng[1], self.m))
+        fixed_start, fixed_end = prev.fixed
+        assert fixed_start <= fixed_end, "Fixed range must not be empty"
+        u0, u1 = is_, fixed_end
+        gu = 0 if is_ < 0 else prev.index(fixed_end)
+        v0, v1 = u0, u1
+
+        def f(x, y):
+            assert y - u1 >= x - u0
+            return gu + abs((x - u0) - (y - u1)) + self.h(x, y)  # extend_cost under unit costs = the gap between the diagonals
+
+        if not self.sparse_h:
+            while v0 < ie:
+                v0 += 1
+                v1 += 1
+                v1 += 1
+                while v1 <= self.m and f(v0, v1) <= f_max:
+                    v1 += 1
+                v1 -= 1
+        else:
+            v0 += 1
+            v1 += 1
+            v1 += self.bw
+            v1 = min(v1, self.m)
+            while True:
+                if v1 < v0 - u0 + u1:
+                    v1 = v0 - u0 + u1
+                    break
+                fv = f(v0, v1)
+                if fv <= f_max:
+                    if v1 == self.m:
+                        break
+                    v1 += 8
+                    if v1 >= self.m:
+                        v1 = self.m
+                else:
+                    v0 += -((f_max - fv) // 2)  # (fv - f_max).div_ceil(2)
+                    if v0 > ie:
+                        v0 = ie
+                        break
+            v0 = ie
+            while True:
+                if v1 < v0 - u0 + u1:
+                    v1 = v0 - u0 + u1
+                    break
+                fv = f(v0, v1)
+                if fv <= f_max:
+                    break
+                v1 -= -((f_max - fv) // 2)
+        rng = (fixed_start, v1)
+        if old_range is not None:
+            rng = _union(rng, old_range)
+        return (max(rng[0], 0), min(rng[1], self.m))
+
+    # ---- domain.rs:251-350 ----
+    def fixed_j_range(self, i, f_max, prev_fixed, block: Block):
+        if self.domain != "astar" or f_max is None:
+            return None
+        f = lambda j: block.index(j) + self.h(i, j)
+        assert block.j_range[0] <= prev_fixed[0]
+        start, end = prev_fixed[0], min(block.orig[1], self.m)
+        while start <= end:
+            fv = f(start)
+            if fv <= f_max:
+                break
+            start += -((f_max - fv) // 2) if self.sparse_h else 1
+        while end >= start:
+            fv = f(end)
+            if fv <= f_max:
+                break
+            end -= -((f_max - fv) // 2) if self.sparse_h else 1
+        fixed = (start, end)
+        if block.fixed is not None:
+            fixed = block.fixed if _empty(fixed) else _union(fixed, block.fixed)
+        return fixed
+
+    # ---- domain.rs:356-541 with trace = true ----
+    def align_for_bounded_dist(self, f_max):
+        self.st["f_max_tries"] += 1
+        assert f_max is None or f_max >= 0
+        first = Block()
+        first.fixed = (-1, -1)
+        initial = self.j_range((-1, 0), f_max, first, self.next_block_j_range())
+        if _empty(initial) or initial[0] > 0:
+            return None
+        self.init(initial)
+        self.set_last_block_fixed_j_range(initial)
+        all_reused = True
+        for i in range(0, self.n, self.bw):
+            i_range = (i, min(i + self.bw, self.n))
+            jr = self.j_range(i_range, f_max, self.last_block(), self.next_block_j_range())
+            if _empty(jr):
+                assert self.next_block_j_range() is None
+                return None
+            reuse = self.next_block_j_range() == jr and all_reused  # (a rounded range against the exact new one, as in the Rust)
+            all_reused = all_reused and reuse
+            prev_fixed = self.last_block().fixed
+            if reuse:
+                self.reuse_next_block(i_range, jr)
+            else:
+                self.compute_next_block(i_range, jr)
+            nf = self.fixed_j_range(i_range[1], f_max, prev_fixed, self.last_block())
+            if nf is not None and _empty(nf):
+                return None
+            self.set_last_block_fixed_j_range(nf)
+        dist = self.last_block().get(self.m)
+        if dist is None:
+            return None
+        if f_max is None or dist <= f_max:
+            return dist, self.trace((0, 0), (self.n, self.m))
+        return dist, None
+
+    def _stats(self):
+        """AstarPa2Stats as cost_or_align returns them: only the BandDoubling arm copies the Blocks' own counters into the result
+        (`nw.stats.block_stats = blocks.stats`, lib.rs:158); the other arms leave them at their defaults."""
+        st = dict(self.st)
+        if self.doubling != "band":
+            st.update(num_blocks=0, num_incremental_blocks=0, computed_lanes=0, unique_lanes=0)
+        return st
+
+    # ---- lib.rs:122-175 + band.rs:11-24, 100-182 ----
+    def align(self):
+        h0 = self.h(0, 0)
+        if self.doubling == "none":
+            assert self.domain == "full"
+            cost, cigar = self.align_for_bounded_dist(None)
+            return cost, cigar, self._stats()
+        gap = abs(self.n - self.m)
+        start_f, start_inc = {"zero": (0, 1), "gap": (gap, gap), "h0": (h0, 1)}[self.start]
+        if self.doubling == "linear":
+            last_s, s, maxs = -1, start_f, I_MAX
+            step = int(self.delta)  # `delta as Cost`
+        else:
+            offset = start_f
+            last_s, s, maxs = -1, offset + max(start_inc, self.bw), I_MAX
+        while True:
+            r = self.align_for_bounded_dist(s)
+            if r is not None:
+                cost, cigar = r
+                assert cost <= maxs
+                if cost <= s:
+                    assert cost > last_s
+                    assert h0 <= cost
+                    return cost, cigar, self._stats()
+                maxs = min(maxs, cost)
+            else:
+                assert maxs == I_MAX
+            last_s = s
+            if self.doubling == "linear":
+                s = min(s + step, maxs)
+            else:
+                s = max(int(math.ceil(_f32(_f32(self.factor) * _f32(s - offset)))), 1) + offset
+                s = min(s, maxs)
+
+    # ---- blocks/trace.rs ----
+    def trace(self, frm, to):  # trace.rs:16-143
+        assert self.blocks[-1].i_range[1] == to[0]
+        ops = []  # (op, cnt), pushed with merging (pa-affine-types cigar.rs:137-146 has the same rule)
+
+        def push(op, cnt):
+            if ops and ops[-1][0] == op:
+                ops[-1][1] += cnt
+            else:
+                ops.append([op, cnt])
+
+        g = [self.blocks[self.last].index(to[1])]
+        while to != frm:
+            while self.last > 0 and self.blocks[self.last].i_range[0] >= to[0]:
+                self.pop_last_block()
+            if self.dt and to[0] > 0:
+                prev = self.blocks[self.last - 1]
+                if prev.i_range[1] < to[0] - 1:
+                    self.st["dt_trace_tries"] += 1
+                    new_to = self.dt_trace_block(to, g, prev, push)
+                    if new_to is not None:
+                        self.st["dt_trace_success"] += 1
+                        to = new_to
+                        continue
+                    self.st["dt_trace_fallback"] += 1
+            if self.sparse and to[0] > 0:
+                block = self.blocks[self.last]
+                prev = self.blocks[self.last - 1]
+                assert prev.i_range[1] < to[0] <= block.i_range[1]
+                if prev.i_range[1] < to[0] - 1 or block.i_range[1] > to[0]:
+                    prev_j_range = prev.j_range
+                    i_range = (prev.i_range[1], to[0])
+                    j_range = (block.j_range[0], to[1])
+                    self.pop_last_block()
+                    height = min(j_range[1] - j_range[0], (i_range[1] - i_range[0]) * 5 // 4)
+                    while True:
+                        jr = _round_out((max(j_range[1] - height, prev_j_range[0]), j_range[1]))
+                        self.st["fill_tries"] += 1
+                        self.fill_with_blocks(i_range, jr)
+                        if self.blocks[self.last].index(to[1]) == g[0]:
+                            self.st["fill_success"] += 1
+                            break
+                        self.st["fill_fallback"] += 1
+                        assert jr[0] != 0, f"No trace found through block {i_range} {jr}"
+                        for _ in range(i_range[0], i_range[1]):
+                            self.pop_last_block()
+                        height *= 2
+            to, (op, cnt) = self.parent(to, g)
+            push(op, cnt)
+        assert g[0] == 0
+        ops.reverse()
+        return "".join((str(c) if c != 1 else "") + o for o, c in ops)
+
+    def parent(self, st, g):  # trace.rs:145-228
+        block = self.blocks[self.last]
+        assert block.i_range[1] == st[0], f"Parent of state {st} but block.i is {block.i_range}"
+        i, j = st
+        cnt = 0
+        while i > 0 and j > 0 and self.a[i - 1] == self.b[j - 1]:
+            cnt += 1
+            i -= 1
+            j -= 1
+        if cnt > 0:
+            return (i, j), ("=", cnt)
+        if block.get_diff(j - 1) == 1:  # vertical delta: an insertion
+            g[0] -= 1
+            return (i, j - 1), ("I", 1)
+        prev = self.blocks[self.last - 1]
+        assert prev.i_range[1] == i - 1
+        hd = 1 if j < prev.j_range[0] else g[0] - prev.index(j)
+        if hd == 1:
+            g[0] -= 1
+            return (i - 1, j), ("D", 1)
+        if j > prev.j_range[1]:
+            assert j == prev.j_range[1] + 1
+            dd = 1
+        else:
+            dd = prev.get_diff(j - 1) + hd
+        if dd == 1:
+            g[0] -= 1
+            return (i - 1, j - 1), ("X", 1)
+        raise AssertionError(f"ERROR: PARENT OF {st} NOT FOUND IN TRACEBACK")
+
+    def _extend_left(self, i, i0, j):  # trace.rs:445-500 -> (i, j, count)
+        cnt = 0
+        while i > i0 and j > 0 and self.a[i - 1] == self.b[j - 1]:
+            i -= 1
+            j -= 1
+            cnt += 1
+        return i, j, cnt
+
+    def dt_trace_block(self, st, g_st, prev: Block, push):  # trace.rs:231-418
+        block_start = prev.i_range[1]
+        fr = {(0, 0): [st[0], 0, 0]}  # (g, d) -> [i, ext, parent_d]; the furthest (leftmost) column at distance g on diagonal d
+
+        def extend_and_check(e, j, target_g):
+            e[0], j, c = self._extend_left(e[0], prev.i_range[1], j)
+            e[1] += c
+            return e[0] == prev.i_range[1] and prev.get(j) == target_g
+
+        def emit(g, d):
+            new_st = (block_start, st[1] - (st[0] - block_start) - d)
+            g_st[0] -= g
+            out = []
+            while True:
+                e = fr[(g, d)]
+                if e[1] > 0:
+                    out.append(("=", e[1]))
+                if g == 0:
+                    break
+                g -= 1
+                d += e[2]
+                out.append(({-1: "I", 0: "X", 1: "D"}[e[2]], 1))
+            for op, c in reversed(out):
+                push(op, c)
+            return new_st
+
+        g = 0
+        if extend_and_check(fr[(0, 0)], st[1], g_st[0]):
+            return emit(0, 0)
+        d0, d1 = 0, 0
+        while True:
+            ng = g + 1
+            for d in range(d0 - 1, d1 + 2):
+                fr[(ng, d)] = [I_MAX, 0, 0]
+            for d in range(d0, d1 + 1):
+                e = fr[(g, d)]
+
+                def update(x, y, pd):
+                    if y < x[0]:
+                        x[0] = y
+                        x[2] = pd
+
+                update(fr[(ng, d - 1)], e[0] - 1, 1)
+                update(fr[(ng, d)], e[0] - 1, 0)
+                update(fr[(ng, d + 1)], e[0], -1)
+            g += 1
+            d0 -= 1
+            d1 += 1
+            min_fr, min_i = I_MAX, I_MAX
+            for d in range(d0, d1 + 1):
+                e = fr[(g, d)]
+                if e[0] == I_MAX:
+                    continue
+                j = st[1] - (st[0] - e[0]) - d
+                if extend_and_check(e, j, g_st[0] - g):
+                    return emit(g, d)
+                min_fr = min(min_fr, 2 * e[0] - d)
+                min_i = min(min_i, e[0])
+            if g == self.max_g // 2 and min_i > (block_start + st[0]) // 2:
+                return None
+            if g == self.max_g:
+                return None
+            if self.fr_drop > 0:
+                while d0 < d1 and (fr[(g, d0)][0] <= block_start or 2 * fr[(g, d0)][0] - d0 > min_fr + self.fr_drop):
+                    d0 += 1
+                while d0 < d1 and (fr[(g, d1)][0] <= block_start or 2 * fr[(g, d1)][0] - d1 > min_fr + self.fr_drop):
+                    d1 -= 1
+                if d0 > d1:
+                    return None
+
+
+def align(a: bytes, b: bytes, **kw):
+    """-> (cost, CIGAR string, statistics) of the restated traced A*PA2 (`simple` family; see the module header)."""
+    return Restated(a, b, **kw).align()

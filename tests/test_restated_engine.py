@@ -1,0 +1,116 @@
+"""Two restatements of the reference's traced A*PA2 host logic against each other, on the CPU.
+
+`oracle.cpu_align` is the product's host engine (csrc/engine.hpp) over the CPU oracle kernels; `oracle/astarpa2_restated.py` is a second
+restatement written from the Rust text alone, in pure Python on big integers, sharing no code with the first.  For every pair the cost,
+the CIGAR STRING and eleven statistics must be identical -- band doubling, ranges, block reuse, the stale-block quirks, DT-trace with its
+x-drop, the re-fill fallback and the parent rules included.  (The twelfth statistic, sanity_violations, is this build's own.)"""
+import random
+
+import pytest
+
+from oracle import astarpa2_restated as restated
+from tests.util_seq import PA_TEST_ES, PA_TEST_NS, PA_TEST_PAIRS, gen_pair, rand_seq
+
+KEYS = ["num_blocks", "num_incremental_blocks", "computed_lanes", "unique_lanes", "f_max_tries", "dt_trace_tries", "dt_trace_success",
+        "dt_trace_fallback", "fill_tries", "fill_success", "fill_fallback"]
+
+BASE = dict(domain="astar", doubling="band", start="h0", factor=2.0, block_width=256, sparse=True, incremental_doubling=False,
+            dt_trace=True, max_g=40, fr_drop=10, sparse_h=True)
+
+
+def variants(o):
+    """name -> (parameters of the engine, keyword arguments of the restatement)"""
+    mk = lambda **kw: o.make_params(**{**BASE, **kw})
+    return {
+        "simple": (o.params_simple(), dict(heuristic="gap")),
+        "dijkstra": (mk(heuristic="none"), dict(heuristic="none")),
+        "sh12": (mk(heuristic="sh", k=12), dict(heuristic="sh", k=12)),
+        "sh5": (mk(heuristic="sh", k=5), dict(heuristic="sh", k=5)),
+        "gap_nosparseh": (mk(heuristic="gap", sparse_h=False), dict(heuristic="gap", sparse_h=False)),
+        "gap_nodt": (mk(heuristic="gap", dt_trace=False), dict(heuristic="gap", dt_trace=False)),
+        "gap_g20_drop5": (mk(heuristic="gap", max_g=20, fr_drop=5), dict(heuristic="gap", max_g=20, fr_drop=5)),
+        "gap_nodrop": (mk(heuristic="gap", fr_drop=0), dict(heuristic="gap", fr_drop=0)),
+        "gap_startgap": (mk(heuristic="gap", start="gap"), dict(heuristic="gap", start="gap")),
+        "gap_startzero_f15": (mk(heuristic="gap", start="zero", factor=1.5), dict(heuristic="gap", start="zero", factor=1.5)),
+        "linear300": (mk(heuristic="gap", doubling="linear", delta=300.0), dict(heuristic="gap", doubling="linear", delta=300.0)),
+        "block64": (mk(heuristic="gap", block_width=64), dict(heuristic="gap", block_width=64)),
+        "gap_gap": (mk(domain="gap_gap", heuristic="none", start="gap"), dict(domain="gap_gap", start="gap")),
+        "gap_start": (mk(domain="gap_start", heuristic="none", start="zero"), dict(domain="gap_start", start="zero")),
+        "nw": (o.params_nw(), dict(domain="full", doubling="none", sparse=False, dt_trace=False)),
+        "full_sparse": (o.make_params(domain="full", heuristic="none", doubling="none", block_width=256, sparse=True, incremental_doubling=False,
+                                      dt_trace=False), dict(domain="full", doubling="none", sparse=True, dt_trace=False)),
+        "full_sparse_dt": (o.make_params(domain="full", heuristic="none", doubling="none", block_width=256, sparse=True,
+                                         incremental_doubling=False, dt_trace=True, max_g=40, fr_drop=10),
+                           dict(domain="full", doubling="none", sparse=True, dt_trace=True)),
+    }
+
+
+def compare(o, a, b, prm, kw, tally=None):
+    want = o.cpu_align(a, b, prm)
+    got = restated.align(a, b, **kw)
+    assert got[0] == want[0], (len(a), len(b), kw)
+    assert got[1] == want[1], (len(a), len(b), kw, got[1][:60], want[1][:60])
+    assert {k: got[2][k] for k in KEYS} == {k: want[2][k] for k in KEYS}, (len(a), len(b), kw)
+    if tally is not None:
+        for k in KEYS:
+            tally[k] = tally.get(k, 0) + got[2][k]
+        tally["regrown"] = tally.get("regrown", 0) + (got[2]["f_max_tries"] > 1 and got[2]["unique_lanes"] < got[2]["computed_lanes"])
+    return got
+
+
+def test_the_reference_harness_pairs_and_grid(oracle):
+    """pa-test/src/lib.rs:7-40: the literal pairs and the (n, e) grid, every variant."""
+    vs = variants(oracle)
+    for name, (prm, kw) in vs.items():
+        for a, b in PA_TEST_PAIRS:
+            compare(oracle, a, b, prm, kw)
+    rng = random.Random(5)
+    for n in PA_TEST_NS:
+        for e in PA_TEST_ES:
+            if n == 0:
+                continue
+            a, b = gen_pair(n, e, seed=n * 131 + int(e * 1000))
+            name = rng.choice(list(vs))
+            compare(oracle, a, b, *vs[name])
+
+
+def test_random_pairs_every_field(oracle):
+    vs = variants(oracle)
+    rng = random.Random(20260927)
+    tally = {}
+    for it in range(700):
+        name = rng.choice(list(vs))
+        n = rng.choice([rng.randint(1, 300), rng.randint(300, 1500), rng.randint(1500, 6000)])
+        e = rng.choice([0.0, 0.01, 0.05, 0.1, 0.2, 0.4, 0.8])
+        a, b = gen_pair(n, e, rng.randint(1, 10**9))
+        mode = rng.random()
+        if mode < 0.25 and n > 50:  # one long indel: band edges move, DT-trace gives up, re-fills grow
+            cut = rng.randint(0, len(b) - 1)
+            ln = rng.randint(1, max(1, min(800, len(b) // 2)))
+            b = b[:cut] + b[cut + ln:] if rng.random() < 0.5 else b[:cut] + rand_seq(ln, it + 7) + b[cut:]
+            b = b or b"A"
+        elif mode < 0.3:
+            b = rand_seq(rng.randint(1, n + 50), it + 9)
+        compare(oracle, a, b, *vs[name], tally=tally)
+    # the comparison has to have been through the interesting paths, not only the straight ones
+    assert tally["dt_trace_success"] > 500 and tally["dt_trace_fallback"] > 100
+    assert tally["fill_success"] > 100 and tally["fill_fallback"] > 20
+    assert tally["f_max_tries"] > 900 and tally["regrown"] > 50  # (regrown: pairs whose later passes recomputed blocks over wider ranges)
+
+
+@pytest.mark.parametrize("name", ["simple", "sh12", "dijkstra", "gap_nodt"])
+def test_long_pairs_several_passes(oracle, name):
+    prm, kw = variants(oracle)[name]
+    for n, e, seed in [(20_000, 0.15, 4), (30_000, 0.08, 5), (12_000, 0.3, 6)]:
+        a, b = gen_pair(n, e, seed)
+        cut = len(b) // 3
+        b = b[:cut] + rand_seq(700, seed + 1) + b[cut:2 * cut] + b[2 * cut + 400:]
+        got = compare(oracle, a, b, prm, kw)
+        assert got[2]["f_max_tries"] >= 3
+
+
+def test_c3_pair_of_the_bench(oracle):
+    """The 100 kbp pair at 5 % of bench.py's c3 legs, `simple`: cost, CIGAR string and statistics."""
+    a, b = gen_pair(100_000, 0.05, seed=3_000_000)
+    got = compare(oracle, a, b, *variants(oracle)["simple"])
+    assert got[2]["f_max_tries"] == 6 and got[2]["dt_trace_tries"] == 391

@@ -1,29 +1,33 @@
 """oracle/astarpa2_restated.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
-A second, independent restatement of the reference's TRACED A*PA2 path for the `simple` family of parameter sets (Domain::Astar with
-the NoCost / GapCost / SH heuristic, band doubling from h0, sparse blocks, no incremental doubling, DT-trace on or off), written from
-the Rust text alone and sharing nothing with csrc/engine.hpp (the product's host logic, which oracle/engine_cpu.cpp instantiates over
-the CPU kernels) nor with any kernel of this repository: the DP of a block runs on Python big integers.
+A second, independent restatement of the reference's TRACED A*PA2 path, written from the Rust text alone and sharing nothing with
+csrc/engine.hpp (the product's host logic, which oracle/engine_cpu.cpp instantiates over the CPU kernels) nor with any kernel of this
+repository: the DP of a block runs on Python big integers.  Covered: Domain::{Astar, Full, GapStart, GapGap}; the NoCost / GapCost /
+SH heuristics (GCSH and pruning are NOT covered -- the `full` preset stays rule-pinned); band doubling, linear search and no doubling
+from every DoublingStart; sparse and dense blocks; incremental doubling (2- and 3-range splits over the stored row of horizontal
+differences); DT-trace with its x-drop, the re-fill fallback and the parent rules.
 
-    astarpa2/src/lib.rs:122-175          cost_or_align                      band.rs:11-24, 100-141   initial_values, exponential_search
-    astarpa2/src/domain.rs:90-246        j_range (Domain::Astar)            domain.rs:251-350        fixed_j_range
+    astarpa2/src/lib.rs:122-175          cost_or_align                      band.rs:11-24, 100-182   initial_values, exponential / linear search
+    astarpa2/src/domain.rs:90-246        j_range                            domain.rs:251-350        fixed_j_range
     astarpa2/src/domain.rs:356-541       align_for_bounded_dist             ranges.rs:49-80          JRange rounding / union
     astarpa2/src/block.rs:35-140         Block::default / first_col / index / get / get_diff
     astarpa2/src/blocks.rs:146-199       Blocks::init / pop_last_block / reuse_next_block
-    astarpa2/src/blocks.rs:205-339       compute_next_block (the sparse traced arm without incremental doubling)
+    astarpa2/src/blocks.rs:205-469       compute_next_block (dense arm, sparse arm, incremental doubling)
     astarpa2/src/blocks.rs:545-660       last_block / next_block_j_range / set_last_block_fixed_j_range / fill_with_blocks
-    astarpa2/src/blocks.rs:686-769       compute_block (statistics, HMode::None) / init_v_with_overlap
+    astarpa2/src/blocks.rs:662-831       HMode, compute_block, init_v_with_overlap, init_v_with_overlap_preserve_fixed
     astarpa2/src/blocks/trace.rs:16-143  Blocks::trace       trace.rs:145-228  parent       trace.rs:231-418  dt_trace_block
     astarpa2/src/blocks/trace.rs:445-500 extend_left / extend_left_simd (the word-at-a-time loop only changes HOW the run is counted)
     pa-bitpacking/src/myers.rs:27-55     compute_block (one Myers step; here on one integer as tall as the block)
     pa-bitpacking/src/scalar.rs:405-425  fill (every column of a block kept)
+    pa-affine-types cost_model.rs:387-399, 453-510  unit costs: max_ins/del_for_cost(s) = s, gap_cost = extend_cost = |d|
     pa-heuristic: GapCost h = |(n - i) - (m - j)|; SH with exact matches (sh.rs:47-106, matches/exact.rs, qgrams.rs:30-43)
 
-Purpose: the CIGAR strings and the twelve statistics of the `simple` family used to be pinned only by the reference's acceptance rules
+Purpose: the CIGAR strings and the statistics of these parameter sets used to be pinned only by the reference's acceptance rules
 (cost = distance, CIGAR valid) plus engine.hpp agreeing with itself over two kernel back ends.  Two restatements that were written
-separately and agree on every field for thousands of random pairs (tests/test_restated_engine.py) leave a mis-reading of the Rust
-text as the only common failure, and that is what `parity: rule-pinned, twice restated` means in DESIGN.md 4.  The Rust binary
-itself cannot be built here (no toolchain), so this is still not a reference-generated pin.
+separately and agree on every field for thousands of random pairs (tests/test_restated_engine.py; one 1 Mbp pair by hand) leave a
+common mis-reading of the Rust text as the only shared failure -- `rule-pinned, twice restated` in DESIGN.md 4.  The first
+disagreement it found was real: engine.hpp reported block counters after a linear search, the reference does not (lib.rs:132-140
+against 158).  The Rust binary itself cannot be built here (no toolchain), so this is still not a reference-generated pin.
 """
 from __future__ import annotations
 
@@ -73,7 +77,7 @@ def sh_table(a: bytes, b: bytes, k: int):
 
 
 class Block:
-    __slots__ = ("v", "i_range", "orig", "j_range", "fixed", "offset", "top", "bot")
+    __slots__ = ("v", "i_range", "orig", "j_range", "fixed", "offset", "top", "bot", "j_h")
 
     def __init__(self):  # block.rs:35-49
         self.v = []
@@ -84,10 +88,12 @@ class Block:
         self.offset = 0
         self.top = I_MAX
         self.bot = I_MAX
+        self.j_h = None
 
     def copy(self):
         o = Block()
         o.v, o.i_range, o.orig, o.j_range, o.fixed, o.offset, o.top, o.bot = list(self.v), self.i_range, self.orig, self.j_range, self.fixed, self.offset, self.top, self.bot
+        o.j_h = self.j_h
         return o
 
     def index(self, j):  # block.rs:69-121
@@ -136,7 +142,7 @@ class Block:
 class Restated:
     def __init__(self, a: bytes, b: bytes, heuristic: str = "gap", k: int = 12, sparse_h: bool = True, block_width: int = 256,
                  dt_trace: bool = True, max_g: int = 40, fr_drop: int = 10, domain: str = "astar", sparse: bool = True,
-                 doubling: str = "band", start: str = "h0", factor: float = 2.0, delta: float = 1.0):
+                 doubling: str = "band", start: str = "h0", factor: float = 2.0, delta: float = 1.0, incremental_doubling: bool = False):
         assert all(c in b"ACGT" for c in a) and all(c in b"ACGT" for c in b)
         assert domain in ("astar", "full", "gap_start", "gap_gap") and doubling in ("band", "linear", "none") and start in ("zero", "gap", "h0")
         self.a, self.b, self.n, self.m = a, b, len(a), len(b)
@@ -146,6 +152,8 @@ class Restated:
         self.sh = sh_table(a, b, k) if self.kind == "sh" else None
         self.peq = {c: sum(1 << j for j in range(self.m) if b[j] == c) for c in set(a)}  # rows >= m never match (profile.rs:127-132)
         # Blocks (blocks.rs:87-107)
+        self.incremental = incremental_doubling
+        self.hrow = [(0, 0)] * self.n if incremental_doubling else []  # horizontal differences (p, m) of the row j_h, per column
         self.blocks: list[Block] = []
         self.last = 0
         self.i_range = (-1, 0)
@@ -160,41 +168,55 @@ class Restated:
             return self.sh[i]
         return 0
 
-    # ---- one Myers step per column on an integer `rows` bits tall (myers.rs:27-55; horizontal input +1 at the top row) ----
-    def _columns(self, i0, i1, w0, vwords, keep):
+    # ---- one Myers step per column on an integer `rows` bits tall (myers.rs:27-55) ----
+    # hin: None (+1 into the top row of every column) or one (p, m) pair per column.  -> (sum of the bottom row's differences, the new
+    # vertical words, every column's words if `keep`, the bottom row's (p, m) per column)
+    def _columns(self, i0, i1, w0, vwords, keep, hin=None):
         rows = len(vwords) * W
         full = (1 << rows) - 1
         vp = sum(p << (W * t) for t, (p, _) in enumerate(vwords))
         vm = sum(m << (W * t) for t, (_, m) in enumerate(vwords))
-        topbit = 1 << (rows - 1)
+        sh = rows - 1
         m64 = (1 << W) - 1
-        hsum, cols, hvals = 0, [], []
+        hsum, cols, hout = 0, [], []
         for i in range(i0, i1):
+            hp0, hm0 = (1, 0) if hin is None else hin[i - i0]
             eq = (self.peq.get(self.a[i], 0) >> (w0 * W)) & full
             xv = eq | vm
+            eq |= hm0  # a -1 coming in acts like a match in the top row
             xh = ((((eq & vp) + vp) & full) ^ vp) | eq
             ph = vm | (full & ~(xh | vp))
             mh = vp & xh
-            hout = (1 if ph & topbit else 0) - (1 if mh & topbit else 0)
-            hsum += hout
-            ph = ((ph << 1) | 1) & full
-            mh = (mh << 1) & full
+            o = ((ph >> sh) & 1, (mh >> sh) & 1)
+            hsum += o[0] - o[1]
+            hout.append(o)
+            ph = ((ph << 1) | hp0) & full
+            mh = ((mh << 1) | hm0) & full
             vp = mh | (full & ~(xv | ph))
             vm = ph & xv
             if keep:
                 cols.append([((vp >> (W * t)) & m64, (vm >> (W * t)) & m64) for t in range(len(vwords))])
-                hvals.append(hout)
         out = [((vp >> (W * t)) & m64, (vm >> (W * t)) & m64) for t in range(len(vwords))]
-        return hsum, out, cols, hvals
+        return hsum, out, cols, hout
 
-    def compute_block(self, i_range, v_range, v):  # blocks.rs:686-748, HMode::None; returns the bottom row's sum, updates v
-        if i_range[1] - i_range[0] > 1:
-            self.st["computed_lanes"] += v_range[1] - v_range[0]
+    def compute_block(self, i_range, v_range, v, lo=0, mode="none"):
+        """blocks.rs:686-748: columns i_range over the words v_range, which sit at v[lo : lo + len]; returns the sum of the bottom row's
+        horizontal differences.  mode (HMode): none = +1 into the top row, nothing kept; output = +1 in, the bottom row's differences
+        stored in self.hrow; input = self.hrow into the top row, nothing kept; update = self.hrow in and replaced."""
+        i0, i1 = i_range
+        nw = v_range[1] - v_range[0]
+        if i1 - i0 > 1:
+            self.st["computed_lanes"] += nw
             self.st["num_incremental_blocks"] += 1
-        if v_range[1] == v_range[0]:
-            return i_range[1] - i_range[0]  # (no words: the sum of the +1 inputs)
-        hsum, out, _, _ = self._columns(i_range[0], i_range[1], v_range[0], v, False)
-        v[:] = out
+        hin = None if mode in ("none", "output") else self.hrow[i0:i1]
+        if nw == 0:  # no words: what comes in at the top goes out at the bottom
+            hout = [(1, 0)] * (i1 - i0) if hin is None else list(hin)
+            hsum = sum(p - m for p, m in hout)
+        else:
+            hsum, out, _, hout = self._columns(i0, i1, v_range[0], v[lo:lo + nw], False, hin)
+            v[lo:lo + nw] = out
+        if mode in ("output", "update"):
+            self.hrow[i0:i1] = hout
         return hsum
 
     # ---- Blocks ----
@@ -251,7 +273,7 @@ class Restated:
         assert o0 <= o1, "ranges of consecutive blocks overlap"
         nxt.v[o0 - v0:o1 - v0] = prev.v[o0 - pv0:o1 - pv0]
 
-    def compute_next_block(self, i_range, j_range):  # blocks.rs:205-339 (trace && sparse && !incremental_doubling)
+    def compute_next_block(self, i_range, j_range):  # blocks.rs:205-469 (trace mode)
         self.st["num_blocks"] += 1
         orig = j_range
         jr = _round_out(j_range)
@@ -273,12 +295,80 @@ class Restated:
             assert self.blocks[self.last + 1].i_range == i_range
         prev, nxt = self.blocks[self.last], self.blocks[self.last + 1]
         self.last += 1
+        old = nxt.copy()  # ("copy settings, but not the vector": the vector stays with nxt)
         # the block is overwritten in place: its v memory and -- note -- its fixed_j_range survive (blocks.rs:303-316)
-        nxt.i_range, nxt.orig, nxt.j_range, nxt.offset = i_range, orig, jr, jr[0]
+        nxt.i_range, nxt.orig, nxt.j_range, nxt.offset, nxt.j_h = i_range, orig, jr, jr[0], None
         nxt.top = prev_top + (i_range[1] - i_range[0])
         nxt.bot = prev_bot
-        self.init_v_with_overlap(prev, nxt)
-        nxt.bot += self.compute_block(i_range, v_range, nxt.v)
+        if not self.incremental or prev.fixed is None:
+            self.init_v_with_overlap(prev, nxt)
+            nxt.bot += self.compute_block(i_range, v_range, nxt.v)
+            return
+        # ---- incremental doubling (blocks.rs:341-469) ----
+        new_j_h = prev.fixed[1] // W * W  # prev_fixed.round_in().1
+        nxt.j_h = new_j_h
+        off = v_range[0]
+        up64 = lambda x: -(-x // W) * W
+        if old.j_h is not None and old.fixed is not None and up64(old.fixed[0] - 1) < old.j_h:
+            self.init_v_with_overlap_preserve_fixed(prev, old, nxt)
+            r0 = _round_out((jr[0], old.fixed[0] - 1))
+            vr0 = (r0[0] // W, r0[1] // W)
+            assert vr0[0] <= vr0[1]
+            assert old.j_h % W == 0 and new_j_h % W == 0 and jr[1] % W == 0
+            vr1 = (old.j_h // W, new_j_h // W)
+            assert vr1[0] <= vr1[1], "j_h may only increase!"
+            vr2 = (new_j_h // W, jr[1] // W)
+            assert vr2[0] <= vr2[1]
+            self.compute_block(i_range, vr0, nxt.v, vr0[0] - off, "none")
+            if vr1[1] > vr1[0]:
+                self.compute_block(i_range, vr1, nxt.v, vr1[0] - off, "update")
+            nxt.bot += self.compute_block(i_range, vr2, nxt.v, vr2[0] - off, "input")
+        else:
+            self.init_v_with_overlap(prev, nxt)
+            assert jr[0] % W == 0 and new_j_h % W == 0
+            vr01 = (jr[0] // W, new_j_h // W)
+            assert vr01[0] <= vr01[1]
+            vr2 = (new_j_h // W, jr[1] // W)
+            assert vr2[0] <= vr2[1]
+            self.compute_block(i_range, vr01, nxt.v, vr01[0] - off, "output")
+            nxt.bot += self.compute_block(i_range, vr2, nxt.v, vr2[0] - off, "input")
+
+    @staticmethod
+    def init_v_with_overlap_preserve_fixed(prev: Block, old: Block, nxt: Block):  # blocks.rs:776-831
+        v = nxt.v  # still the old block's words
+        assert prev.offset == prev.j_range[0] and old.offset == old.j_range[0] and nxt.offset == nxt.j_range[0]
+        assert nxt.j_range[0] <= old.j_range[0] and old.j_range[1] <= nxt.j_range[1]
+        pv = (prev.j_range[0] // W, prev.j_range[1] // W)
+        ov = (old.j_range[0] // W, old.j_range[1] // W)
+        nv = (nxt.j_range[0] // W, nxt.j_range[1] // W)
+        assert pv[0] <= nv[0] <= ov[0]
+        preserve = (-(-(old.fixed[0] - 1) // W), old.j_h // W)  # JRange(old_fixed.0 - 1, old_j_h).round_in().v_range()
+        assert preserve[0] < preserve[1]
+        # 1. resize (Vec::resize keeps the front, pads with V::one() or truncates)
+        n = nv[1] - nv[0]
+        if len(v) < n:
+            v.extend([ONE] * (n - len(v)))
+        else:
+            del v[n:]
+        # 2. move the preserved words to where they belong in the new range
+        if nv[0] != ov[0]:
+            chunk = v[preserve[0] - ov[0]:preserve[1] - ov[0]]
+            assert len(chunk) == preserve[1] - preserve[0]
+            v[preserve[0] - nv[0]:preserve[0] - nv[0] + len(chunk)] = chunk
+        # 3. prefix and suffix from the previous block
+        k = preserve[0] - nv[0]
+        src = prev.v[nv[0] - pv[0]:preserve[0] - pv[0]]
+        assert len(src) == k
+        v[:k] = src
+        copy_end = min(nv[1], pv[1])
+        assert copy_end >= preserve[1]
+        src = prev.v[preserve[1] - pv[0]:copy_end - pv[0]]
+        assert len(src) == copy_end - preserve[1]
+        v[preserve[1] - nv[0]:copy_end - nv[0]] = src
+        # 4. the rest: +1
+        for t in range(copy_end - nv[0], n):
+            v[t] = ONE
+        assert len(v) == n
 
     def fill_with_blocks(self, i_range, original_j_range):  # blocks.rs:571-660
         jr = _round_out(original_j_range)
@@ -291,7 +381,11 @@ class Restated:
         nb.top, nb.bot = prev.index(jr[0]), 0
         self.init_v_with_overlap(prev, nb)
         bot = prev.index(jr[1])
-        _, _, cols, hvals = self._columns(i_range[0], i_range[1], v_range[0], nb.v, True) if v_range[1] > v_range[0] else (0, [], [[] for _ in range(i_range[0], i_range[1])], [1] * (i_range[1] - i_range[0]))
+        if v_range[1] > v_range[0]:
+            _, _, cols, hpairs = self._columns(i_range[0], i_range[1], v_range[0], nb.v, True)
+            hvals = [p - m for p, m in hpairs]
+        else:
+            cols, hvals = [[] for _ in range(i_range[0], i_range[1])], [1] * (i_range[1] - i_range[0])
         for t, i in enumerate(range(i_range[0], i_range[1])):
             nb.i_range = (i, i + 1)
             nb.top += 1

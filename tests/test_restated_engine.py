@@ -34,6 +34,12 @@ def variants(o):
         "gap_startzero_f15": (mk(heuristic="gap", start="zero", factor=1.5), dict(heuristic="gap", start="zero", factor=1.5)),
         "linear300": (mk(heuristic="gap", doubling="linear", delta=300.0), dict(heuristic="gap", doubling="linear", delta=300.0)),
         "block64": (mk(heuristic="gap", block_width=64), dict(heuristic="gap", block_width=64)),
+        "gap_incr": (mk(heuristic="gap", incremental_doubling=True), dict(heuristic="gap", incremental_doubling=True)),
+        "sh12_incr": (mk(heuristic="sh", k=12, incremental_doubling=True), dict(heuristic="sh", k=12, incremental_doubling=True)),
+        "dijkstra_incr_nodt": (mk(heuristic="none", incremental_doubling=True, dt_trace=False),
+                               dict(heuristic="none", incremental_doubling=True, dt_trace=False)),
+        "gap_incr_f15": (mk(heuristic="gap", incremental_doubling=True, start="zero", factor=1.5),
+                         dict(heuristic="gap", incremental_doubling=True, start="zero", factor=1.5)),
         "gap_gap": (mk(domain="gap_gap", heuristic="none", start="gap"), dict(domain="gap_gap", start="gap")),
         "gap_start": (mk(domain="gap_start", heuristic="none", start="zero"), dict(domain="gap_start", start="zero")),
         "nw": (o.params_nw(), dict(domain="full", doubling="none", sparse=False, dt_trace=False)),
@@ -98,7 +104,7 @@ def test_random_pairs_every_field(oracle):
     assert tally["f_max_tries"] > 900 and tally["regrown"] > 50  # (regrown: pairs whose later passes recomputed blocks over wider ranges)
 
 
-@pytest.mark.parametrize("name", ["simple", "sh12", "dijkstra", "gap_nodt"])
+@pytest.mark.parametrize("name", ["simple", "sh12", "dijkstra", "gap_nodt", "gap_incr", "sh12_incr", "gap_incr_f15"])
 def test_long_pairs_several_passes(oracle, name):
     prm, kw = variants(oracle)[name]
     for n, e, seed in [(20_000, 0.15, 4), (30_000, 0.08, 5), (12_000, 0.3, 6)]:

@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "pa_pairs_read", "pa_pairs_count", "pa_pairs_get", "pa_pairs_free", "pa_write_results_csv", "pa_align_file",
     "pa_align", "pa_batch_align_multi", "pa_batch_create_trace_params",
     "pa_bp_ctx_create", "pa_bp_ctx_compute", "pa_bp_ctx_fill", "pa_bp_ctx_destroy",
-    "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools", "pa_align_file_params", "pa_batch_params_supported",
+    "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools", "pa_align_file_params", "pa_batch_params_supported", "pa_alloc_cache_stats",
 ]
 
 _lib = None
@@ -54,6 +54,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L = C.CDLL(str(path))
     L.pa_runtime_hints.restype = C.c_int
     L.pa_release_pools.restype = None
+    L.pa_alloc_cache_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
+    L.pa_alloc_cache_stats.restype = None
     L.pa_runtime_hints()  # this package is the application here: more hardware queues, before the first HIP call
     vp, sz = C.c_void_p, C.c_size_t
     L.pa_last_error.restype = C.c_char_p
@@ -152,6 +154,18 @@ def _marshal_pairs(pairs):
     al = np.fromiter((len(a) for a, _ in pairs), dtype=np.uint64, count=n) if n else np.zeros(1, np.uint64)
     bl = np.fromiter((len(b) for _, b in pairs), dtype=np.uint64, count=n) if n else np.zeros(1, np.uint64)
     return ap, _p(al), bp, _p(bl)
+
+
+def alloc_cache_stats() -> dict:
+    """pa_alloc_cache_stats: the library's cache of large device buffers (pa_astarpa2.h)."""
+    h, m, b = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    load().pa_alloc_cache_stats(C.byref(h), C.byref(m), C.byref(b))
+    return {"hits": h.value, "misses": m.value, "cached_bytes": b.value}
+
+
+def release_pools() -> None:
+    """pa_release_pools: the calling thread's engine pools and the cache of large device buffers back to the driver."""
+    load().pa_release_pools()
 
 
 def require_gpu() -> None:

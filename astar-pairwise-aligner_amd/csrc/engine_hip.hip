@@ -852,6 +852,7 @@ extern "C" void pa_release_pools(void) {
     (void)hipDeviceSynchronize();
     sweep_pool_slot().reset();
     pooled_backend_slot().reset();
+    release_alloc_cache();  // (after the pools: their buffers land in the cache first)
 }
 
 // The engine's bookkeeping without any kernel work (used where the numbers come from a fused GPU pass).

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <atomic>
 #include <mutex>
 #include <set>
 #include <thread>
@@ -184,14 +185,129 @@ bool ensure_device() {
     return true;
 }
 
+// ---- device memory -----------------------------------------------------------------------------------------------------------
+// Large buffers are CACHED: hipMalloc + hipFree of the 40 GB block-column store of a 4096 x 100 kbp batch cost about a second, seven
+// times the alignment of the pairs it holds, and pa_align_file / the work queue create a batch per chunk.  A buffer of at least
+// kCacheMin bytes goes to a free list when its owner lets go of it and is handed to the next request on the same device that it fits
+// (at most a quarter larger than asked for).  Nothing in this library reads device memory it has not written, and a cached block is
+// as undefined as a fresh one.  The list is bounded (kCacheMaxBytes, oldest out first), emptied when an allocation fails, and
+// returned to the driver by pa_release_pools().  PA_NO_ALLOC_CACHE=1 switches it off; PA_POISON_ALLOC=1 fills every buffer handed
+// out with 0xA5 (tests: nothing may depend on fresh memory being zero).
+namespace {
+constexpr size_t kCacheMin = size_t(16) << 20, kCacheMaxBytes = size_t(96) << 30;
+struct CachedBlock {
+    int dev;
+    void* ptr;
+    size_t size;
+};
+// (never destroyed: buffers of thread-local pools are released after the statics of this file at process exit)
+std::mutex& g_cache_mu = *new std::mutex;
+std::vector<CachedBlock>& g_cache = *new std::vector<CachedBlock>;  // oldest first
+size_t g_cache_bytes = 0;
+std::atomic<uint64_t> g_cache_hits{0}, g_cache_misses{0};
+
+bool cache_on() {
+    static const bool off = getenv("PA_NO_ALLOC_CACHE") != nullptr;
+    return !off;
+}
+void* cache_take(int dev, size_t bytes, size_t* got) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    size_t best = g_cache.size();
+    for (size_t i = 0; i < g_cache.size(); ++i)
+        if (g_cache[i].dev == dev && g_cache[i].size >= bytes && g_cache[i].size <= bytes + bytes / 4 &&
+            (best == g_cache.size() || g_cache[i].size < g_cache[best].size))
+            best = i;
+    if (best == g_cache.size()) return nullptr;
+    void* p = g_cache[best].ptr;
+    *got = g_cache[best].size;
+    g_cache_bytes -= g_cache[best].size;
+    g_cache.erase(g_cache.begin() + (long)best);
+    return p;
+}
+// -> blocks the caller has to hipFree (outside the lock)
+std::vector<CachedBlock> cache_put(int dev, void* ptr, size_t size) {
+    std::vector<CachedBlock> out;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_cache.push_back({dev, ptr, size});
+    g_cache_bytes += size;
+    while (g_cache_bytes > kCacheMaxBytes && !g_cache.empty()) {
+        out.push_back(g_cache.front());
+        g_cache_bytes -= g_cache.front().size;
+        g_cache.erase(g_cache.begin());
+    }
+    return out;
+}
+void free_blocks(const std::vector<CachedBlock>& blocks) {
+    if (blocks.empty()) return;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (const CachedBlock& b : blocks) {
+        if (b.dev != cur) (void)hipSetDevice(b.dev);
+        (void)hipFree(b.ptr);
+        if (b.dev != cur) (void)hipSetDevice(cur);
+    }
+}
+}  // namespace
+
+// PA_POISON_ALLOC: on a stream of its own that does not synchronise with the null stream (persistent kernels may be in flight)
+static bool poison_fill(void* ptr, size_t size) {
+    static thread_local hipStream_t st = nullptr;
+    if (!st && !hip_ok(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "poison stream")) return false;
+    return hip_ok(hipMemsetAsync(ptr, 0xA5, size, st), "poison") && hip_ok(hipStreamSynchronize(st), "poison sync");
+}
+
+void release_alloc_cache() {
+    std::vector<CachedBlock> all;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        all.swap(g_cache);
+        g_cache_bytes = 0;
+    }
+    free_blocks(all);
+}
+
+extern "C" void pa_alloc_cache_stats(uint64_t* hits, uint64_t* misses, uint64_t* cached_bytes) {
+    if (hits) *hits = g_cache_hits.load();
+    if (misses) *misses = g_cache_misses.load();
+    if (cached_bytes) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        *cached_bytes = g_cache_bytes;
+    }
+}
+
 bool DeviceBuf::alloc(size_t bytes) {
     release();
     if (bytes < 64) bytes = 64;
-    if (!hip_ok(hipMalloc(&ptr, bytes), "hipMalloc")) {
+    static const bool poison = getenv("PA_POISON_ALLOC") != nullptr;
+    int dev = 0;
+    if (!hip_ok(hipGetDevice(&dev), "hipGetDevice")) return false;
+    const bool big = bytes >= kCacheMin && cache_on();
+    if (big) {
+        bytes = (bytes + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);  // (2 MB steps: requests of almost the same size meet)
+        size_t got = 0;
+        if (void* p = cache_take(dev, bytes, &got)) {
+            ptr = p;
+            size = got;
+            device = dev;
+            g_cache_hits += 1;
+            if (poison && !poison_fill(ptr, size)) return false;
+            return true;
+        }
+        g_cache_misses += 1;
+    }
+    hipError_t e = hipMalloc(&ptr, bytes);
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {  // give the cached blocks back and try once more
+        (void)hipGetLastError();
+        release_alloc_cache();
+        e = hipMalloc(&ptr, bytes);
+    }
+    if (!hip_ok(e, "hipMalloc")) {
         ptr = nullptr;
         return false;
     }
     size = bytes;
+    device = dev;
+    if (poison && !poison_fill(ptr, size)) return false;
     return true;
 }
 bool DeviceBuf::reserve(size_t bytes, bool* grew) {
@@ -203,7 +319,16 @@ bool DeviceBuf::reserve(size_t bytes, bool* grew) {
     return true;
 }
 void DeviceBuf::release() {
-    if (ptr) (void)hipFree(ptr);
+    if (ptr) {
+        if (size >= kCacheMin && cache_on()) {
+            // hipFree waits for the device before it lets a buffer go; a cached block may be handed to another thread at once, so
+            // this waits too (whoever must not wait -- the sweep's pool while passes are in flight -- never frees, engine_hip.hip)
+            (void)hipDeviceSynchronize();
+            free_blocks(cache_put(device, ptr, size));
+        } else {
+            (void)hipFree(ptr);
+        }
+    }
     ptr = nullptr;
     size = 0;
 }

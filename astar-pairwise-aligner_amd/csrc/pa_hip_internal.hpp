@@ -19,9 +19,12 @@ void set_error(const char* fmt, ...);
 bool hip_ok(hipError_t e, const char* what);
 bool ensure_device();
 
+void release_alloc_cache();  // the cached device blocks back to the driver (pa_release_pools)
+
 struct DeviceBuf {
     void* ptr = nullptr;
     size_t size = 0;
+    int device = 0;  // the device ptr lives on
     DeviceBuf() = default;
     DeviceBuf(const DeviceBuf&) = delete;
     DeviceBuf& operator=(const DeviceBuf&) = delete;

@@ -83,8 +83,13 @@ int pa_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, con
 int pa_runtime_hints(void);
 
 /* pa_align and the astarpa-c symbols keep device buffers, pinned staging and streams in per-thread pools that only grow (after one
- * 10 Mbp alignment: gigabytes).  This frees the calling thread's pools; the next call builds them again. */
+ * 10 Mbp alignment: gigabytes).  This frees the calling thread's pools; the next call builds them again.
+ * It also returns the library's cache of large device buffers to the driver: a device buffer of 16 MB or more is kept when its
+ * batch or pool lets go of it and handed to the next request it fits (hipMalloc + hipFree of a 40 GB block-column store cost about
+ * a second; the cache is bounded at 96 GB, emptied when an allocation fails, off with PA_NO_ALLOC_CACHE=1). */
 void pa_release_pools(void);
+/* Diagnostics of that cache: requests served from it / not served from it, bytes it holds now.  Any argument may be NULL. */
+void pa_alloc_cache_stats(uint64_t* hits, uint64_t* misses, uint64_t* cached_bytes);
 
 #ifdef __cplusplus
 }

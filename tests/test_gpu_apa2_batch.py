@@ -169,3 +169,31 @@ def test_few_long_pairs_take_the_single_pair_engine_and_agree_with_the_kernel_ro
     short = pa.Batch(long_pairs[:1] + [gen_pair(20_000, 0.05, seed=94)], params=gpu_params(pa, oc))  # one short pair: kernel route
     short.align()
     short.close()
+
+
+def test_allocation_cache_reuses_large_buffers_and_leaks_nothing_into_results(pa, oracle):
+    """Large device buffers of a destroyed batch are handed to the next one (pa_astarpa2.h): the second creation is served from the
+    cache, results are those of the oracle whatever the recycled memory held before, pa_release_pools empties it."""
+    from astar_pairwise_aligner_amd import capi
+    from tests.test_gpu_engine import gpu_params
+
+    oc = oracle.params_simple()
+    capi.release_pools()
+    assert capi.alloc_cache_stats()["cached_bytes"] == 0
+    pairs1 = [gen_pair(20_000, 0.05, seed=200 + i) for i in range(48)]
+    pairs2 = [gen_pair(20_000, 0.12, seed=300 + i) for i in range(48)]  # the same sizes, other contents, wider bands
+    s0 = capi.alloc_cache_stats()
+    check(pa, oracle, pairs1, oc, fallbacks=0, verify_only_sample=range(0, 48, 7))
+    s1 = capi.alloc_cache_stats()
+    assert s1["cached_bytes"] >= 16 << 20 and s1["misses"] > s0["misses"]
+    check(pa, oracle, pairs2, oc, fallbacks=0, verify_only_sample=range(0, 48, 5))
+    s2 = capi.alloc_cache_stats()
+    assert s2["hits"] > s1["hits"]
+    bt = pa.Batch(pairs2[:8] + pairs1[:8], trace=True)  # a full-DP traced batch out of the same recycled memory
+    costs, cigars, _, _ = bt.align()
+    bt.close()
+    prm = oracle.make_params(domain="full", heuristic="none", doubling="none", block_width=256, sparse=True, incremental_doubling=False, dt_trace=False)
+    for (a, b), c, g in zip(pairs2[:8] + pairs1[:8], costs, cigars):
+        assert (int(c), g) == oracle.cpu_align(a, b, prm)[:2]
+    capi.release_pools()
+    assert capi.alloc_cache_stats()["cached_bytes"] == 0

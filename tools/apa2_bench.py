@@ -27,6 +27,9 @@ def bench(pairs, label, reps=3):
           f"=> {len(pairs)/best[0]:.0f} pairs/s ({len(pairs)/(best[3]*1e-3):.0f} at the C ABI)  computed lanes {lanes:.3e} = {lanes*256*64/(best[1]*1e-3)/1e9:.0f} band-GCUPS  "
           f"strip VALU instructions (model) {strip_instr:.3e} = {strip_instr/(best[1]*1e-3)/1e9:.0f} G/s  fallbacks {bt.trace_fallbacks()}  tries {sum(s['f_max_tries'] for s in st)/len(st):.2f}", flush=True)
     bt.close()
+    t = time.perf_counter()
+    pa.Batch(pairs, params=pa.AstarPa2Params.simple()).close()
+    print(f"   the same batch created again (large device buffers come from the library's cache): {(time.perf_counter() - t)*1e3:.1f} ms  {pa.capi.alloc_cache_stats()}", flush=True)
     return costs
 
 

@@ -3,8 +3,8 @@
 A second, independent restatement of the reference's TRACED A*PA2 path, written from the Rust text alone and sharing nothing with
 csrc/engine.hpp (the product's host logic, which oracle/engine_cpu.cpp instantiates over the CPU kernels) nor with any kernel of this
 repository: the DP of a block runs on Python big integers.  Covered: Domain::{Astar, Full, GapStart, GapGap}; the NoCost / GapCost /
-SH heuristics (GCSH and pruning are NOT covered -- the `full` preset stays rule-pinned); band doubling, linear search and no doubling
-from every DoublingStart; sparse and dense blocks; incremental doubling (2- and 3-range splits over the stored row of horizontal
+SH / GCSH heuristics (GCSH with exact matches, local pruning and Prune::Start, by its definition: class Gcsh -- so the `full`
+preset is covered too); band doubling, linear search and no doubling from every DoublingStart; sparse and dense blocks; incremental doubling (2- and 3-range splits over the stored row of horizontal
 differences); DT-trace with its x-drop, the re-fill fallback and the parent rules.
 
     astarpa2/src/lib.rs:122-175          cost_or_align                      band.rs:11-24, 100-182   initial_values, exponential / linear search
@@ -76,6 +76,199 @@ def sh_table(a: bytes, b: bytes, k: int):
     return h
 
 
+class Gcsh:
+    """GCSH with exact matches (r = 1), local pruning p and Prune::Start, by its DEFINITION (pa-heuristic/src):
+        seeds           consecutive k-mers of a from 0; potential P(i) = seeds starting at >= i          seeds.rs:34-71, qgrams.rs:99-109
+        matches         every (seed start i, j) with a[i..i+k) == b[j..j+k), pushed for j DEcreasing and, per j, i increasing
+                                                                                                        matches/exact.rs:15-69, qgrams.rs:81-97
+        push filters    T(start) <= T(target), then local pruning (a diagonal-transition look-ahead over the next p seeds)
+                                                                                                        matches.rs:205-247, matches/prepruning.rs:95-203
+        transform       T(i, j) = (i - j - P(i), j - i - P(i)), compared componentwise                  seeds.rs:140-143
+        layers          val(start) = 1 + score(T(end)) over the active matches whose T(end) <= T(target), starts taken in
+                        decreasing (i, j); score(q) = max val over starts s with T(s) >= q, 0 if none   contour/hint_contours.rs:213-272
+        h(u)            P(u) - score(T(u)), or max(gap distance, P(u)) when the score is 0              heuristic/csh.rs:341-376, seeds.rs:81-86
+        prune_block     per seed a window of examined rows: matches of the seed's column whose start row falls into the
+                        block's rows are marked (prune.rs:245-292); the layers are re-derived at the start of the next pass
+                        (update_contours, csh.rs:498-554; domain.rs:365-371), so h does not move during a pass.
+    The reference keeps the layers incrementally; its update re-scores every layer from the lowest touched one upwards, which is the
+    state a fresh construction over the still active matches gives -- that state is what this class computes (with numpy)."""
+
+    def __init__(self, a: bytes, b: bytes, k: int, p: int, prune: bool):
+        import numpy as np
+
+        self.np = np
+        self.a, self.b, self.n, self.m, self.k, self.p, self.prune_on = a, b, len(a), len(b), k, p, prune
+        n, m = self.n, self.m
+        starts = list(range(0, n - k + 1, k))
+        self.seed_starts = starts
+        self.P = [0] * (n + 1)  # potential
+        self.seed_at = [None] * (n + 1)  # index of the seed covering position i (seeds cover [start, end))
+        cur, nxt = 0, len(starts) - 1
+        for i in range(n, -1, -1):
+            if nxt >= 0:
+                if i < starts[nxt] + k:
+                    self.seed_at[i] = nxt
+                if i == starts[nxt]:
+                    cur += 1
+                    nxt -= 1
+            self.P[i] = cur
+        self.t_target = self.T(n, m)
+        # ---- find the matches: hash of a's seeds, all k-mers of b looked up for decreasing j ----
+        table = {}
+        for i in starts:
+            table.setdefault(a[i:i + k], []).append(i)
+        self.next_match_per_diag = {}
+        kept = []
+        for j in range(m - k, -1, -1):
+            for i in table.get(b[j:j + k], ()):
+                ts = self.T(i, j)
+                if not (ts[0] <= self.t_target[0] and ts[1] <= self.t_target[1]):
+                    continue
+                if p != 0 and not self._preserve(i, j):
+                    continue
+                if p != 0:
+                    d = i - j
+                    old = self.next_match_per_diag.get(d, I_MAX)
+                    assert old >= i, "Matches should be added in reverse order on each diagonal"
+                    self.next_match_per_diag[d] = i
+                kept.append((i, j))
+        kept = sorted(set(kept))  # by (i, j); dedup of (start, end)
+        self.mi = np.array([x[0] for x in kept], dtype=np.int64)
+        self.mj = np.array([x[1] for x in kept], dtype=np.int64)
+        self.active = np.ones(len(kept), dtype=bool)
+        Parr = np.array(self.P, dtype=np.int64)
+        self.Parr = Parr
+        self.tsx = self.mi - self.mj - Parr[self.mi] if len(kept) else np.zeros(0, np.int64)
+        self.tsy = self.mj - self.mi - Parr[self.mi] if len(kept) else np.zeros(0, np.int64)
+        pe = Parr[self.mi + k] if len(kept) else np.zeros(0, np.int64)
+        self.tex = self.mi - self.mj - pe
+        self.tey = self.mj - self.mi - pe
+        # the per-seed windows of prune_block (prune.rs:96-102, 166-189): [before0, before1) and, once visited, [after0, after1)
+        self.rng = []
+        idx = 0
+        for s0 in starts:
+            b0 = idx
+            while idx < len(kept) and kept[idx][0] == s0:
+                idx += 1
+            self.rng.append([b0, idx, None, None])
+        self.dirty = False
+        self._build_layers()
+
+    def T(self, i, j):
+        pp = self.P[i]
+        return (i - j - pp, j - i - pp)
+
+    # ---- matches/prepruning.rs:95-203 ----
+    def _extend_right(self, i, j, end_i):  # -> (i, reached end_i); the word-at-a-time version only overshoots when it returns true
+        a, b = self.a, self.b
+        if j < 0:
+            raise AssertionError("local pruning walked above row 0 (the reference would index out of bounds)")
+        while i < end_i and j < self.m and i < self.n and a[i] == b[j]:
+            i += 1
+            j += 1
+        return i, i >= end_i
+
+    def _preserve(self, si, sj):
+        k, p, P = self.k, self.p, self.P
+        e0, e1 = si + k, sj + k
+        start_pot = P[si]
+        seed_idx = self.seed_at[si]
+        last = self.seed_starts[min(seed_idx + p - 1, len(self.seed_starts) - 1)]
+        end_i = last + k
+        end_pot = P[end_i]
+        pd = start_pot - end_pot
+        fr = {pd: e0}
+        fr[pd], done = self._extend_right(fr[pd], e1, end_i)
+        if done:
+            return True
+        if self.next_match_per_diag.get(e0 - e1, I_MAX) <= fr[pd]:
+            return True
+        d0, d1 = pd, pd + 1  # the half-open range of diagonal indices alive
+        for g in range(1, pd):
+            nf = {}
+            for d in range(d0, d1):
+                v = fr[d]
+                nf[d - 1] = max(nf.get(d - 1, -I_MAX), v)
+                nf[d] = max(nf.get(d, -I_MAX), v + 1)
+                nf[d + 1] = max(nf.get(d + 1, -I_MAX), v + 1)
+            fr = nf
+            d0, d1 = d0 - 1, d1 + 1
+            while d0 < d1 and g + P[fr[d0]] >= start_pot:
+                d0 += 1
+            while d0 < d1 and g + P[fr[d1 - 1]] >= start_pot:
+                d1 -= 1
+            if d0 >= d1:
+                return False
+            for d in range(d0, d1):
+                i = fr[d]
+                dd = e0 - e1 + (d - pd)
+                j = i - dd
+                old_i = i
+                fr[d], done = self._extend_right(i, j, end_i)
+                if done:
+                    return True
+                nm = self.next_match_per_diag.get(dd, I_MAX)
+                if old_i <= nm <= fr[d]:
+                    return True
+        return False
+
+    # ---- the layers of the active matches ----
+    def _build_layers(self):
+        np = self.np
+        M = len(self.mi)
+        self.val = np.zeros(M, dtype=np.int64)
+        tx, ty = self.t_target
+        usable = self.active & (self.tex <= tx) & (self.tey <= ty)  # arrows: active, T(end) <= T(target)
+        # starts in decreasing (i, j); all matches of one start position share one value (r = 1: one match per start)
+        done = np.zeros(M, dtype=bool)
+        for t in range(M - 1, -1, -1):
+            if usable[t]:
+                dom = done & (self.tsx >= self.tex[t]) & (self.tsy >= self.tey[t])
+                self.val[t] = 1 + (int(self.val[dom].max()) if dom.any() else 0)
+                done[t] = True
+        self.in_layers = done
+        self.dirty = False
+
+    def score(self, q):
+        dom = self.in_layers & (self.tsx >= q[0]) & (self.tsy >= q[1])
+        return int(self.val[dom].max()) if dom.any() else 0
+
+    def h(self, i, j):
+        sc = self.score(self.T(i, j))
+        if sc == 0:
+            return max(abs((self.n - i) - (self.m - j)), self.P[i])
+        return self.P[i] - sc
+
+    # ---- prune.rs:245-292 (both ranges inclusive: columns i0 + 1 ..= i1 come from the caller's i0..i1) ----
+    def prune_block(self, i0, i1, j0, j1):
+        assert j0 <= j1
+        k = self.k
+        first = -(-(i0 + 1) // k)  # first seed with start >= i0 + 1
+        for sidx in range(max(first, 0), len(self.seed_starts)):
+            col = self.seed_starts[sidx]
+            if col > i1:
+                break
+            r = self.rng[sidx]
+            if r[2] is None:
+                a0 = a1 = r[1]
+                while a0 >= r[0] + 1 and self.mj[a0 - 1] > j1:
+                    r[1] -= 1
+                    a0 -= 1
+                r[2], r[3] = a0, a1
+            while r[1] > r[0] and self.mj[r[1] - 1] >= j0:
+                self.active[r[1] - 1] = False
+                self.dirty = True
+                r[1] -= 1
+            while r[2] < r[3] and self.mj[r[2]] <= j1:
+                self.active[r[2]] = False
+                self.dirty = True
+                r[2] += 1
+
+    def update_contours(self):
+        if self.dirty:
+            self._build_layers()
+
+
 class Block:
     __slots__ = ("v", "i_range", "orig", "j_range", "fixed", "offset", "top", "bot", "j_h")
 
@@ -142,7 +335,8 @@ class Block:
 class Restated:
     def __init__(self, a: bytes, b: bytes, heuristic: str = "gap", k: int = 12, sparse_h: bool = True, block_width: int = 256,
                  dt_trace: bool = True, max_g: int = 40, fr_drop: int = 10, domain: str = "astar", sparse: bool = True,
-                 doubling: str = "band", start: str = "h0", factor: float = 2.0, delta: float = 1.0, incremental_doubling: bool = False):
+                 doubling: str = "band", start: str = "h0", factor: float = 2.0, delta: float = 1.0, incremental_doubling: bool = False,
+                 p: int = 0, prune: bool = False):
         assert all(c in b"ACGT" for c in a) and all(c in b"ACGT" for c in b)
         assert domain in ("astar", "full", "gap_start", "gap_gap") and doubling in ("band", "linear", "none") and start in ("zero", "gap", "h0")
         self.a, self.b, self.n, self.m = a, b, len(a), len(b)
@@ -150,6 +344,8 @@ class Restated:
         self.kind, self.sparse_h, self.bw = (heuristic if domain == "astar" else "none"), sparse_h, block_width
         self.dt, self.max_g, self.fr_drop = dt_trace, max_g, fr_drop
         self.sh = sh_table(a, b, k) if self.kind == "sh" else None
+        self.prune = prune and self.kind == "gcsh"
+        self.gcsh = Gcsh(a, b, k, p, prune) if self.kind == "gcsh" else None
         self.peq = {c: sum(1 << j for j in range(self.m) if b[j] == c) for c in set(a)}  # rows >= m never match (profile.rs:127-132)
         # Blocks (blocks.rs:87-107)
         self.incremental = incremental_doubling
@@ -166,6 +362,8 @@ class Restated:
             return abs((self.n - i) - (self.m - j))
         if self.kind == "sh":
             return self.sh[i]
+        if self.kind == "gcsh":
+            return self.gcsh.h(i, j)
         return 0
 
     # ---- one Myers step per column on an integer `rows` bits tall (myers.rs:27-55) ----
@@ -495,6 +693,8 @@ class Restated:
     # ---- domain.rs:356-541 with trace = true ----
     def align_for_bounded_dist(self, f_max):
         self.st["f_max_tries"] += 1
+        if self.prune:
+            self.gcsh.update_contours()  # pending prunes take effect now (domain.rs:365-371)
         assert f_max is None or f_max >= 0
         first = Block()
         first.fixed = (-1, -1)
@@ -521,6 +721,10 @@ class Restated:
             if nf is not None and _empty(nf):
                 return None
             self.set_last_block_fixed_j_range(nf)
+            if self.prune:  # matches starting in the columns of this block, rows fixed before AND after it (domain.rs:505-515)
+                inter = (max(prev_fixed[0], nf[0]), min(prev_fixed[1], nf[1]))
+                if not _empty(inter):
+                    self.gcsh.prune_block(i_range[0], i_range[1], inter[0], inter[1])
         dist = self.last_block().get(self.m)
         if dist is None:
             return None

@@ -40,6 +40,13 @@ def variants(o):
                                dict(heuristic="none", incremental_doubling=True, dt_trace=False)),
         "gap_incr_f15": (mk(heuristic="gap", incremental_doubling=True, start="zero", factor=1.5),
                          dict(heuristic="gap", incremental_doubling=True, start="zero", factor=1.5)),
+        "full": (o.params_full(), dict(heuristic="gcsh", k=12, p=14, prune=True, incremental_doubling=True)),
+        "gcsh_noprune": (mk(heuristic="gcsh", k=12, p=14, incremental_doubling=True), dict(heuristic="gcsh", k=12, p=14, incremental_doubling=True)),
+        "gcsh_k8_p0_prune": (mk(heuristic="gcsh", k=8, p=0, prune=True), dict(heuristic="gcsh", k=8, p=0, prune=True)),
+        "gcsh_k6_p3_prune_incr": (mk(heuristic="gcsh", k=6, p=3, prune=True, incremental_doubling=True),
+                                  dict(heuristic="gcsh", k=6, p=3, prune=True, incremental_doubling=True)),
+        "gcsh_k10_p5_nosparseh": (mk(heuristic="gcsh", k=10, p=5, prune=True, sparse_h=False, dt_trace=False),
+                                  dict(heuristic="gcsh", k=10, p=5, prune=True, sparse_h=False, dt_trace=False)),
         "gap_gap": (mk(domain="gap_gap", heuristic="none", start="gap"), dict(domain="gap_gap", start="gap")),
         "gap_start": (mk(domain="gap_start", heuristic="none", start="zero"), dict(domain="gap_start", start="zero")),
         "nw": (o.params_nw(), dict(domain="full", doubling="none", sparse=False, dt_trace=False)),
@@ -104,7 +111,7 @@ def test_random_pairs_every_field(oracle):
     assert tally["f_max_tries"] > 900 and tally["regrown"] > 50  # (regrown: pairs whose later passes recomputed blocks over wider ranges)
 
 
-@pytest.mark.parametrize("name", ["simple", "sh12", "dijkstra", "gap_nodt", "gap_incr", "sh12_incr", "gap_incr_f15"])
+@pytest.mark.parametrize("name", ["simple", "sh12", "dijkstra", "gap_nodt", "gap_incr", "sh12_incr", "gap_incr_f15", "full", "gcsh_k8_p0_prune"])
 def test_long_pairs_several_passes(oracle, name):
     prm, kw = variants(oracle)[name]
     for n, e, seed in [(20_000, 0.15, 4), (30_000, 0.08, 5), (12_000, 0.3, 6)]:
@@ -120,3 +127,30 @@ def test_c3_pair_of_the_bench(oracle):
     a, b = gen_pair(100_000, 0.05, seed=3_000_000)
     got = compare(oracle, a, b, *variants(oracle)["simple"])
     assert got[2]["f_max_tries"] == 6 and got[2]["dt_trace_tries"] == 391
+
+
+def test_gcsh_matches_local_pruning_and_h_values(oracle):
+    """GCSH by its definition (restated.Gcsh, numpy) against the engine's (csrc/gcsh.hpp over oracle/engine_cpu.cpp): the matches that
+    survive the transform filter and local pruning, and h at random positions before any pruning."""
+    rnd = random.Random(3)
+    for n, e, k, p, seed in [(3000, 0.08, 6, 5, 7), (5000, 0.05, 12, 14, 8), (2000, 0.2, 5, 3, 9), (4000, 0.1, 8, 14, 10), (6000, 0.15, 10, 2, 11),
+                             (1500, 0.02, 4, 0, 12)]:
+        a, b = gen_pair(n, e, seed)
+        g = restated.Gcsh(a, b, k, p, True)
+        q = [(rnd.randrange(len(a) + 1), rnd.randrange(len(b) + 1)) for _ in range(300)] + [(0, 0), (len(a), len(b))]
+        want_h, want_kept = oracle.gcsh_probe(a, b, k, p, q)
+        assert sorted(map(tuple, want_kept)) == sorted(zip(g.mi.tolist(), g.mj.tolist()))
+        assert [g.h(i, j) for i, j in q] == want_h
+        if p:
+            assert len(g.mi) < len(restated.Gcsh(a, b, k, 0, True).mi)  # (local pruning removed something)
+
+
+def test_c3_pair_of_the_bench_full_preset(oracle):
+    """The 100 kbp pair of the bench through `full` (GCSH k = 12, p = 14, pruning at the start, incremental doubling)."""
+    a, b = gen_pair(100_000, 0.05, seed=3_000_000)
+    prm, kw = variants(oracle)["full"]
+    r = restated.Restated(a, b, **kw)
+    got = r.align()
+    want = oracle.cpu_align(a, b, prm)
+    assert (got[0], got[1]) == want[:2] and {k: got[2][k] for k in KEYS} == {k: want[2][k] for k in KEYS}
+    assert int((~r.gcsh.active).sum()) > 1000  # matches were pruned on the way

@@ -217,3 +217,31 @@ def test_c_abi_is_reentrant_across_threads(pa, oracle):
         for cost, cigar in out:
             assert cost == want[t] and oracle.cigar_verify(cigar, *pairs[t]) == cost
         assert len({c for _, c in out}) == 1  # deterministic
+
+
+def test_gpu_results_equal_the_second_restatement(pa, oracle):
+    """Every GPU route against oracle/astarpa2_restated.py directly (pure Python on big integers, no line shared with csrc/engine.hpp):
+    pa_align with the three presets (the sweep kernel for `simple`, the host-driven HIP engine for `full` and `nw`) and the batched A*PA2."""
+    from oracle import astarpa2_restated as restated
+    from tests.test_restated_engine import KEYS
+
+    kw = {"nw": dict(domain="full", doubling="none", sparse=False, dt_trace=False), "simple": dict(heuristic="gap"),
+          "full": dict(heuristic="gcsh", k=12, p=14, prune=True, incremental_doubling=True)}
+    mk = {"nw": pa.AstarPa2Params.nw, "simple": pa.AstarPa2Params.simple, "full": pa.AstarPa2Params.full}
+    pairs = [gen_pair(n, e, seed=500 + t) for t, (n, e) in enumerate([(700, 0.1), (3000, 0.04), (5000, 0.15), (12_000, 0.08), (20_000, 0.02), (9000, 0.3)])]
+    a, b = pairs[3]
+    pairs.append((a, b[:4000] + b[4600:]))  # a long deletion
+    want = {name: [restated.align(x, y, **kw[name]) for x, y in pairs if name != "nw" or len(x) <= 5000] for name in kw}
+    for name in kw:
+        sel = [p_ for p_ in pairs if name != "nw" or len(p_[0]) <= 5000]
+        al = mk[name]().make_aligner(True)
+        for (x, y), w in zip(sel, want[name]):
+            cost, cigar, stats = al.align_with_stats(x, y)
+            assert (cost, cigar) == w[:2], (name, len(x))
+            assert {k: int(stats[k]) for k in KEYS} == {k: w[2][k] for k in KEYS}, (name, len(x))
+    bt = pa.Batch(pairs, params=pa.AstarPa2Params.simple())
+    costs, cigars, _, _ = bt.align()
+    st = bt.pair_stats()
+    bt.close()
+    for i, w in enumerate(want["simple"]):
+        assert (int(costs[i]), cigars[i]) == w[:2] and {k: int(st[i][k]) for k in KEYS} == {k: w[2][k] for k in KEYS}, i

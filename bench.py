@@ -462,12 +462,29 @@ def main():
                 "kernel": "pa::apa2::apa2_kernel + pa::trace_kernel<true>",
             }
             ba.close()
+            t = time.perf_counter()
+            pa.Batch(ps, params=pa.AstarPa2Params.simple()).close()  # the large device buffers come back from the library's cache
+            leg["create_again_ms"] = round((time.perf_counter() - t) * 1e3, 1)
             return leg
 
         c4a = [generate_pair(10_000, divs[i % 4], seed=1_000_000 + i) for i in range(args.c4_pairs)]
         out["c4_astarpa2_simple"] = apa2_leg(c4a, f"C4: {args.c4_pairs} independent 10 kbp pairs, 1/5/10/15 % divergence, A*PA2 `simple` (band doubling, GapCost, DT-trace): "
                                              "cost + CIGAR + statistics of every pair, strings delivered to the host", range(0, min(args.c4_pairs, 40), 1))
         del c4a
+        # one traced 100 kbp pair through the batch API (goes through the single-pair engine: pa_bitpacking_hip.h)
+        one = [generate_pair(100_000, 0.05, seed=3_000_000)]
+        b1 = pa.Batch(one, params=pa.AstarPa2Params.simple())
+        b1.align()
+        t1 = []
+        for _ in range(3):
+            t = time.perf_counter()
+            c1, g1, _, _ = b1.align()
+            t1.append(time.perf_counter() - t)
+        w1 = _orc.cpu_align(*one[0], _orc.params_simple())
+        assert (int(c1[0]), g1[0]) == w1[:2]
+        b1.close()
+        out["c3_batch_1"] = {"workload": "one 100 kbp pair, 5 %, A*PA2 `simple` with traceback through pa_batch_create_params / pa_batch_align",
+                             "ms": round(min(t1) * 1e3, 3), "cost": int(c1[0])}
         for n3 in args.c3_batch:
             c3a = [generate_pair(100_000, 0.05, seed=3_000_000 + i) for i in range(n3)]
             out[f"c3_batch_{n3}"] = apa2_leg(c3a, f"C3 batched: {n3} independent 100 kbp pairs, 5 % divergence, A*PA2 `simple` with traceback", range(0, min(n3, 2)))

@@ -323,7 +323,11 @@ void DeviceBuf::release() {
         if (size >= kCacheMin && cache_on()) {
             // hipFree waits for the device before it lets a buffer go; a cached block may be handed to another thread at once, so
             // this waits too (whoever must not wait -- the sweep's pool while passes are in flight -- never frees, engine_hip.hip)
+            int cur = device;
+            (void)hipGetDevice(&cur);
+            if (cur != device) (void)hipSetDevice(device);  // (a batch destroyed from a thread bound to another GPU)
             (void)hipDeviceSynchronize();
+            if (cur != device) (void)hipSetDevice(cur);
             free_blocks(cache_put(device, ptr, size));
         } else {
             (void)hipFree(ptr);

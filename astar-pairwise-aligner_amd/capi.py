@@ -55,6 +55,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_runtime_hints.restype = C.c_int
     L.pa_release_pools.restype = None
     L.pa_alloc_cache_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
+    L.pa_batch_params_supported.argtypes = [C.c_void_p]
+    L.pa_batch_params_supported.restype = C.c_int
     L.pa_alloc_cache_stats.restype = None
     L.pa_runtime_hints()  # this package is the application here: more hardware queues, before the first HIP call
     vp, sz = C.c_void_p, C.c_size_t
@@ -161,6 +163,12 @@ def alloc_cache_stats() -> dict:
     h, m, b = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
     load().pa_alloc_cache_stats(C.byref(h), C.byref(m), C.byref(b))
     return {"hits": h.value, "misses": m.value, "cached_bytes": b.value}
+
+
+def batch_params_supported(params) -> bool:
+    """pa_batch_params_supported: does pa_batch_create_params take this AstarPa2Params (the `simple` family)?"""
+    cp = params._to_c()
+    return load().pa_batch_params_supported(C.byref(cp)) == 1
 
 
 def release_pools() -> None:

@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "pa_pairs_read", "pa_pairs_count", "pa_pairs_get", "pa_pairs_free", "pa_write_results_csv", "pa_align_file",
     "pa_align", "pa_batch_align_multi", "pa_batch_create_trace_params",
     "pa_bp_ctx_create", "pa_bp_ctx_compute", "pa_bp_ctx_fill", "pa_bp_ctx_destroy",
-    "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools", "pa_align_file_params", "pa_batch_params_supported", "pa_alloc_cache_stats",
+    "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools", "pa_align_file_params", "pa_batch_params_supported", "pa_alloc_cache_stats", "pa_free_cigars",
 ]
 
 _lib = None
@@ -55,6 +55,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_runtime_hints.restype = C.c_int
     L.pa_release_pools.restype = None
     L.pa_alloc_cache_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
+    L.pa_free_cigars.argtypes = [C.c_void_p, C.c_size_t]
+    L.pa_free_cigars.restype = None
     L.pa_batch_params_supported.argtypes = [C.c_void_p]
     L.pa_batch_params_supported.restype = C.c_int
     L.pa_alloc_cache_stats.restype = None
@@ -354,9 +356,7 @@ def align_multi(pairs: list[tuple[bytes, bytes]], devices: list[int], trace: boo
         try:
             cigars = [C.string_at(cig[i]).decode() if cig[i] else "" for i in range(n)]
         finally:
-            for i in range(n):
-                if cig[i]:
-                    L.astarpa_free_cigar(C.c_void_p(cig[i]))
+            L.pa_free_cigars(cig, n)
     if st is not None:
         from .aligner import _StatsC
 
@@ -426,9 +426,7 @@ class Batch:
                 raise PaError(f"pa_batch_align rc={rc}: {last_error()}")
             cigars = [C.string_at(cig[i]).decode() if cig[i] else "" for i in range(self.pairs)]
         finally:
-            for i in range(self.pairs):
-                if cig[i]:
-                    L.astarpa_free_cigar(C.c_void_p(cig[i]))
+            L.pa_free_cigars(cig, self.pairs)
         return out, cigars, float(fms.value), float(tms.value)
 
     def pair_stats(self) -> list[dict]:

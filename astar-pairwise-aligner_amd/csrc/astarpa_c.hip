@@ -76,3 +76,11 @@ extern "C" uint64_t astarpa_gcsh(const uint8_t* a, uintptr_t a_len, const uint8_
 }
 
 extern "C" void astarpa_free_cigar(uint8_t* cigar) { std::free(cigar); }  // lib.rs:99-101
+// All strings of a batch result at once (bindings: one call instead of one per pair); entries may be NULL, they are set to NULL.
+extern "C" void pa_free_cigars(char** cigars, size_t n) {
+    if (!cigars) return;
+    for (size_t i = 0; i < n; ++i) {
+        std::free(cigars[i]);
+        cigars[i] = nullptr;
+    }
+}

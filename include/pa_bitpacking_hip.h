@@ -135,6 +135,8 @@ struct pa_astarpa2_params;
 pa_batch* pa_batch_create_trace_params(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len,
                                        size_t pairs, const struct pa_astarpa2_params* trace_params);
 int pa_batch_align(pa_batch* plan, int32_t* cost_out, char** cigar_out, float* forward_ms, float* trace_ms);
+/* Releases cigars[0 .. n) of a batch result in one call (entries may be NULL; they are set to NULL). */
+void pa_free_cigars(char** cigars, size_t n);
 /* Pairs (summed over all pa_batch_align calls of this plan) whose traceback was redone by the host engine. */
 size_t pa_batch_trace_fallbacks(const pa_batch* plan);
 

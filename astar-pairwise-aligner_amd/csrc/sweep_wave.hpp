@@ -696,7 +696,7 @@ struct StripProg {
             }
         }
         if (!bot_interior && je_c > row0 && je_c <= rowE) {
-            const uint64_t tq0 = PA_CLK(W);
+            [[maybe_unused]] const uint64_t tq0 = PA_CLK(W);
             bottom_edge(p_end);
             PA_CLK_ADD(t_bottom, W::clock() - tq0);
         }
@@ -981,7 +981,7 @@ struct StripProg {
             if (fin || (kc < c.nblk && t0 == blk_end(c, kc))) {
                 // (last block: the strip below needs my last granule to finish ITS block, which my boundary may wait for)
                 if (fin && has_below && q - q_first >= 3) publish_granule(q - 3);
-                const uint64_t tb0 = PA_CLK(W);
+                [[maybe_unused]] const uint64_t tb0 = PA_CLK(W);
                 const bool okb = boundary_begin();
                 PA_CLK_ADD(t_begin, W::clock() - tb0);
                 if (!okb) return;
@@ -1002,7 +1002,7 @@ struct StripProg {
             } else {
                 vec XS;
                 {
-                    const uint64_t tg0 = PA_CLK(W);
+                    [[maybe_unused]] const uint64_t tg0 = PA_CLK(W);
                     const bool okd = decode_inputs(q, XS);
                     PA_CLK_ADD(t_wait_gran, W::clock() - tg0);
                     if (!okd) return;
@@ -1022,7 +1022,7 @@ struct StripProg {
                 // ---- 32 steps ----
                 const bool tail = t0 + 31 >= c.n;   // some lane runs past the last column: its V freezes there
                 const bool head = q - q_first < 2;  // lanes whose column is still left of the strip's first column do not move
-                const uint64_t tc0 = PA_CLK(W);
+                [[maybe_unused]] const uint64_t tc0 = PA_CLK(W);
                 const int32_t jeb = bot_interior ? INT32_MAX : je_c;
                 const int32_t cl0 = t0 - cx;  // the lane that crosses in step 0 of this chunk (crossing chunks)
                 if (tail || head) {
@@ -1075,7 +1075,7 @@ struct StripProg {
                             if (sc_active) {
                                 const int32_t jh = lane_of(sc_j) - cl0;  // the step in which the scanned row's lane crosses
                                 if (jh == j) {
-                                    const uint64_t tp0 = PA_CLK(W);
+                                    [[maybe_unused]] const uint64_t tp0 = PA_CLK(W);
                                     scan_probe(cl0 + j);
                                     PA_CLK_ADD(t_probe, W::clock() - tp0);
                                     if (!alive) return;
@@ -1104,9 +1104,9 @@ struct StripProg {
                 PA_NOUNROLL
                 while (qq < qs && qq - q_first >= 2) {
                     vec XS;
-                    const uint64_t tg0 = PA_CLK(W);
+                    [[maybe_unused]] const uint64_t tg0 = PA_CLK(W);
                     if (!decode_inputs(qq, XS)) return;
-                    const uint64_t tg1 = PA_CLK(W);
+                    [[maybe_unused]] const uint64_t tg1 = PA_CLK(W);
                     PA_CLK_ADD(t_wait_gran, tg1 - tg0);
                     if (qq - q_first >= 3 && has_below) publish_granule(qq - 3);
                     prefetch_inputs(qq + 1);
@@ -1118,7 +1118,7 @@ struct StripProg {
                 q = qq - 1;
             }
             if (block_done) {
-                const uint64_t te0 = PA_CLK(W);
+                [[maybe_unused]] const uint64_t te0 = PA_CLK(W);
                 boundary_end();
                 PA_CLK_ADD(t_end, W::clock() - te0);
                 if (!alive) return;

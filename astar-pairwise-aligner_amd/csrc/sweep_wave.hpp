@@ -32,7 +32,7 @@
 #if defined(__clang__)
 #define PA_NOUNROLL _Pragma("nounroll")
 #else
-#define PA_NOUNROLL _Pragma("GCC unroll 1")
+#define PA_NOUNROLL  // (host emulation under gcc: its unroll pragma does not apply to while loops, and nothing depends on it there)
 #endif
 
 // Phase clocks (diagnostics): compiled in with -DPA_SWEEP_PHASE_TIMERS only -- eight 64-bit accumulators are 16 scalar registers

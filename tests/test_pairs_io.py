@@ -40,6 +40,58 @@ def test_fasta_format(pa, tmp_path):
         assert pa.read_pairs(g) == [(b"AC", b"AG")]
 
 
+def test_reader_edge_cases(pa, tmp_path):
+    """The reader works on views into the mapped file: no final newline, empty files, CRLF everywhere, sequence data before the first
+    FASTA header, FASTA records compacted in place."""
+    f = tmp_path / "nonl.txt"
+    f.write_bytes(b"ACGT\nAC")  # no newline at the end: still a line
+    assert pa.read_pairs(f) == [(b"ACGT", b"AC")]
+    f = tmp_path / "empty.seq"
+    f.write_bytes(b"")
+    assert pa.read_pairs(f) == []
+    f = tmp_path / "one.seq"
+    f.write_bytes(b">ACGT")  # a lone first line is dropped unchecked
+    assert pa.read_pairs(f) == []
+    f = tmp_path / "crlf.fa"
+    f.write_bytes(b">h1\r\nAC\r\nGT\r\n\r\n>h2\r\nA\r\n>h3\r\n>h4\r\nTTTT")
+    assert pa.read_pairs(f) == [(b"ACGT", b"A"), (b"", b"TTTT")]
+    f = tmp_path / "early.fa"
+    f.write_bytes(b"ACGT\n>h\nAC\n")
+    with pytest.raises(pa.PaError):
+        pa.read_pairs(f)
+    f = tmp_path / "blank_first.fa"
+    f.write_bytes(b"\n\n>h\nAC\n>g\nAG\n")  # empty lines before the first header are no data
+    assert pa.read_pairs(f) == [(b"AC", b"AG")]
+    f = tmp_path / "bad2.seq"
+    f.write_bytes(b">AC\n<AG\n>AC\nAG\n")
+    with pytest.raises(pa.PaError, match="line 3"):
+        pa.read_pairs(f)
+
+
+def test_reader_large_file_equals_a_plain_parse(pa, tmp_path):
+    import random
+
+    rng = random.Random(7)
+    lines = []
+    want = []
+    for i in range(3000):
+        a = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(0, 400)))
+        b = bytes(rng.choice(b"ACGT") for _ in range(rng.randint(0, 400)))
+        want.append((a, b))
+        lines.append(b">" + a + (b"\r\n" if i % 7 == 0 else b"\n") + b"<" + b + b"\n")
+    f = tmp_path / "big.seq"
+    f.write_bytes(b"".join(lines))
+    assert pa.read_pairs(f) == want
+    fa = tmp_path / "big.fa"
+    with fa.open("wb") as out:
+        for i, (a, b) in enumerate(want):
+            for r, s in (("a", a), ("b", b)):
+                out.write(f">rec{i}{r}\n".encode())
+                for k in range(0, len(s), 60):
+                    out.write(s[k:k + 60] + b"\n")
+    assert pa.read_pairs(fa) == want
+
+
 def test_directory_and_unknown_extension(pa, tmp_path):
     d = tmp_path / "in"
     d.mkdir()

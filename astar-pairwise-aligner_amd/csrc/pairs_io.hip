@@ -301,6 +301,7 @@ static int batch_align_queue(const uint8_t* const* a, const size_t* a_len, const
     if (chunk < 256) chunk = 256;
     if (chunk * (size_t)ndevices > pairs) chunk = (pairs + (size_t)ndevices - 1) / (size_t)ndevices;
     if (chunk == 0) chunk = 1;
+    if (ndevices == 1) chunk = std::max<size_t>(pairs, 1);  // one worker: nothing to balance, every chunk more is a batch creation more
     if (const char* e = std::getenv("PA_MULTI_CHUNK")) chunk = std::max<size_t>(1, (size_t)std::atoll(e));  // (tests)
     // ... and no chunk's block-column store (traced batches: one V column per 256 columns of a, full height) beyond ~24 GB
     const double kChunkBytes = 24e9;

@@ -26,7 +26,7 @@ H_DTYPE = np.dtype([("p", "<u8"), ("m", "<u8")])
 BITS_DTYPE = np.dtype([("b0", "<u8"), ("b1", "<u8")])
 
 
-_TARGETS = ("libpa_oracle.so", "libpa_engine_cpu.so", "libpa_sweep_emu.so", "libpa_apa2_emu.so")
+_TARGETS = ("libpa_oracle.so", "libpa_engine_cpu.so", "libpa_sweep_emu.so", "libpa_apa2_emu.so", "libpa_apa2_full_emu.so")
 
 
 def _source_hash() -> str:
@@ -37,7 +37,7 @@ def _source_hash() -> str:
     h = hashlib.sha256()
     csrc = _DIR.parent / "astar-pairwise-aligner_amd" / "csrc"
     files = sorted(list(_DIR.glob("*.c")) + list(_DIR.glob("*.cpp")) + list(_DIR.glob("*.h")) + list(_DIR.glob("*.hpp")) + [_DIR / "Makefile"] +
-                   [csrc / n for n in ("engine.hpp", "gcsh.hpp", "engine_capi.hpp", "sweep_logic.hpp", "sweep_wave.hpp", "sweep_host.hpp", "apa2_logic.hpp")] +
+                   [csrc / n for n in ("engine.hpp", "gcsh.hpp", "engine_capi.hpp", "sweep_logic.hpp", "sweep_wave.hpp", "sweep_host.hpp", "apa2_logic.hpp", "apa2_full_logic.hpp")] +
                    [_DIR.parent / "include" / "pa_astarpa2.h"])
     for f in files:
         h.update(f.name.encode())
@@ -373,6 +373,34 @@ def apa2_emu_align(a: bytes, b: bytes, params: AstarPa2ParamsC):
     stats = AstarPa2StatsC()
     info = np.zeros(8, np.int32)
     rc = _alib.pa_apa2_emu_align(_buf(a), len(a), _buf(b), len(b), C.byref(params), C.byref(cost), C.byref(cig), C.byref(stats), _p(info))
+    s = None
+    if cig.value:
+        s = C.string_at(cig.value).decode()
+        engine_lib().pa_cpu_free(cig)
+    return rc, cost.value, s, stats.as_dict(), info.tolist()
+
+
+_flib = None
+
+
+def apa2_full_emu_align(a: bytes, b: bytes, params: AstarPa2ParamsC):
+    """The flat per-pair program of the whole A*PA2 family (csrc/apa2_full_logic.hpp: any heuristic, incremental doubling, pruning --
+    groundwork for a batched `full`, not yet run by the library) over the CPU oracle kernels.  -> (rc, cost, cigar, stats, info);
+    rc 0 = ran, 1 = outside the program, 2 = gave up (info[0]); info[1] = h calls, info[2] = prune_block calls, info[3] = 3-range
+    splits, info[4] = plain initialisations."""
+    global _flib
+    if _flib is None:
+        build()
+        L = C.CDLL(str(_DIR / "_build" / "libpa_apa2_full_emu.so"))
+        L.pa_apa2_full_emu_align.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(AstarPa2ParamsC), C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_void_p), C.POINTER(AstarPa2StatsC), C.c_void_p]
+        L.pa_apa2_full_emu_align.restype = C.c_int
+        _flib = L
+    cost = C.c_int32(0)
+    cig = C.c_void_p(None)
+    stats = AstarPa2StatsC()
+    info = np.zeros(8, np.int32)
+    rc = _flib.pa_apa2_full_emu_align(_buf(a), len(a), _buf(b), len(b), C.byref(params), C.byref(cost), C.byref(cig), C.byref(stats), _p(info))
     s = None
     if cig.value:
         s = C.string_at(cig.value).decode()

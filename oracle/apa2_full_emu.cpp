@@ -1,0 +1,178 @@
+/*
+ * oracle/apa2_full_emu.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Runs the flat per-pair program of the WHOLE A*PA2 family (astar-pairwise-aligner_amd/csrc/apa2_full_logic.hpp: any heuristic
+ * behind h(i, j), incremental doubling, pruning) without a GPU: block columns live in per-block slots addressed by absolute word
+ * (the layout a device backend uses), the rectangles are computed by the oracle's CPU kernels with the four modes of the
+ * horizontal differences, the heuristic is csrc/gcsh.hpp / engine.hpp's.  tests/test_apa2_full_emu.py compares cost, CIGAR string and
+ * statistics with the host engine and with the second restatement.  The traceback is engine.hpp's Blocks::trace over the blocks the
+ * program left behind.
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../astar-pairwise-aligner_amd/csrc/apa2_full_logic.hpp"
+#include "cpu_backend.hpp"
+
+using namespace pa::engine;
+using namespace pa::apa2;
+using pa_oracle_cpu::CpuBackend;
+
+namespace {
+
+struct FullEmuBackend {
+    CpuBackend& cb;
+    Heuristic& heur;
+    size_t wtot;
+    std::vector<FullRec> rec;
+    std::vector<std::vector<V>> col;  // slot k, absolute words
+    BlockParams bp;
+    uint64_t h_calls = 0, prune_calls = 0, three_range = 0, two_range = 0;
+
+    FullEmuBackend(CpuBackend& c, Heuristic& h, int nblk) : cb(c), heur(h) {
+        wtot = (size_t)(c.m() + 63) / 64;
+        FullRec none;
+        std::memset(&none, 0, sizeof none);
+        none.js = none.je = none.ojs = none.oje = none.fs = none.fe = none.j_h = pa::sweep::kNone;
+        rec.assign((size_t)nblk + 2, none);
+        col.assign((size_t)nblk + 2, std::vector<V>(wtot + 1, V::one()));
+        bp.simd = true;
+        bp.no_ilp = false;
+    }
+    FullRec load_rec(int32_t k) const { return rec[(size_t)k]; }
+    void store_rec(int32_t k, const FullRec& r) { rec[(size_t)k] = r; }
+    int32_t index(int32_t k, const FullRec& r, int32_t j) const {  // block.rs:69-122 (from the top; the first column is all +1)
+        if (k == 0) return j;
+        if (j > r.je) return r.bot_val + (j - r.je);
+        int32_t v = r.top_val, j0 = r.js;
+        while (j0 + 64 <= j) {
+            v += col[(size_t)k][(size_t)j0 / 64].value();
+            j0 += 64;
+        }
+        if (j > j0) v += col[(size_t)k][(size_t)j0 / 64].value_of_prefix(j - j0);
+        return v;
+    }
+    bool in_prev(int32_t k, const FullRec& prev, size_t w) const { return k > 1 && (int32_t)(w * 64) >= prev.js && (int32_t)(w * 64) < prev.je; }
+    void init_plain(int32_t k, const FullRec& prev, const FullRec& cur) {  // blocks.rs:753-769
+        two_range += 1;
+        for (size_t w = (size_t)cur.js / 64; w < (size_t)cur.je / 64; ++w) col[(size_t)k][w] = in_prev(k, prev, w) ? col[(size_t)k - 1][w] : V::one();
+    }
+    void init_preserve(int32_t k, const FullRec& prev, const FullRec& cur, int32_t p0, int32_t p1, int32_t prev_w1) {  // blocks.rs:776-831
+        three_range += 1;
+        const int32_t w0 = cur.js / 64, w1 = cur.je / 64;
+        const int32_t copy_end = w1 < prev_w1 ? w1 : prev_w1;
+        for (int32_t w = w0; w < p0; ++w) col[(size_t)k][(size_t)w] = col[(size_t)k - 1][(size_t)w];
+        for (int32_t w = p1; w < copy_end; ++w) col[(size_t)k][(size_t)w] = col[(size_t)k - 1][(size_t)w];
+        for (int32_t w = copy_end > p1 ? copy_end : p1; w < w1; ++w) col[(size_t)k][(size_t)w] = V::one();
+        (void)prev;
+    }
+    int32_t compute(int32_t k, int32_t i0, int32_t i1, int32_t w0, int32_t w1, int32_t mode) {
+        const HMode hm = mode == kHNone ? HMode::None : mode == kHInput ? HMode::Input : mode == kHUpdate ? HMode::Update : HMode::Output;
+        if (w1 == w0) {  // no rows: what comes in at the top leaves at the bottom
+            int32_t s = 0;
+            if (hm == HMode::None) return i1 - i0;
+            if (hm == HMode::Output)
+                for (int32_t i = i0; i < i1; ++i) cb.h_[(size_t)i] = pa_h_t{1, 0};
+            for (int32_t i = i0; i < i1; ++i) s += (int32_t)cb.h_[(size_t)i].p - (int32_t)cb.h_[(size_t)i].m;
+            return s;
+        }
+        return cb.compute(i0, i1, (size_t)w0, (size_t)w1, col[(size_t)k].data() + w0, hm, bp);
+    }
+    int32_t h(int32_t i, int32_t j) {
+        h_calls += 1;
+        return heur.h(i, j);
+    }
+    void prune_block(int32_t i0, int32_t i1, int32_t j0, int32_t j1) {
+        prune_calls += 1;
+        heur.prune_block(i0, i1, j0, j1);
+    }
+    void update_contours() { heur.update_contours(); }
+};
+
+}  // namespace
+
+// rc 0 = ran; 1 = parameters outside the program (not Domain::Astar over sparse 256-column blocks with a search); 2 = the program
+// gave up (info[0] = its status).  info[1] = h calls, info[2] = prune_block calls, info[3] = 3-range splits, info[4] = plain inits.
+extern "C" int pa_apa2_full_emu_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params* params,
+                                      int32_t* cost_out, char** cigar_out, pa_astarpa2_stats* stats_out, int32_t* info) {
+    if (!params || !params_valid(*params)) return -4;
+    const AstarPa2Params p = params_from_c(*params);
+    const bool ok = p.domain == DomainKind::Astar && p.block_width == 256 && p.front.sparse &&
+                    (p.doubling == DoublingKind::BandDoubling || p.doubling == DoublingKind::LinearSearch);
+    if (!ok || a_len == 0 || b_len == 0) return 1;
+    CpuBackend cb(a, a_len, b, b_len);
+    if (!cb.ok) return -1;
+    if (p.front.incremental_doubling) cb.enable_h_row();
+    std::unique_ptr<Heuristic> heur;
+    if (p.heuristic == HeuristicKind::Gap) heur = std::make_unique<GapCostH>((I)a_len, (I)b_len);
+    else if (p.heuristic == HeuristicKind::SH) heur = std::make_unique<SeedHeuristicH>(a, (I)a_len, b, (I)b_len, p.heuristic_k);
+    else if (p.heuristic == HeuristicKind::GCSH) heur = std::make_unique<GcshHeuristic>(a, (I)a_len, b, (I)b_len, p.heuristic_k, (int)p.heuristic_p, p.prune);
+    else heur = std::make_unique<NoCostH>();
+    FullParams sp;
+    sp.sparse_h = p.sparse_h ? 1 : 0;
+    sp.prune = p.prune ? 1 : 0;
+    sp.incremental = p.front.incremental_doubling ? 1 : 0;
+    sp.doubling = p.doubling == DoublingKind::LinearSearch ? 2 : 1;
+    sp.start = (int32_t)p.start;
+    sp.factor = p.factor;
+    sp.delta = (int32_t)p.delta;
+    const int nblk = ((int)a_len + 255) / 256;
+    FullEmuBackend be(cb, *heur, nblk);
+    PairProgFull<FullEmuBackend> prog(be, sp, (int32_t)a_len, (int32_t)b_len);
+    FullResult res;
+    prog.run(&res);
+    if (info) {
+        info[0] = res.status;
+        info[1] = (int32_t)be.h_calls;
+        info[2] = (int32_t)be.prune_calls;
+        info[3] = (int32_t)be.three_range;
+        info[4] = (int32_t)be.two_range;
+    }
+    if (res.status != kFullOk) return 2;
+    AstarPa2Stats st;
+    if (sp.doubling == 1) {  // lib.rs:158
+        st.block_stats.num_blocks = res.num_blocks;
+        st.block_stats.num_incremental_blocks = res.num_incremental_blocks;
+        st.block_stats.computed_lanes = res.computed_lanes;
+        st.block_stats.unique_lanes = res.unique_lanes;
+    }
+    st.f_max_tries = res.f_max_tries;
+    st.sanity_violations = res.sanity_violations;
+    std::string cig;
+    try {
+        Blocks<CpuBackend> blocks(p.front, true, cb);
+        blocks.blocks.resize((size_t)nblk + 1);
+        const FullRec& r0 = be.rec[0];
+        blocks.blocks[0] = Block::first_col(JRange{r0.ojs, r0.oje}, JRange{r0.js, r0.je});
+        for (int k = 1; k <= nblk; ++k) {
+            const FullRec& r = be.rec[(size_t)k];
+            Block& x = blocks.blocks[(size_t)k];
+            x.i_range = IRange{(k - 1) * 256, k * 256 < (int)a_len ? k * 256 : (int)a_len};
+            x.original_j_range = JRange{r.ojs, r.oje};
+            x.j_range = JRange{r.js, r.je};
+            x.fixed_j_range = JRange{r.fs, r.fe};
+            x.offset = r.js;
+            x.top_val = r.top_val;
+            x.bot_val = r.bot_val;
+            x.v.assign(be.col[(size_t)k].begin() + r.js / 64, be.col[(size_t)k].begin() + r.je / 64);
+        }
+        blocks.last_block_idx = (size_t)nblk;
+        blocks.i_range = IRange{-1, (I)a_len};
+        auto [cg, ts] = blocks.trace(0, 0, (I)a_len, (I)b_len);
+        st.trace_stats = ts;
+        cig = cg.to_string();
+    } catch (const EnginePanic& e) {
+        std::fprintf(stderr, "apa2 full emu: engine panic in trace: %s\n", e.what());
+        return -5;
+    }
+    if (cost_out) *cost_out = res.cost;
+    if (cigar_out) {
+        *cigar_out = (char*)std::malloc(cig.size() + 1);
+        std::memcpy(*cigar_out, cig.c_str(), cig.size() + 1);
+    }
+    if (stats_out) stats_to_c(st, stats_out);
+    return 0;
+}

@@ -37,7 +37,7 @@ def _source_hash() -> str:
     h = hashlib.sha256()
     csrc = _DIR.parent / "astar-pairwise-aligner_amd" / "csrc"
     files = sorted(list(_DIR.glob("*.c")) + list(_DIR.glob("*.cpp")) + list(_DIR.glob("*.h")) + list(_DIR.glob("*.hpp")) + [_DIR / "Makefile"] +
-                   [csrc / n for n in ("engine.hpp", "gcsh.hpp", "engine_capi.hpp", "sweep_logic.hpp", "sweep_wave.hpp", "sweep_host.hpp", "apa2_logic.hpp", "apa2_full_logic.hpp")] +
+                   [csrc / n for n in ("engine.hpp", "gcsh.hpp", "engine_capi.hpp", "sweep_logic.hpp", "sweep_wave.hpp", "sweep_host.hpp", "apa2_logic.hpp", "apa2_full_logic.hpp", "gcsh_flat.hpp")] +
                    [_DIR.parent / "include" / "pa_astarpa2.h"])
     for f in files:
         h.update(f.name.encode())
@@ -387,7 +387,8 @@ def apa2_full_emu_align(a: bytes, b: bytes, params: AstarPa2ParamsC):
     """The flat per-pair program of the whole A*PA2 family (csrc/apa2_full_logic.hpp: any heuristic, incremental doubling, pruning --
     groundwork for a batched `full`, not yet run by the library) over the CPU oracle kernels.  -> (rc, cost, cigar, stats, info);
     rc 0 = ran, 1 = outside the program, 2 = gave up (info[0]); info[1] = h calls, info[2] = prune_block calls, info[3] = 3-range
-    splits, info[4] = plain initialisations."""
+    splits, info[4] = plain initialisations, info[5] = h calls where the flat GCSH probe (gcsh_flat.hpp) disagreed with gcsh.hpp,
+    info[6] = builds of the flat arrays."""
     global _flib
     if _flib is None:
         build()

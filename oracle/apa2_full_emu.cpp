@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../astar-pairwise-aligner_amd/csrc/apa2_full_logic.hpp"
+#include "../astar-pairwise-aligner_amd/csrc/gcsh_flat.hpp"
 #include "cpu_backend.hpp"
 
 using namespace pa::engine;
@@ -30,7 +31,27 @@ struct FullEmuBackend {
     std::vector<FullRec> rec;
     std::vector<std::vector<V>> col;  // slot k, absolute words
     BlockParams bp;
-    uint64_t h_calls = 0, prune_calls = 0, three_range = 0, two_range = 0;
+    uint64_t h_calls = 0, prune_calls = 0, three_range = 0, two_range = 0, flat_mismatch = 0, flat_builds = 0;
+    // the device form of the GCSH probe (gcsh_flat.hpp), cross-checked against gcsh.hpp at every call
+    GcshHeuristic* gcsh = nullptr;
+    GcshFlatStorage flat;
+    std::vector<int32_t> flat_mj;
+    std::vector<uint8_t> flat_active;
+    std::vector<GcshSeedWindow> flat_win;
+    uint64_t prune_mismatch = 0, flat_pruned = 0;
+    void rebuild_flat() {
+        if (!gcsh) return;
+        flat.build(gcsh->layers);
+        flat_builds += 1;
+    }
+    void init_flat_matches() {  // the matches and the per-seed windows as flat arrays (what a device-side prune_block works on)
+        if (!gcsh) return;
+        flat_mj.clear();
+        for (const auto& mt : gcsh->by_start) flat_mj.push_back(mt.j);
+        flat_active.assign(flat_mj.size(), 1);
+        flat_win.clear();
+        for (const auto& ar : gcsh->active_range) flat_win.push_back(GcshSeedWindow{(int32_t)ar.b0, (int32_t)ar.b1, -1, 0});
+    }
 
     FullEmuBackend(CpuBackend& c, Heuristic& h, int nblk) : cb(c), heur(h) {
         wtot = (size_t)(c.m() + 63) / 64;
@@ -83,19 +104,32 @@ struct FullEmuBackend {
     }
     int32_t h(int32_t i, int32_t j) {
         h_calls += 1;
-        return heur.h(i, j);
+        const int32_t v = heur.h(i, j);
+        if (gcsh && gcsh_h(flat.view(gcsh->n, gcsh->m, gcsh->k, gcsh->nseeds), i, j) != v) flat_mismatch += 1;
+        return v;
     }
     void prune_block(int32_t i0, int32_t i1, int32_t j0, int32_t j1) {
         prune_calls += 1;
         heur.prune_block(i0, i1, j0, j1);
+        if (gcsh && gcsh->prune_enabled) {
+            flat_pruned += (uint64_t)gcsh_prune_block(flat_mj.data(), flat_active.data(), flat_win.data(), (int32_t)flat_win.size(), gcsh->k, i0, i1, j0, j1);
+            for (size_t t = 0; t < flat_active.size(); ++t)
+                if ((flat_active[t] != 0) != gcsh->by_start[t].active) prune_mismatch += 1;
+        }
     }
-    void update_contours() { heur.update_contours(); }
+    void update_contours() {
+        const bool was_dirty = gcsh && gcsh->dirty;
+        heur.update_contours();
+        if (was_dirty) rebuild_flat();
+    }
 };
 
 }  // namespace
 
 // rc 0 = ran; 1 = parameters outside the program (not Domain::Astar over sparse 256-column blocks with a search); 2 = the program
-// gave up (info[0] = its status).  info[1] = h calls, info[2] = prune_block calls, info[3] = 3-range splits, info[4] = plain inits.
+// gave up (info[0] = its status).  info[1] = h calls, info[2] = prune_block calls, info[3] = 3-range splits, info[4] = plain inits,
+// info[5] = h calls where the flat (device-form) GCSH probe of gcsh_flat.hpp disagreed with gcsh.hpp, info[6] = times the flat arrays were built,
+// info[7] = match flags on which the flat prune_block (gcsh_flat.hpp) and gcsh.hpp disagreed, summed over the calls.
 extern "C" int pa_apa2_full_emu_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params* params,
                                       int32_t* cost_out, char** cigar_out, pa_astarpa2_stats* stats_out, int32_t* info) {
     if (!params || !params_valid(*params)) return -4;
@@ -121,6 +155,9 @@ extern "C" int pa_apa2_full_emu_align(const uint8_t* a, size_t a_len, const uint
     sp.delta = (int32_t)p.delta;
     const int nblk = ((int)a_len + 255) / 256;
     FullEmuBackend be(cb, *heur, nblk);
+    be.gcsh = dynamic_cast<GcshHeuristic*>(heur.get());
+    be.rebuild_flat();
+    be.init_flat_matches();
     PairProgFull<FullEmuBackend> prog(be, sp, (int32_t)a_len, (int32_t)b_len);
     FullResult res;
     prog.run(&res);
@@ -130,6 +167,9 @@ extern "C" int pa_apa2_full_emu_align(const uint8_t* a, size_t a_len, const uint
         info[2] = (int32_t)be.prune_calls;
         info[3] = (int32_t)be.three_range;
         info[4] = (int32_t)be.two_range;
+        info[5] = (int32_t)be.flat_mismatch;
+        info[6] = (int32_t)be.flat_builds;
+        info[7] = (int32_t)be.prune_mismatch;
     }
     if (res.status != kFullOk) return 2;
     AstarPa2Stats st;

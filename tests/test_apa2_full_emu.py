@@ -19,12 +19,15 @@ def compare(o, a, b, prm, tally=None):
     want = o.cpu_align(a, b, prm)
     rc, cost, cigar, stats, info = o.apa2_full_emu_align(a, b, prm)
     assert rc == 0, (rc, info)
+    assert info[5] == 0, ("the flat GCSH probe disagrees with gcsh.hpp", info)
+    assert info[7] == 0, ("the flat prune_block disagrees with gcsh.hpp", info)
     assert (cost, cigar) == want[:2], (len(a), len(b))
     assert {k: stats[k] for k in KEYS} == {k: want[2][k] for k in KEYS}, (len(a), len(b))
     if tally is not None:
         tally["prunes"] = tally.get("prunes", 0) + info[2]
         tally["three"] = tally.get("three", 0) + info[3]
         tally["tries"] = tally.get("tries", 0) + stats["f_max_tries"]
+        tally["flat_builds"] = tally.get("flat_builds", 0) + info[6]
     return stats, info
 
 
@@ -55,7 +58,7 @@ def test_random_pairs_every_field(oracle):
         elif mode < 0.3:
             b = rand_seq(rng.randint(1, n + 50), it + 9)
         compare(oracle, a, b, vs[name][0], tally)
-    assert tally["prunes"] > 500 and tally["three"] > 100 and tally["tries"] > 800, tally
+    assert tally["prunes"] > 500 and tally["three"] > 100 and tally["tries"] > 800 and tally["flat_builds"] > 150, tally
 
 
 @pytest.mark.parametrize("name", ["full", "gap_incr", "sh12_incr", "gcsh_k6_p3_prune_incr", "simple"])

@@ -12,10 +12,8 @@
 
 #include "sweep_logic.hpp"  // PA_HD
 
-#if !defined(__HIPCC__)
 #include <algorithm>
 #include <vector>
-#endif
 
 namespace pa {
 namespace apa2 {
@@ -104,7 +102,6 @@ PA_HD int32_t gcsh_prune_block(const int32_t* mj, uint8_t* active, GcshSeedWindo
     return pruned;
 }
 
-#if !defined(__HIPCC__)
 // Host: the flat arrays of a set of layers given as point lists (layer 0 = the sentinel, ignored).
 struct GcshFlatStorage {
     std::vector<int32_t> layer_off, px, py;
@@ -147,7 +144,6 @@ struct GcshFlatStorage {
         return g;
     }
 };
-#endif
 
 }  // namespace apa2
 }  // namespace pa

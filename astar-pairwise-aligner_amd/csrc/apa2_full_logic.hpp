@@ -203,7 +203,7 @@ struct PairProgFull {
     // One align_for_bounded_dist (domain.rs:356-541).  true: Some(dist); false: None.  Check `err` afterwards.
     PA_HD bool pass(int32_t f_max, int32_t* dist) {
         f_max_tries += 1;
-        if (sp.prune) be.update_contours();
+        if (sp.prune && !external_update) be.update_contours();
         FullRec none;
         none.js = none.je = none.ojs = none.oje = none.fs = none.fe = none.j_h = kNone;
         none.top_val = none.bot_val = 0;
@@ -310,55 +310,114 @@ struct PairProgFull {
         return (c > 1 ? c : 1) + offset;
     }
 
-    // lib.rs:122-175 + band.rs:100-182
-    PA_HD void run(FullResult* out) {
-        const int32_t h0 = be.h(0, 0);
+    // ---- lib.rs:122-175 + band.rs:100-182, one pass per step ----
+    // The search is resumable: everything it carries from pass to pass is in SearchState (plus the block records and columns the
+    // backend keeps), so a device can run ONE pass per launch and let the host re-derive the contours of the pairs that need another
+    // pass in between (with `external_update` the program does not call update_contours itself).
+    struct SearchState {
+        int32_t h0, offset, s, last_s, maxs, it;
+        int32_t cost, f_ok;
+        int32_t done;  // 0 running, 1 found, 2 gave up (err / bound ran away / too many passes)
+        // what PairProgFull itself carries
+        int32_t last_block_idx, blocks_len, err;
+        uint32_t f_max_tries, sanity, num_blocks, num_incremental;
+        uint64_t computed_lanes, unique_lanes;
+    };
+    bool external_update = false;
+
+    PA_HD void save(SearchState* st) const {
+        st->last_block_idx = last_block_idx;
+        st->blocks_len = blocks_len;
+        st->err = err;
+        st->f_max_tries = f_max_tries;
+        st->sanity = sanity;
+        st->num_blocks = num_blocks;
+        st->num_incremental = num_incremental;
+        st->computed_lanes = computed_lanes;
+        st->unique_lanes = unique_lanes;
+    }
+    PA_HD void load(const SearchState& st) {
+        last_block_idx = st.last_block_idx;
+        blocks_len = st.blocks_len;
+        err = st.err;
+        f_max_tries = st.f_max_tries;
+        sanity = st.sanity;
+        num_blocks = st.num_blocks;
+        num_incremental = st.num_incremental;
+        computed_lanes = st.computed_lanes;
+        unique_lanes = st.unique_lanes;
+    }
+
+    PA_HD void begin(SearchState* st) {
+        st->h0 = be.h(0, 0);
         int32_t start_f = 0, start_inc = 1;
         if (sp.start == 1) {
             start_f = start_inc = sweep::iabs32(n - m);
         } else if (sp.start == 2) {
-            start_f = h0;
+            start_f = st->h0;
             start_inc = 1;
         }
-        const int32_t offset = start_f;
-        int32_t s;
+        st->offset = start_f;
         if (sp.doubling == 2) {
-            s = start_f;
+            st->s = start_f;
         } else {
             if (start_inc < kBlockW) start_inc = kBlockW;
-            s = offset + start_inc;
+            st->s = st->offset + start_inc;
         }
-        int32_t last_s = -1, maxs = INT32_MAX, cost = 0, f_ok = 0;
-        bool done = false;
-        for (int32_t it = 0; it < 4000 && !done && err == kFullOk; ++it) {
-            int32_t dist = 0;
-            const bool some = pass(s, &dist);
-            if (err != kFullOk) break;
+        st->last_s = -1;
+        st->maxs = INT32_MAX;
+        st->it = 0;
+        st->cost = st->f_ok = 0;
+        st->done = 0;
+        save(st);
+    }
+
+    // One pass with the bound st->s; afterwards st->done says whether another step is needed (then st->s is its bound).
+    PA_HD void step(SearchState* st) {
+        load(*st);
+        if (st->done == 0 && (st->it >= 4000 || err != kFullOk)) st->done = 2;
+        if (st->done != 0) return;
+        int32_t dist = 0;
+        const bool some = pass(st->s, &dist);
+        st->it += 1;
+        if (err != kFullOk) {
+            st->done = 2;
+        } else {
+            bool found = false;
             if (some) {
-                if (dist > maxs) sanity += 1;
-                if (dist <= s) {
-                    if (dist <= last_s) sanity += 1;
-                    cost = dist;
-                    f_ok = s;
-                    done = true;
-                    break;
+                if (dist > st->maxs) sanity += 1;
+                if (dist <= st->s) {
+                    if (dist <= st->last_s) sanity += 1;
+                    st->cost = dist;
+                    st->f_ok = st->s;
+                    found = true;
+                } else if (dist < st->maxs) {
+                    st->maxs = dist;
                 }
-                if (dist < maxs) maxs = dist;
-            } else if (maxs != INT32_MAX) {
+            } else if (st->maxs != INT32_MAX) {
                 sanity += 1;
             }
-            const int32_t before = s;
-            last_s = s;
-            const int32_t nx = next_bound(s, offset);
-            s = nx < maxs ? nx : maxs;
-            if (s <= before) s = next_bound(before, offset);
-            if (s < 0 || s > 4 * (n + m) + 8 * kBlockW) break;
+            if (found) {
+                st->done = 1;
+            } else {
+                const int32_t before = st->s;
+                st->last_s = st->s;
+                const int32_t nx = next_bound(st->s, st->offset);
+                st->s = nx < st->maxs ? nx : st->maxs;
+                if (st->s <= before) st->s = next_bound(before, st->offset);
+                if (st->s < 0 || st->s > 4 * (n + m) + 8 * kBlockW) st->done = 2;
+            }
         }
-        if (err == kFullOk && !done) err = kFullErrPasses;
-        if (err == kFullOk && h0 > cost) err = kFullErrH0;
+        save(st);
+    }
+
+    PA_HD void finish(const SearchState& st, FullResult* out) {
+        load(st);
+        if (err == kFullOk && st.done != 1) err = kFullErrPasses;
+        if (err == kFullOk && st.h0 > st.cost) err = kFullErrH0;
         out->status = err;
-        out->cost = cost;
-        out->f_max = f_ok;
+        out->cost = st.cost;
+        out->f_max = st.f_ok;
         out->f_max_tries = f_max_tries;
         out->sanity_violations = sanity;
         out->num_blocks = num_blocks;
@@ -367,6 +426,14 @@ struct PairProgFull {
         out->unique_lanes = unique_lanes;
         out->last_block_idx = last_block_idx;
         out->blocks_len = blocks_len;
+    }
+
+    // The whole search in one go (what a single launch per pair would run).
+    PA_HD void run(FullResult* out) {
+        SearchState st;
+        begin(&st);
+        while (st.done == 0) step(&st);
+        finish(st, out);
     }
 };
 

@@ -158,9 +158,27 @@ extern "C" int pa_apa2_full_emu_align(const uint8_t* a, size_t a_len, const uint
     be.gcsh = dynamic_cast<GcshHeuristic*>(heur.get());
     be.rebuild_flat();
     be.init_flat_matches();
-    PairProgFull<FullEmuBackend> prog(be, sp, (int32_t)a_len, (int32_t)b_len);
     FullResult res;
-    prog.run(&res);
+    if (std::getenv("PA_FULL_EMU_STEPWISE")) {
+        // the orchestration a device needs: ONE pass per "launch" by a program object built afresh from the saved state, the contours
+        // re-derived by the host in between
+        PairProgFull<FullEmuBackend>::SearchState st;
+        {
+            PairProgFull<FullEmuBackend> prog(be, sp, (int32_t)a_len, (int32_t)b_len);
+            prog.begin(&st);
+        }
+        while (st.done == 0) {
+            be.update_contours();  // (host side, between two launches)
+            PairProgFull<FullEmuBackend> prog(be, sp, (int32_t)a_len, (int32_t)b_len);
+            prog.external_update = true;
+            prog.step(&st);
+        }
+        PairProgFull<FullEmuBackend> prog(be, sp, (int32_t)a_len, (int32_t)b_len);
+        prog.finish(st, &res);
+    } else {
+        PairProgFull<FullEmuBackend> prog(be, sp, (int32_t)a_len, (int32_t)b_len);
+        prog.run(&res);
+    }
     if (info) {
         info[0] = res.status;
         info[1] = (int32_t)be.h_calls;

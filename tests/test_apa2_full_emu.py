@@ -80,3 +80,22 @@ def test_c3_pair_full_preset(oracle):
     a, b = gen_pair(100_000, 0.05, seed=3_000_000)
     stats, info = compare(oracle, a, b, oracle.params_full())
     assert stats["f_max_tries"] == 1 and info[2] > 300  # one pass, matches pruned after (almost) every block
+
+
+def test_one_pass_per_launch_orchestration(oracle, monkeypatch):
+    """The search resumed from its saved state, one pass per step by a freshly built program object, the contours re-derived outside
+    the program between two steps (what a kernel launch per pass with host threads in between would do): same results."""
+    monkeypatch.setenv("PA_FULL_EMU_STEPWISE", "1")
+    vs = {k: v for k, v in variants(oracle).items() if k not in OUTSIDE}
+    rng = random.Random(5)
+    tries = 0
+    for it in range(150):
+        name = rng.choice(["full", "gcsh_k6_p3_prune_incr", "gcsh_k8_p0_prune", "gap_incr", "simple", "linear300", "gcsh_k10_p5_nosparseh"])
+        n = rng.choice([rng.randint(1, 300), rng.randint(300, 2500), rng.randint(2500, 9000)])
+        a, b = gen_pair(n, rng.choice([0.0, 0.02, 0.1, 0.2, 0.4]), rng.randint(1, 10**9))
+        if rng.random() < 0.3 and n > 50:
+            cut = rng.randint(0, len(b) - 1)
+            b = (b[:cut] + b[cut + rng.randint(1, max(1, len(b) // 3)):]) or b"A"
+        stats, _ = compare(oracle, a, b, vs[name][0])
+        tries += stats["f_max_tries"]
+    assert tries > 180  # (many of the pairs took more than one step)

@@ -24,12 +24,27 @@ def sources() -> list[Path]:
     return [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()]
 
 
+STAMP_PATH = PKG_DIR / ".libastarpa_c_hip.hash"
+
+
+def source_hash() -> str:
+    """Content hash of everything the library is built from.  File times do not survive the copy to a GPU box in any useful order (a
+    header edited after the last build made the box spend 50 s in hipcc before its first kernel), contents do."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for d in sorted(list(CSRC.glob("*")) + list((PKG_DIR.parent / "include").glob("*.h"))):
+        if d.is_file():
+            h.update(d.name.encode())
+            h.update(d.read_bytes())
+    h.update(os.environ.get("PA_HIPCC_EXTRA", "").encode())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
-    if not LIB_PATH.exists():
+    if not LIB_PATH.exists() or not STAMP_PATH.exists():
         return True
-    t = LIB_PATH.stat().st_mtime
-    deps = list(CSRC.glob("*")) + list((PKG_DIR.parent / "include").glob("*.h"))
-    return any(d.stat().st_mtime > t for d in deps)
+    return STAMP_PATH.read_text().strip() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
@@ -42,4 +57,5 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    STAMP_PATH.write_text(source_hash() + "\n")
     return LIB_PATH

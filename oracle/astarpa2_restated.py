@@ -1,6 +1,6 @@
 """oracle/astarpa2_restated.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
 
-A second, independent restatement of the reference's TRACED A*PA2 path, written from the Rust text alone and sharing nothing with
+A second, independent restatement of the reference's A*PA2 path (traced, and with trace = False its cost-only arms), written from the Rust text alone and sharing nothing with
 csrc/engine.hpp (the product's host logic, which oracle/engine_cpu.cpp instantiates over the CPU kernels) nor with any kernel of this
 repository: the DP of a block runs on Python big integers.  Covered: Domain::{Astar, Full, GapStart, GapGap}; the NoCost / GapCost /
 SH / GCSH heuristics (GCSH with exact matches, local pruning and Prune::Start, by its definition: class Gcsh -- so the `full`
@@ -336,7 +336,7 @@ class Restated:
     def __init__(self, a: bytes, b: bytes, heuristic: str = "gap", k: int = 12, sparse_h: bool = True, block_width: int = 256,
                  dt_trace: bool = True, max_g: int = 40, fr_drop: int = 10, domain: str = "astar", sparse: bool = True,
                  doubling: str = "band", start: str = "h0", factor: float = 2.0, delta: float = 1.0, incremental_doubling: bool = False,
-                 p: int = 0, prune: bool = False):
+                 p: int = 0, prune: bool = False, trace: bool = True):
         assert all(c in b"ACGT" for c in a) and all(c in b"ACGT" for c in b)
         assert domain in ("astar", "full", "gap_start", "gap_gap") and doubling in ("band", "linear", "none") and start in ("zero", "gap", "h0")
         self.a, self.b, self.n, self.m = a, b, len(a), len(b)
@@ -349,6 +349,7 @@ class Restated:
         self.peq = {c: sum(1 << j for j in range(self.m) if b[j] == c) for c in set(a)}  # rows >= m never match (profile.rs:127-132)
         # Blocks (blocks.rs:87-107)
         self.incremental = incremental_doubling
+        self.trace_mode = trace  # false: the cost-only arms of Blocks (blocks.rs:160-171, 252-277) -- one block updated in place
         self.hrow = [(0, 0)] * self.n if incremental_doubling else []  # horizontal differences (p, m) of the row j_h, per column
         self.blocks: list[Block] = []
         self.last = 0
@@ -440,6 +441,9 @@ class Restated:
         assert initial[0] == 0
         bl.v = [ONE] * ((initial[1] - initial[0]) // W)
         bl.i_range, bl.orig, bl.j_range, bl.fixed, bl.offset, bl.top, bl.bot = (-1, 0), fixed, initial, fixed, 0, 0, initial[1] - initial[0]
+        if not self.trace_mode:  # one block spanning the entire first column (blocks.rs:160-171)
+            bl.v = [ONE] * (-(-self.m // W))
+            bl.bot = initial[1]
         if not self.blocks:
             self.blocks.append(bl)
         else:
@@ -487,6 +491,12 @@ class Restated:
         self._push_i(i_range)
         prev_top = self.last_block().index(jr[0])
         prev_bot = self.last_block().index(jr[1])
+        if not self.trace_mode and not self.incremental:  # blocks.rs:252-277: the single block's v updated in place
+            bl = self.blocks[self.last]
+            bot = prev_bot + self.compute_block(i_range, v_range, bl.v, v_range[0] - bl.offset // W)
+            bl.i_range, bl.orig, bl.j_range = i_range, orig, jr
+            bl.top, bl.bot = prev_top + (i_range[1] - i_range[0]), bot
+            return
         if self.last + 1 == len(self.blocks):
             self.blocks.append(Block())
         else:
@@ -728,7 +738,7 @@ class Restated:
         dist = self.last_block().get(self.m)
         if dist is None:
             return None
-        if f_max is None or dist <= f_max:
+        if self.trace_mode and (f_max is None or dist <= f_max):
             return dist, self.trace((0, 0), (self.n, self.m))
         return dist, None
 

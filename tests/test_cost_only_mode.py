@@ -38,3 +38,35 @@ def test_cost_only_restatement_agrees_with_the_engine_elsewhere(oracle):
         st = CostOnly(a, b, heur, 12, True)
         assert st.cost() == want[0] == oracle.levenshtein(a, b)
         assert (st.f_max_tries, st.computed_lanes) == (want[2]["f_max_tries"], want[2]["computed_lanes"])
+
+
+def test_cost_only_arms_of_the_second_restatement(oracle):
+    """oracle/astarpa2_restated.py with trace = False (the cost-only arms of Blocks: one block updated in place without incremental
+    doubling, the sparse blocks with it) against the engine's cost-only mode: the upper bound of the soak's pair, and cost, passes and
+    block counters of random pairs over nine parameter sets (GCSH with pruning and incremental doubling among them)."""
+    import random
+
+    from oracle import astarpa2_restated as restated
+    from tests.test_restated_engine import variants
+    from tests.util_seq import gen_pair, rand_seq
+
+    j = json.loads((Path(__file__).resolve().parent / "golden" / "cost_only_pair.json").read_text())
+    a, b = j["a"].encode(), j["b"].encode()
+    got = restated.align(a, b, heuristic="sh", k=12, trace=False)
+    assert got[0] == 11353 and got[1] is None  # (the distance is 11325)
+    keys = ["num_blocks", "num_incremental_blocks", "computed_lanes", "unique_lanes", "f_max_tries"]
+    vs = variants(oracle)
+    rng = random.Random(3)
+    for it in range(250):
+        name = rng.choice(["simple", "sh12", "dijkstra", "gap_incr", "full", "gcsh_k8_p0_prune", "sh12_incr", "linear300", "gcsh_noprune"])
+        n = rng.choice([rng.randint(1, 300), rng.randint(300, 2500), rng.randint(2500, 8000)])
+        a, b = gen_pair(n, rng.choice([0.0, 0.02, 0.1, 0.2, 0.4]), rng.randint(1, 10**9))
+        if rng.random() < 0.3 and n > 50:
+            cut = rng.randint(0, len(b) - 1)
+            ln = rng.randint(1, max(1, min(2000, len(b) // 2)))
+            b = (b[:cut] + b[cut + ln:] if rng.random() < 0.5 else b[:cut] + rand_seq(ln, it) + b[cut:]) or b"A"
+        prm, kw = vs[name]
+        want = oracle.cpu_align(a, b, prm, trace=False)
+        got = restated.align(a, b, trace=False, **kw)
+        assert got[0] == want[0] and got[1] is None, (name, len(a), len(b))
+        assert {k: got[2][k] for k in keys} == {k: want[2][k] for k in keys}, (name, len(a), len(b))

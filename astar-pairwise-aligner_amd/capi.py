@@ -168,9 +168,24 @@ def alloc_cache_stats() -> dict:
 
 
 def batch_params_supported(params) -> bool:
-    """pa_batch_params_supported: does pa_batch_create_params take this AstarPa2Params (the `simple` family)?"""
+    """pa_batch_params_supported: does pa_batch_create_params take this AstarPa2Params (Domain::Astar over sparse 256-column blocks with a
+    search: the `simple` and `full` presets and their relatives)?"""
     cp = params._to_c()
     return load().pa_batch_params_supported(C.byref(cp)) == 1
+
+
+def gcsh_probe(a: bytes, b: bytes, k: int, p: int, queries) -> tuple[list[int], int]:
+    """pa_debug_gcsh_probe (diagnostics): GCSH h at `queries` [(i, j), ..] as the GPU computes it -- contours derived and probed by one
+    wavefront (csrc/apa2_full_kernel.hpp) -- and the number of contour layers."""
+    L = load()
+    L.pa_debug_gcsh_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.pa_debug_gcsh_probe.restype = C.c_int
+    q = np.ascontiguousarray(np.array(queries, np.int32).reshape(-1, 2))
+    out = np.zeros(len(q) + 1, np.int32)
+    rc = L.pa_debug_gcsh_probe(_buf(a), len(a), _buf(b), len(b), k, p, _p(q), len(q), _p(out))
+    if rc != 0:
+        raise PaError(f"pa_debug_gcsh_probe rc={rc}: {last_error()}")
+    return out[:-1].tolist(), int(out[-1])
 
 
 def release_pools() -> None:
@@ -370,7 +385,7 @@ class Batch:
     def __init__(self, pairs: list[tuple[bytes, bytes]], trace: bool = False, band: float | None = None, trace_params=None, params=None):
         """band: expected edit rate (e.g. 0.05) -> diagonal-band DP, re-run wider where it was too narrow (still exact).
         trace_params: an AstarPa2Params whose `front` (dt_trace, max_g, fr_drop) the batched traceback follows.
-        params: an AstarPa2Params of the `simple` family -> batched A*PA2 (pa_batch_create_params): align() returns what a loop over
+        params: an AstarPa2Params of the `simple` or `full` family -> batched A*PA2 (pa_batch_create_params): align() returns what a loop over
         AstarPa2(params).align(a, b) returns, pair_stats() the statistics."""
         L = load()
         self._keep = pairs

@@ -1,0 +1,417 @@
+// apa2_full_kernel.hpp -- the gfx950 backend of apa2_full_logic.hpp: ONE WAVEFRONT runs the whole band search of one pair for the
+// WHOLE A*PA2 family -- AstarPa2Params::full() (GCSH k = 12 with local pruning p = 14, pruning of matches between blocks, incremental
+// doubling with the stored row of horizontal differences; astarpa2/src/params.rs:98-128) and every other Domain::Astar parameter set
+// over sparse 256-column blocks that apa2_kernel.hpp does not take.
+//
+// What it replaces: `for (a, b) in pairs { aligner.align(a, b) }` (pa-bin/src/main.rs:24-35) over astarpa2/src/lib.rs:122-175,
+// band.rs:100-182, domain.rs:117-541, blocks.rs:146-469 and, per probe / block / pass, pa-heuristic's csh.rs:341-376 (h),
+// prune.rs:245-292 (prune_block) and csh.rs:497-554 + contour/hint_contours.rs:213-272 (contours re-derived).
+//
+// MI355X-first shape (next to what apa2_kernel.hpp already does: persistent grid, pairs by ticket, strips of strip_kernel.hpp, block
+// columns in HBM at their absolute words, wave-parallel Block::index):
+//  * The heuristic lives on the GPU.  A contour layer is a short linked list whose newest point sits inline in the layer's 16-byte
+//    record (gcsh_dev.hpp); one probe of h(i, j) tests 64 LAYERS AT ONCE, one per lane, in a window around the previous answer --
+//    layers are nested, so the score is the highest lane that says yes; a window that misses is followed by 64-ary bracketing.
+//    The reference's hinted linear probe (hint_contours.rs:283-344) becomes one load round.
+//  * The contours are (re-)derived by the same wavefront: matches from the last start to the first, one wave-parallel score each
+//    (hint_contours.rs:213-255); between two passes the pruned matches are simply left out (csh.rs:525-545 reaches the same layers).
+//  * prune_block: one lane per seed of the block (at most 64 seeds per 256 columns for k >= 4) runs the two-pointer windows of
+//    prune.rs:245-292.
+//  * Incremental doubling WITHOUT extra strips: the rows above and below the stored row j_h -- HMode::Output + HMode::Input, or
+//    HMode::Update + HMode::Input (blocks.rs:406-468), two operator calls in the reference -- run as ONE strip whose lane at row j_h
+//    "taps" its outgoing horizontal deltas into the stored row (run_strip<.., TAP>): a block of `full` (about ten 64-row words) is one
+//    half-wave strip, as in the `simple` kernel.
+//  * The probing loops of j_range / fixed_j_range stay literal (GCSH with local pruning is not consistent: a jump may skip rows that
+//    would pass, and the reference's results depend on where the probes land).
+#pragma once
+#include "apa2_full_logic.hpp"
+#include "apa2_kernel.hpp"
+#include "gcsh_dev.hpp"
+#include "strip_kernel.hpp"
+
+namespace pa {
+namespace apa2 {
+
+enum : int32_t { kFullHeurNone = 0, kFullHeurGap = 1, kFullHeurSH = 2, kFullHeurGcsh = 3 };  // engine.hpp HeuristicKind
+
+struct FullJob {
+    const uint32_t* a_codes;  // packed 2-bit codes of a
+    const uint32_t* b_prof;   // BitProfile words of b, u32 view
+    BlockRec* rec;            // [nblk + 2] persistent block records (the traceback reads them: trace_kernel.hpp)
+    int32_t* jh;              // [nblk + 2] row of the stored horizontal differences per block (Block::j_h), kNone: none
+    uint32_t* col;            // column store: slot k = col + k * col_stride * 4, indexed by absolute word
+    int64_t col_stride;
+    uint8_t* hrow;            // [n] the stored row: one byte per column, bit0 = +1, bit1 = -1 (blocks.rs:103-105)
+    const int32_t* sh_h;      // SH: h(i) for i = 0..n
+    uint64_t* gran;           // 2 rows x 8 granules, zero between uses
+    int32_t* sum;             // scratch: bottom-row sum of the last strip
+    PairResult* result;
+    GcshDev g;                // GCSH
+    int32_t n, m, heur, pad;
+};
+
+typedef int32_t pa_i32x4 __attribute__((ext_vector_type(4)));
+
+struct FullDevBackend {
+    const FullJob& job;
+    GcshDev g;
+    uint32_t* err;
+    uint32_t* dbg;
+    int lane;
+    int32_t hint = 0;      // the last score (the next probe's window is centred on it)
+    bool dirty = false;    // matches were pruned since the contours were derived
+    mutable uint32_t strip_units = 0;
+    uint32_t n_probe = 0, n_round = 0;  // diagnostics: h probes and the load rounds they took
+
+    __device__ __forceinline__ FullDevBackend(const FullJob& j, uint32_t* e, uint32_t* d) : job(j), g(j.g), err(e), dbg(d) { lane = (int)(threadIdx.x & 63); }
+    __device__ __forceinline__ uint64_t strip_instructions() const { return (uint64_t)strip_units << 5; }
+    __device__ __forceinline__ int32_t uniform(int32_t x) const { return (int32_t)rfl((uint32_t)x); }
+    __device__ __forceinline__ bool failed() const { return rfl(__hip_atomic_load((const PA_GLOBAL uint32_t*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != PA_ERR_NONE; }
+    __device__ __forceinline__ gu32 slot(int32_t k) const { return (gu32)job.col + (size_t)k * (size_t)job.col_stride * 4; }
+    __device__ __forceinline__ void sync_mem() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }  // same wavefront writes, then reads
+
+    // ---- block records --------------------------------------------------------------------------------------------------------
+    __device__ __forceinline__ FullRec load_rec(int32_t k) const {
+        const PA_GLOBAL int32_t* p = (const PA_GLOBAL int32_t*)job.rec + (size_t)k * 8;
+        const PA_GLOBAL int32_t* q = (const PA_GLOBAL int32_t*)job.jh + k;
+        const int32_t x = lane < 8 ? p[lane] : (lane == 8 ? q[0] : 0);
+        FullRec r;
+        r.js = __builtin_amdgcn_readlane(x, 0);
+        r.je = __builtin_amdgcn_readlane(x, 1);
+        r.ojs = __builtin_amdgcn_readlane(x, 2);
+        r.oje = __builtin_amdgcn_readlane(x, 3);
+        r.fs = __builtin_amdgcn_readlane(x, 4);
+        r.fe = __builtin_amdgcn_readlane(x, 5);
+        r.top_val = __builtin_amdgcn_readlane(x, 6);
+        r.bot_val = __builtin_amdgcn_readlane(x, 7);
+        r.j_h = __builtin_amdgcn_readlane(x, 8);
+        r.pad[0] = r.pad[1] = r.pad[2] = 0;
+        return r;
+    }
+    __device__ __forceinline__ void store_rec(int32_t k, const FullRec& r) const {
+        // every lane stores the same bytes (see apa2_kernel.hpp: no lane-dependent select chain, no divergent branch)
+        PA_GLOBAL pa_i32x4* p = (PA_GLOBAL pa_i32x4*)((PA_GLOBAL int32_t*)job.rec + (size_t)k * 8);
+        const pa_i32x4 lo = {r.js, r.je, r.ojs, r.oje}, hi = {r.fs, r.fe, r.top_val, r.bot_val};
+        p[0] = lo;
+        p[1] = hi;
+        ((PA_GLOBAL int32_t*)job.jh)[k] = r.j_h;
+        sync_mem();
+    }
+
+    // ---- Block::index (block.rs:69-122) -----------------------------------------------------------------------------------------
+    __device__ __forceinline__ int32_t prefix(int32_t k, int32_t w_from, int32_t w_end, int32_t j) const {
+        const gcu32 c = (gcu32)slot(k);
+        const int32_t full = j >> 6, rem = j & 63;
+        int32_t acc = 0;
+        for (int32_t base = w_from; base <= full; base += 64) {
+            const int32_t wi = base + lane;
+            if (wi < full || (wi == full && rem != 0)) {
+                uint64_t p = ~0ull, mm = 0ull;
+                if (wi < w_end) {
+                    p = (uint64_t)c[(size_t)wi * 4 + 0] | ((uint64_t)c[(size_t)wi * 4 + 1] << 32);
+                    mm = (uint64_t)c[(size_t)wi * 4 + 2] | ((uint64_t)c[(size_t)wi * 4 + 3] << 32);
+                }
+                const uint64_t mask = wi < full ? ~0ull : ((1ull << rem) - 1ull);
+                acc += __builtin_popcountll(p & mask) - __builtin_popcountll(mm & mask);
+            }
+        }
+        return wsum(acc);
+    }
+    __device__ __forceinline__ int32_t index(int32_t k, const FullRec& r, int32_t j) const {
+        if (k == 0) return j;
+        if (j > r.je) return r.bot_val + (j - r.je);
+        return r.top_val + prefix(k, r.js >> 6, r.je >> 6, j);
+    }
+
+    // ---- the left edge of a block (blocks.rs:753-831) -----------------------------------------------------------------------------
+    __device__ __forceinline__ void put_word(gu32 dst, gcu32 src, int32_t wi, bool copy) const {
+        uint32_t x0 = 0xFFFFFFFFu, x1 = 0xFFFFFFFFu, x2 = 0u, x3 = 0u;
+        if (copy) {
+            x0 = src[(size_t)wi * 4 + 0];
+            x1 = src[(size_t)wi * 4 + 1];
+            x2 = src[(size_t)wi * 4 + 2];
+            x3 = src[(size_t)wi * 4 + 3];
+        }
+        dst[(size_t)wi * 4 + 0] = x0;
+        dst[(size_t)wi * 4 + 1] = x1;
+        dst[(size_t)wi * 4 + 2] = x2;
+        dst[(size_t)wi * 4 + 3] = x3;
+    }
+    __device__ __forceinline__ void init_plain(int32_t k, const FullRec& prev, const FullRec& cur) const {
+        const int32_t w0 = cur.js >> 6, w1 = cur.je >> 6, pw0 = prev.js >> 6, pw1 = prev.je >> 6;
+        const gu32 dst = slot(k);
+        const gcu32 src = (gcu32)slot(k > 0 ? k - 1 : 0);
+        for (int32_t wi = w0 + lane; wi < w1; wi += 64) put_word(dst, src, wi, k > 1 && wi >= pw0 && wi < pw1);
+        sync_mem();
+    }
+    // words [p0, p1) of slot k stay as the older pass left them; [w0, p0) and [p1, min(w1, prev_w1)) come from the previous block
+    // (the first column is all +1), the rest is V::one()
+    __device__ __forceinline__ void init_preserve(int32_t k, const FullRec&, const FullRec& cur, int32_t p0, int32_t p1, int32_t prev_w1) const {
+        const int32_t w0 = cur.js >> 6, w1 = cur.je >> 6;
+        const int32_t copy_end = w1 < prev_w1 ? w1 : prev_w1;
+        const gu32 dst = slot(k);
+        const gcu32 src = (gcu32)slot(k > 0 ? k - 1 : 0);
+        for (int32_t wi = w0 + lane; wi < w1; wi += 64) {
+            if (wi >= p0 && wi < p1) continue;
+            put_word(dst, src, wi, k > 1 && (wi < p0 || wi < copy_end));
+        }
+        sync_mem();
+    }
+
+    // ---- the DP of a block: one range of rows, see apa2_full_logic.hpp `compute2` --------------------------------------------------
+    __device__ __forceinline__ int32_t row_sum(int32_t i0, int32_t i1) const {
+        const gcu8 hr = (gcu8)job.hrow;
+        int32_t acc = 0;
+        for (int32_t i = i0 + lane; i < i1; i += 64) {
+            const uint32_t b = hr[i];
+            acc += (int32_t)(b & 1u) - (int32_t)((b >> 1) & 1u);
+        }
+        return wsum(acc);
+    }
+    __device__ __forceinline__ int32_t compute2(int32_t k, int32_t i0, int32_t i1, int32_t w0, int32_t wt, int32_t w1, bool hin, bool tap) const {
+        const int32_t words = w1 - w0;
+        if (tap && !hin && wt == w0) {  // an empty HMode::Output range: the stored row becomes the +1 row it was given (blocks.rs:443-455)
+            for (int32_t i = i0 + lane; i < i1; i += 64) ((gu8)job.hrow)[i] = 1;
+            sync_mem();
+        }
+        if (words <= 0) return hin ? row_sum(i0, i1) : i1 - i0;  // no rows: the bottom row is the top row
+        const bool tap_inside = tap && wt > w0;
+        int32_t done = 0;
+        for (int32_t st = 0; done < words; ++st) {
+            const int32_t left = words - done;
+            const int32_t kk = left > 32 ? 2 : 1;  // lane = 32 or 64 rows: the tap can sit on any 64-row boundary
+            const int32_t take = left < 32 * kk ? left : 32 * kk;
+            const bool last = done + take >= words;
+            const int32_t sw0 = w0 + done;
+            StripJob j;
+            j.a_codes = job.a_codes;
+            j.b_prof = job.b_prof;
+            j.v = job.col + (size_t)k * (size_t)job.col_stride * 4;
+            j.hin_gran = st > 0 ? job.gran + (size_t)((st - 1) & 1) * 8 : nullptr;
+            j.hin_arr = (st == 0 && hin) ? job.hrow : nullptr;
+            j.hout_gran = last ? nullptr : job.gran + (size_t)(st & 1) * 8;
+            j.hout_arr = job.hrow;  // (TAP: written only when tap_lane >= 0)
+            j.values = nullptr;
+            j.sum_out = last ? job.sum : nullptr;
+            j.n = i1 - i0;
+            j.word0 = sw0;
+            j.nlanes = 2 * take;
+            j.fill_stride = 0;
+            j.fill_word0 = 0;
+            j.exact_tail = last ? 0 : 1;
+            j.flags = 0;
+            j.col0 = i0;
+            j.tail_rows = -1;
+            j.k = kk;
+            j.ckpt = nullptr;
+            j.ckpt_stride = 0;
+            j.hin_n = 0;
+            j.vsum_out = nullptr;
+            // the tap: the deltas leaving the lane whose last row is 64 wt - 1, if that row is in this strip
+            int tl = -1;
+            if (tap_inside && wt > sw0 && wt <= sw0 + take) tl = kk == 2 ? (wt - sw0) - 1 : 2 * (wt - sw0) - 1;
+            if (kk == 2) run_strip<2, false, false, false, true, false, false, true, true>(j, err, 0, tl);
+            else if (j.nlanes <= 32) run_strip<1, false, false, false, true, false, true, true, true>(j, err, 0, tl);
+            else run_strip<1, false, false, false, true, false, false, true, true>(j, err, 0, tl);
+            sync_mem();
+            strip_units += (uint32_t)((((i1 - i0 + 31) >> 5) + ((kk == 1 && j.nlanes <= 32) ? 1 : 2)) * (11 + 12 * kk));
+            done += take;
+        }
+        return (int32_t)rfl((uint32_t)*(const PA_GLOBAL int32_t*)job.sum);
+    }
+
+    // ---- the heuristic -------------------------------------------------------------------------------------------------------------
+    __device__ __forceinline__ int32_t pot(int32_t i) const {  // gd_potential with the quotient back in a scalar register
+        if (i < 0 || i > g.n) return 0;
+        const int32_t before = (int32_t)rfl((uint32_t)((i + g.k - 1) / g.k));
+        return before < g.nseeds ? g.nseeds - before : 0;
+    }
+    __device__ __forceinline__ bool contains_lane(int32_t v, int32_t qx, int32_t qy) const {  // per lane: its own layer v >= 1
+        const PA_GLOBAL pa_i32x4* lr = (const PA_GLOBAL pa_i32x4*)g.lrec;
+        const PA_GLOBAL pa_i32x4* cl = (const PA_GLOBAL pa_i32x4*)g.cell;
+        pa_i32x4 c = lr[v];
+        bool hit = c.x >= qx && c.y >= qy;
+        int32_t nx = hit ? -1 : c.z;
+        for (int32_t guard = g.nmatch; nx >= 0 && guard > 0; --guard) {  // (a list is at most nmatch long)
+            c = cl[nx];
+            hit = c.x >= qx && c.y >= qy;
+            nx = hit ? -1 : c.z;
+        }
+        return hit;
+    }
+    // The highest layer that holds a point >= (qx, qy) (hint_contours.rs:258-272): lo is known to hold one (layer 0 holds everything),
+    // hi is known not to (or is past the last layer); 64 layers per round.
+    __device__ __forceinline__ int32_t score(int32_t qx, int32_t qy) {
+        const int32_t nl = g.nlayers;
+        int32_t lo = 0, hi = nl;
+        int32_t stride = 1;
+        int32_t base = hint - 31;
+        if (base > nl - 64) base = nl - 64;
+        if (base < 1) base = 1;
+        n_probe += 1;
+        while (hi - lo > 1) {
+            n_round += 1;
+            const int32_t v = base + lane * stride;
+            const bool valid = v > lo && v < hi;
+            const bool c = valid && contains_lane(v, qx, qy);
+            const uint64_t mv = __ballot(valid), mt = __ballot(c);
+            const uint64_t mf = mv & ~mt;
+            if (mt) lo = base + (63 - __builtin_clzll(mt)) * stride;
+            if (mf) {
+                const int32_t f = base + __builtin_ctzll(mf) * stride;
+                if (f < hi) hi = f;
+            }
+            const int32_t span = hi - lo - 1;
+            if (span <= 0) break;
+            stride = (span + 63) >> 6;
+            base = lo + stride;
+            if (stride == 1) base = lo + 1;
+        }
+        hint = lo;
+        return lo;
+    }
+    __device__ __forceinline__ int32_t h(int32_t i, int32_t j) {
+        if (job.heur == kFullHeurGap) {
+            const int32_t d = (job.n - i) - (job.m - j);
+            return d < 0 ? -d : d;
+        }
+        if (job.heur == kFullHeurSH) return (int32_t)rfl((uint32_t)((const PA_GLOBAL int32_t*)job.sh_h)[i]);
+        if (job.heur != kFullHeurGcsh) return 0;
+        const int32_t p = pot(i);
+        const int32_t val = score(i - j - p, j - i - p);
+        if (val == 0) {  // csh.rs:178-187, seeds.rs:84-89
+            const int32_t d = (g.n - i) - (g.m - j);
+            const int32_t gap = d < 0 ? -d : d;
+            const int32_t pd = p - pot(g.n);
+            return gap > pd ? gap : pd;
+        }
+        return p - val;
+    }
+
+    // Contours from the active matches, last start first (hint_contours.rs:213-255; csh.rs:525-545 reaches the same state).
+    __device__ __forceinline__ void build_contours() {
+        g.nlayers = 1;
+        hint = 0;
+        dirty = false;
+        const int32_t ttx = g.n - g.m - pot(g.n), tty = g.m - g.n - pot(g.n);
+        const PA_GLOBAL int32_t* mi = (const PA_GLOBAL int32_t*)g.mi;
+        const PA_GLOBAL int32_t* mj = (const PA_GLOBAL int32_t*)g.mj;
+        const PA_GLOBAL uint8_t* act = (const PA_GLOBAL uint8_t*)g.active;
+        PA_GLOBAL pa_i32x4* lr = (PA_GLOBAL pa_i32x4*)g.lrec;
+        PA_GLOBAL pa_i32x4* cl = (PA_GLOBAL pa_i32x4*)g.cell;
+        for (int32_t top = g.nmatch - 1; top >= 0; top -= 64) {
+            const int32_t t = top - lane;  // lane 0 holds the last match of this round
+            int32_t sx = 0, sy = 0, ex = 0, ey = 0;
+            bool ok = false;
+            if (t >= 0) {
+                const int32_t i = mi[t], j = mj[t];
+                const int32_t ps = gd_potential(g, i), pe = gd_potential(g, i + g.k);
+                sx = i - j - ps;
+                sy = j - i - ps;
+                ex = i - j - pe;  // T(i + k, j + k)
+                ey = j - i - pe;
+                ok = act[t] != 0 && ex <= ttx && ey <= tty;
+            }
+            uint64_t mask = __ballot(ok);
+            while (mask) {
+                const int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const int32_t qx = __builtin_amdgcn_readlane(ex, l), qy = __builtin_amdgcn_readlane(ey, l);
+                const int32_t px = __builtin_amdgcn_readlane(sx, l), py = __builtin_amdgcn_readlane(sy, l);
+                const int32_t v = score(qx, qy) + 1;
+                pa_i32x4 rec = {px, py, -1, 0};
+                if (v < g.nlayers) {  // the layer's previous newest point moves into this match's cell
+                    cl[top - l] = lr[v];
+                    rec.z = top - l;
+                } else {
+                    g.nlayers = v + 1;
+                }
+                lr[v] = rec;
+                sync_mem();
+            }
+        }
+    }
+    __device__ __forceinline__ void update_contours() {  // csh.rs:497-554, called at the start of a pass (domain.rs:365-371)
+        if (job.heur == kFullHeurGcsh && dirty) build_contours();
+    }
+    // prune.rs:245-292: one lane per seed of the block
+    __device__ __forceinline__ void prune_block(int32_t i0, int32_t i1, int32_t j0, int32_t j1) {
+        if (job.heur != kFullHeurGcsh || !g.prune) return;
+        int32_t s0 = (int32_t)rfl((uint32_t)((i0 + 1 + g.k - 1) / g.k));
+        int32_t s1 = (int32_t)rfl((uint32_t)(i1 / g.k)) + 1;
+        if (s0 < 0) s0 = 0;
+        if (s1 > g.nseeds) s1 = g.nseeds;
+        for (int32_t base = s0; base < s1; base += 64) {
+            const int32_t s = base + lane;
+            int32_t cnt = 0;
+            if (s < s1) cnt = gd_prune_seed(g, s, j0, j1);
+            if (__ballot(cnt > 0)) dirty = true;
+        }
+        sync_mem();
+    }
+};
+
+__device__ __forceinline__ void store_full_result(const FullJob& job, const FullResult& fr, uint64_t strip_instr) {
+    PairResult res;
+    res.status = fr.status == kFullOk ? kOk : (fr.status == kFullErrPasses ? kErrTooManyPasses : (fr.status == kFullErrH0 ? kErrH0 : kErrRangeOrder));
+    res.cost = fr.cost;
+    res.f_max = fr.f_max;
+    res.f_max_tries = fr.f_max_tries;
+    res.sanity_violations = fr.sanity_violations;
+    res.num_blocks = fr.num_blocks;
+    res.num_incremental_blocks = fr.num_incremental_blocks;
+    res.pad0 = 0;
+    res.computed_lanes = fr.computed_lanes;
+    res.unique_lanes = fr.unique_lanes;
+    res.last_block_idx = fr.last_block_idx;
+    res.blocks_len = fr.blocks_len;
+    res.strip_instr = strip_instr;
+    *job.result = res;  // (every lane stores the same 64 bytes)
+}
+
+// Pairs are claimed by ticket in the order of `order` (heaviest first); a block is four independent wavefronts.
+// probe_stats (optional): [0] += h probes, [1] += load rounds they took (diagnostics).
+__global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_full_kernel(const FullJob* __restrict__ jobs, const int32_t* __restrict__ order, int npairs,
+                                                                         FullParams sp, uint32_t* ticket, uint32_t* err, uint32_t* dbg,
+                                                                         unsigned long long* probe_stats) {
+    const int lane = (int)(threadIdx.x & 63);
+    for (;;) {
+        uint32_t t = atomicAdd(ticket, lane == 0 ? 1u : 0u);  // (branch-free: see apa2_kernel.hpp)
+        t = rfl(t);
+        if (t >= (uint32_t)npairs) break;
+        const int pair = (int)rfl((uint32_t)order[t]);
+        const FullJob job = jobs[pair];
+        FullDevBackend be(job, err, dbg);
+        FullResult fr{};
+        if (job.n > 0 && job.m > 0) {
+            if (job.heur == kFullHeurGcsh) be.build_contours();
+            PairProgFull<FullDevBackend> prog(be, sp, job.n, job.m);
+            prog.run(&fr);
+        } else {  // an empty sequence: left to the host engine
+            fr.status = kFullErrOrder;
+        }
+        if (rfl(*(const PA_GLOBAL uint32_t*)err) != PA_ERR_NONE && fr.status == kFullOk) fr.status = kFullErrOrder;
+        store_full_result(job, fr, be.strip_instructions());
+        if (probe_stats) {
+            atomicAdd(probe_stats, lane == 0 ? (unsigned long long)be.n_probe : 0ull);
+            atomicAdd(probe_stats + 1, lane == 0 ? (unsigned long long)be.n_round : 0ull);
+        }
+    }
+}
+
+// Diagnostics / tests: the device heuristic alone.  One wavefront derives the contours of job 0 and evaluates h at nq positions
+// (q[2 t], q[2 t + 1]); out[t] = h, out[nq] = number of layers.  tests/test_gpu_apa2_full.py compares with csrc/gcsh.hpp on the host.
+__global__ __launch_bounds__(64) void gcsh_probe_kernel(const FullJob* __restrict__ jobs, const int32_t* __restrict__ q, int nq, int32_t* __restrict__ out, uint32_t* err) {
+    const FullJob job = jobs[0];
+    FullDevBackend be(job, err, nullptr);
+    be.build_contours();
+    for (int t = 0; t < nq; ++t) {
+        const int32_t i = (int32_t)rfl((uint32_t)q[2 * t]), j = (int32_t)rfl((uint32_t)q[2 * t + 1]);
+        const int32_t v = be.h(i, j);
+        out[t] = v;
+    }
+    out[nq] = be.g.nlayers;
+}
+
+}  // namespace apa2
+}  // namespace pa

@@ -23,8 +23,14 @@
 //   void init_plain(k, prev, cur)                  slot k := prev's words where the ranges overlap, V::one() elsewhere
 //   void init_preserve(k, prev, cur, p0, p1, prev_w1)   words [p0, p1) of slot k stay; [cur.js/64, p0) and [p1, copy_end) come from
 //                                                  slot k - 1, the rest is V::one()   (copy_end = min(cur.je/64, prev_w1))
-//   int32_t compute(k, i0, i1, w0, w1, mode)       columns [i0, i1) over words [w0, w1) of slot k; returns the bottom row's sum
+//   int32_t compute2(k, i0, i1, w0, wt, w1, hin, tap)   columns [i0, i1) over words [w0, w1) of slot k as ONE range; the top row is the
+//                                                  stored row of horizontal differences (hin) or +1; with `tap` the differences of row
+//                                                  64 wt (w0 <= wt <= w1) replace the stored row on the way (wt == w0: the top row
+//                                                  itself).  Returns the bottom row's sum.  In the reference's terms (blocks.rs:662-748):
+//                                                  (!hin, !tap) = None; (hin, !tap) = Input; (!hin, tap) = Output over [w0, wt) then
+//                                                  Input over [wt, w1); (hin, tap) = Update over [w0, wt) then Input over [wt, w1)
 //   int32_t h(i, j); void prune_block(i0, i1, j0, j1); void update_contours()
+//   int32_t uniform(x)                             x, known to be the same in every lane (device: back into a scalar register)
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -129,13 +135,12 @@ struct PairProgFull {
         return v1;
     }
 
-    // One compute_block call (blocks.rs:686-748): statistics + the backend's strips.
-    PA_HD int32_t compute_range(int32_t k, int32_t i0, int32_t i1, int32_t w0, int32_t w1, int32_t mode) {
+    // The statistics of one compute_block call (blocks.rs:686-748).
+    PA_HD void count_range(int32_t i0, int32_t i1, int32_t w0, int32_t w1) {
         if (i1 - i0 > 1) {
             computed_lanes += (uint64_t)(w1 - w0);
             num_incremental += 1;
         }
-        return be.compute(k, i0, i1, w0, w1, mode);
     }
 
     // blocks.rs:205-469 for the sparse traced engine.  `old` = the block an older pass left at this index (js == kNone: none).
@@ -168,7 +173,8 @@ struct PairProgFull {
         const int32_t w0 = cur.js / 64, w1 = cur.je / 64;
         if (!sp.incremental || prev.fs == kNone) {
             be.init_plain(k, prev, cur);
-            cur.bot_val += compute_range(k, i0, i1, w0, w1, kHNone);
+            count_range(i0, i1, w0, w1);
+            cur.bot_val += be.compute2(k, i0, i1, w0, w0, w1, false, false);  // HMode::None
             *out = cur;
             return true;
         }
@@ -187,14 +193,22 @@ struct PairProgFull {
                 err = kFullErrSplit;
                 return false;
             }
+            const int32_t wt = new_j_h / 64;
             be.init_preserve(k, prev, cur, p0, p1, prev.je / 64);
-            compute_range(k, i0, i1, w0, p0, kHNone);
-            if (new_j_h / 64 > p1) compute_range(k, i0, i1, p1, new_j_h / 64, kHUpdate);
-            cur.bot_val += compute_range(k, i0, i1, new_j_h / 64, w1, kHInput);
+            count_range(i0, i1, w0, p0);
+            be.compute2(k, i0, i1, w0, w0, p0, false, false);  // HMode::None
+            // HMode::Update over [p1, wt) (only if not empty) and HMode::Input over [wt, w1): one range from the stored row at the
+            // top, the deltas of row 64 wt stored on the way
+            if (wt > p1) count_range(i0, i1, p1, wt);
+            count_range(i0, i1, wt, w1);
+            cur.bot_val += be.compute2(k, i0, i1, wt > p1 ? p1 : wt, wt, w1, true, wt > p1);
         } else {
+            const int32_t wt = new_j_h / 64;
             be.init_plain(k, prev, cur);
-            compute_range(k, i0, i1, w0, new_j_h / 64, kHOutput);
-            cur.bot_val += compute_range(k, i0, i1, new_j_h / 64, w1, kHInput);
+            // HMode::Output over [w0, wt) (runs even if empty: it sets the stored row) and HMode::Input over [wt, w1): one range
+            count_range(i0, i1, w0, wt);
+            count_range(i0, i1, wt, w1);
+            cur.bot_val += be.compute2(k, i0, i1, w0, wt, w1, false, true);
         }
         *out = cur;
         return true;
@@ -306,7 +320,7 @@ struct PairProgFull {
 
     PA_HD int32_t next_bound(int32_t s, int32_t offset) const {
         if (sp.doubling == 2) return s + sp.delta;
-        const int32_t c = (int32_t)ceilf(sp.factor * (float)(s - offset));
+        const int32_t c = be.uniform((int32_t)ceilf(sp.factor * (float)(s - offset)));  // band.rs:138, f32 (a vector unit on the GPU)
         return (c > 1 ? c : 1) + offset;
     }
 

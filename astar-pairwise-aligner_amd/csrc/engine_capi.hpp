@@ -78,7 +78,9 @@ inline bool params_valid(const pa_astarpa2_params& c) {
            c.heuristic_p >= 0 && c.doubling >= 0 && c.doubling <= 2 &&
            c.doubling_start >= 0 && c.doubling_start <= 2 && c.block_width >= 1 &&
            !(c.doubling == PA_DOUBLING_NONE && c.domain != PA_DOMAIN_FULL) &&
-           !(c.doubling == PA_DOUBLING_LINEAR && c.delta < 1.0f) && c.front.max_g >= 0 &&
+           // a band that does not grow never ends the search (band.rs:138: factor <= 1 or NaN; a delta below 1 or beyond i32)
+           !(c.doubling == PA_DOUBLING_BAND && !(c.factor > 1.0f && c.factor <= 1.0e6f)) &&
+           !(c.doubling == PA_DOUBLING_LINEAR && !(c.delta >= 1.0f && c.delta <= 1073741824.0f)) && c.front.max_g >= 0 &&
            !(c.front.sparse == 0 && c.doubling != PA_DOUBLING_NONE && c.front.incremental_doubling);
 }
 

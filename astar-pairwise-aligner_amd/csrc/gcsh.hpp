@@ -161,7 +161,8 @@ struct GcshHeuristic : Heuristic {
         return false;
     }
 
-    GcshHeuristic(const uint8_t* a_, I n_, const uint8_t* b_, I m_, I k_, int p_, bool prune_)
+    // build_layers = false: the matches and the per-seed windows only (the batched GPU path derives the contours on the device)
+    GcshHeuristic(const uint8_t* a_, I n_, const uint8_t* b_, I m_, I k_, int p_, bool prune_, bool build_layers = true)
         : a(a_), b(b_), n(n_), m(m_), k(k_ < 1 ? 1 : k_), p(p_), prune_enabled(prune_) {
         // seeds + potentials (qgrams.rs:99-109, seeds.rs:34-71)
         nseeds = n >= k ? (n - k) / k + 1 : 0;
@@ -255,7 +256,7 @@ struct GcshHeuristic : Heuristic {
                 active_range.push_back(ar);
             }
         }
-        rebuild_contours();
+        if (build_layers) rebuild_contours();
     }
 
     bool layer_contains(size_t v, TP q) const {

@@ -4,6 +4,9 @@
 #include "engine_capi.hpp"
 #include "trace_kernel.hpp"
 #include "apa2_kernel.hpp"
+#include "apa2_full_kernel.hpp"
+
+#include <sched.h>
 
 #include <algorithm>
 #include <chrono>
@@ -1110,6 +1113,12 @@ struct pa_batch {
     pa_astarpa2_params aparams_c{};
     apa2::SearchParams sp{};
     DeviceBuf d_rec, d_results, d_pjobs, d_order, d_tstats, d_sh;
+    // ... the whole family (pa_batch_create_params with GCSH / pruning / incremental doubling: apa2_full_kernel.hpp)
+    bool astar_full = false;
+    apa2::FullParams fsp{};
+    DeviceBuf d_fjobs, d_jh, d_hrow, d_mi, d_mj, d_active, d_win, d_win0, d_lrec, d_cell, d_probe;
+    size_t full_matches = 0, full_seeds = 0;
+    double full_build_ms = 0;  // host time spent on the matches of the heuristic (reporting)
     std::vector<pa_astarpa2_stats> pair_stats;  // of the last pa_batch_align
     double apa2_strip_instr = 0;  // modelled VALU instructions of the DP strips of the last pa_batch_align (reporting)
     double cells = 0, word_updates = 0, algo_bytes = 0;
@@ -1321,6 +1330,15 @@ static bool apa2_supported(const engine::AstarPa2Params& p) {
            (!p.front.dt_trace || (p.front.max_g >= 1 && p.front.max_g <= kDtMaxG));
 }
 
+// ... and what apa2_full_kernel.hpp takes on top: GCSH, pruning, incremental doubling -- every Domain::Astar parameter set over sparse
+// 256-column blocks with a search around it (AstarPa2Params::full() among them).
+static bool apa2_full_supported(const engine::AstarPa2Params& p) {
+    using namespace engine;
+    return p.domain == DomainKind::Astar && p.block_width == sweep::kBlockW && p.front.sparse &&
+           (p.doubling == DoublingKind::BandDoubling || p.doubling == DoublingKind::LinearSearch) &&
+           (!p.front.dt_trace || (p.front.max_g >= 1 && p.front.max_g <= kDtMaxG));
+}
+
 // The per-pair descriptors of the A*PA2 mode; completes the trace jobs (banded blocks, statistics).
 static bool astar_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t* const* b, std::vector<TraceJob>& tjobs) {
     const engine::AstarPa2Params ap = engine::params_from_c(p->aparams_c);
@@ -1381,6 +1399,175 @@ static bool astar_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t* cons
     return true;
 }
 
+// Host threads for per-pair host work of a batch (the matches of GCSH, the SH tables): as many as the process may run on.
+static unsigned host_threads() {
+    static const unsigned n = [] {
+        if (const char* e = getenv("PA_HOST_THREADS")) return (unsigned)std::max(1, atoi(e));
+        unsigned c = 0;
+#if defined(__linux__)
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0) c = (unsigned)CPU_COUNT(&set);
+#endif
+        if (c == 0) c = std::thread::hardware_concurrency();
+        return std::max(1u, std::min(c, 64u));
+    }();
+    return n;
+}
+template <class F>
+static void parallel_pairs(size_t P, F&& f) {
+    const unsigned nt = (unsigned)std::min<size_t>(host_threads(), std::max<size_t>(P, 1));
+    if (nt <= 1) {
+        for (size_t i = 0; i < P; ++i) f(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&] {
+            for (size_t i = next.fetch_add(1); i < P; i = next.fetch_add(1)) f(i);
+        });
+    for (auto& t : th) t.join();
+}
+
+// The per-pair descriptors of the whole-family mode (apa2_full_kernel.hpp); completes the trace jobs like astar_jobs.
+// The matches of GCSH (seeds, exact k-mer matches in the reference's push order, the transform filter, local pruning p:
+// csrc/gcsh.hpp) are found on host threads; the contours are derived on the device.
+static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t* const* b, std::vector<TraceJob>& tjobs) {
+    const engine::AstarPa2Params ap = engine::params_from_c(p->aparams_c);
+    const size_t P = p->pairs;
+    p->sp.heur = ap.heuristic == engine::HeuristicKind::Gap ? sweep::kHeurGap : (ap.heuristic == engine::HeuristicKind::SH ? sweep::kHeurSH : sweep::kHeurNone);
+    p->sp.sparse_h = ap.sparse_h ? 1 : 0;
+    p->sp.doubling = ap.doubling == engine::DoublingKind::LinearSearch ? apa2::kDoublingLinear : apa2::kDoublingBand;
+    p->sp.start = (int32_t)ap.start;
+    p->sp.factor = ap.factor;
+    p->sp.delta = (int32_t)ap.delta;
+    p->fsp.sparse_h = ap.sparse_h ? 1 : 0;
+    p->fsp.prune = ap.prune ? 1 : 0;
+    p->fsp.incremental = ap.front.incremental_doubling ? 1 : 0;
+    p->fsp.doubling = ap.doubling == engine::DoublingKind::LinearSearch ? 2 : 1;
+    p->fsp.start = (int32_t)ap.start;
+    p->fsp.factor = ap.factor;
+    p->fsp.delta = (int32_t)ap.delta;
+    const bool gcsh = ap.heuristic == engine::HeuristicKind::GCSH, sh = ap.heuristic == engine::HeuristicKind::SH;
+    const int32_t hk = ap.heuristic_k < 1 ? 1 : ap.heuristic_k;
+    std::vector<size_t> rec_off(P), sh_off(P), col_off(P), seed_off(P), match_off(P + 1, 0);
+    size_t tr = 0, tsh = 0, tn = 0, tseeds = 0;
+    for (size_t i = 0; i < P; ++i) {
+        rec_off[i] = tr;
+        tr += (p->n[i] + 255) / 256 + 2;
+        sh_off[i] = tsh;
+        if (sh) tsh += p->n[i] + 1;
+        col_off[i] = tn;
+        tn += (p->n[i] + 63) & ~size_t(63);
+        seed_off[i] = tseeds;
+        if (gcsh) tseeds += p->n[i] >= (size_t)hk ? (p->n[i] - hk) / hk + 1 : 0;
+    }
+    // ---- host threads: the matches (GCSH) / the per-column table (SH) of every pair ----
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::vector<int32_t>> pmi(gcsh ? P : 0), pmj(gcsh ? P : 0);
+    std::vector<apa2::GcshSeedWindow> win(tseeds);
+    std::vector<int32_t> shv(tsh);
+    std::atomic<bool> bad_base{false};
+    if (gcsh || sh)
+        parallel_pairs(P, [&](size_t i) {
+            const engine::I n = (engine::I)p->n[i], m = (engine::I)p->m[i];
+            if (n == 0 || m == 0) return;
+            if (sh) {
+                engine::SeedHeuristicH h(a[i], n, b[i], m, ap.heuristic_k);
+                std::copy(h.h_by_i.begin(), h.h_by_i.end(), shv.begin() + (long)sh_off[i]);
+                return;
+            }
+            engine::GcshHeuristic gh(a[i], n, b[i], m, ap.heuristic_k, (int)ap.heuristic_p, ap.prune, false);
+            pmi[i].reserve(gh.by_start.size());
+            pmj[i].reserve(gh.by_start.size());
+            for (const auto& mt : gh.by_start) {
+                pmi[i].push_back(mt.i);
+                pmj[i].push_back(mt.j);
+            }
+            for (size_t s = 0; s < gh.active_range.size(); ++s)
+                win[seed_off[i] + s] = apa2::GcshSeedWindow{(int32_t)gh.active_range[s].b0, (int32_t)gh.active_range[s].b1, -1, 0};
+        });
+    size_t tm = 0;
+    for (size_t i = 0; i < P; ++i) {
+        match_off[i] = tm;
+        if (gcsh) tm += pmi[i].size();
+    }
+    match_off[P] = tm;
+    p->full_matches = tm;
+    p->full_seeds = tseeds;
+    p->full_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (!p->d_rec.alloc(std::max<size_t>(tr, 1) * sizeof(sweep::BlockRec)) || !p->d_jh.alloc(std::max<size_t>(tr, 1) * 4) ||
+        !p->d_results.alloc(std::max<size_t>(P, 1) * sizeof(apa2::PairResult)) || !p->d_fjobs.alloc(std::max<size_t>(P, 1) * sizeof(apa2::FullJob)) ||
+        !p->d_order.alloc(std::max<size_t>(P, 1) * 4) || !p->d_tstats.alloc(std::max<size_t>(P, 1) * 32) || !p->d_sh.alloc(std::max<size_t>(tsh, 1) * 4) ||
+        !p->d_hrow.alloc(std::max<size_t>(tn, 64)) || !p->d_mi.alloc(std::max<size_t>(tm, 1) * 4) || !p->d_mj.alloc(std::max<size_t>(tm, 1) * 4) ||
+        !p->d_active.alloc(std::max<size_t>(tm, 64)) || !p->d_win.alloc(std::max<size_t>(tseeds, 1) * sizeof(apa2::GcshSeedWindow)) ||
+        !p->d_win0.alloc(std::max<size_t>(tseeds, 1) * sizeof(apa2::GcshSeedWindow)) ||
+        !p->d_lrec.alloc((tm + 2 * std::max<size_t>(P, 1)) * sizeof(apa2::GcshCell)) || !p->d_cell.alloc(std::max<size_t>(tm, 1) * sizeof(apa2::GcshCell)) ||
+        !p->d_probe.alloc(64))
+        return false;
+    if (tsh && !hip_ok(hipMemcpy(p->d_sh.ptr, shv.data(), tsh * 4, hipMemcpyHostToDevice), "H2D sh")) return false;
+    if (tm) {
+        std::vector<int32_t> mi(tm), mj(tm);
+        for (size_t i = 0; i < P; ++i) {
+            std::copy(pmi[i].begin(), pmi[i].end(), mi.begin() + (long)match_off[i]);
+            std::copy(pmj[i].begin(), pmj[i].end(), mj.begin() + (long)match_off[i]);
+        }
+        if (!hip_ok(hipMemcpy(p->d_mi.ptr, mi.data(), tm * 4, hipMemcpyHostToDevice), "H2D matches") ||
+            !hip_ok(hipMemcpy(p->d_mj.ptr, mj.data(), tm * 4, hipMemcpyHostToDevice), "H2D matches"))
+            return false;
+    }
+    if (tseeds && !hip_ok(hipMemcpy(p->d_win0.ptr, win.data(), tseeds * sizeof(apa2::GcshSeedWindow), hipMemcpyHostToDevice), "H2D seed windows")) return false;
+    std::vector<apa2::FullJob> fj(P);
+    std::vector<int32_t> order(P);
+    for (size_t i = 0; i < P; ++i) {
+        const size_t w = (p->m[i] + 63) / 64, nblk = (p->n[i] + 255) / 256;
+        apa2::FullJob& j = fj[i];
+        std::memset(&j, 0, sizeof j);
+        j.a_codes = p->d_codes.as<uint32_t>() + p->code_off[i];
+        j.b_prof = p->d_prof.as<uint32_t>() + p->prof_off[i] * 4;
+        j.rec = p->d_rec.as<sweep::BlockRec>() + rec_off[i];
+        j.jh = p->d_jh.as<int32_t>() + rec_off[i];
+        j.col = p->d_ckpt.as<uint32_t>() + p->ckpt_off[i];
+        j.col_stride = (int64_t)w;
+        j.hrow = p->d_hrow.as<uint8_t>() + col_off[i];
+        j.sh_h = sh ? p->d_sh.as<int32_t>() + sh_off[i] : nullptr;
+        j.gran = p->d_scratch_gran.as<uint64_t>() + i * 16;
+        j.sum = p->d_sums.as<int32_t>() + i;
+        j.result = p->d_results.as<apa2::PairResult>() + i;
+        j.n = (int32_t)p->n[i];
+        j.m = (int32_t)p->m[i];
+        j.heur = (int32_t)ap.heuristic;
+        if (gcsh) {
+            apa2::GcshDev& g = j.g;
+            g.mi = p->d_mi.as<int32_t>() + match_off[i];
+            g.mj = p->d_mj.as<int32_t>() + match_off[i];
+            g.active = p->d_active.as<uint8_t>() + match_off[i];
+            g.win = p->d_win.as<apa2::GcshSeedWindow>() + seed_off[i];
+            g.lrec = p->d_lrec.as<apa2::GcshCell>() + match_off[i] + 2 * i;
+            g.cell = p->d_cell.as<apa2::GcshCell>() + match_off[i];
+            g.nmatch = (int32_t)(match_off[i + 1] - match_off[i]);
+            g.nlayers = 1;
+            g.n = j.n;
+            g.m = j.m;
+            g.k = hk;
+            g.nseeds = j.n >= hk ? (j.n - hk) / hk + 1 : 0;
+            g.prune = ap.prune ? 1 : 0;
+        }
+        TraceJob& t = tjobs[i];
+        t.rec = j.rec;
+        t.res = j.result;
+        t.tstats = p->d_tstats.as<uint32_t>() + 8 * i;
+        t.final_v = p->d_ckpt.as<uint32_t>() + p->ckpt_off[i] + nblk * w * 4;
+        order[i] = (int32_t)i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return p->n[x] + p->m[x] > p->n[y] + p->m[y]; });  // heaviest first
+    if (P && (!hip_ok(hipMemcpy(p->d_fjobs.ptr, fj.data(), P * sizeof(apa2::FullJob), hipMemcpyHostToDevice), "H2D pair jobs") ||
+              !hip_ok(hipMemcpy(p->d_order.ptr, order.data(), P * 4, hipMemcpyHostToDevice), "H2D order")))
+        return false;
+    return true;
+}
+
 static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len, size_t pairs,
                               bool trace, float band_hint = -1.f, int dt_max_g = 0, int dt_fr_drop = 0, const pa_astarpa2_params* astar = nullptr) {
     if (!ensure_device()) return nullptr;
@@ -1399,6 +1586,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
     if (astar) {
         p->astar = true;
         p->aparams_c = *astar;
+        p->astar_full = !apa2_supported(engine::params_from_c(*astar));  // GCSH / pruning / incremental doubling: apa2_full_kernel.hpp
     }
     p->dt_max_g = dt_max_g;
     p->dt_fr_drop = dt_fr_drop;
@@ -1610,7 +1798,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             t.dt_fr_drop = dt_fr_drop;
             src_off[i] = p->cigar_off[i];
         }
-        if (astar && !astar_jobs(p.get(), a, b, tjobs)) return nullptr;
+        if (astar && !(p->astar_full ? astar_full_jobs(p.get(), a, b, tjobs) : astar_jobs(p.get(), a, b, tjobs))) return nullptr;
         if (!hip_ok(hipMemsetAsync(p->d_scratch_gran.ptr, 0, pairs * 16 * 8, p->stream), "memset trace granules") ||
             !hip_ok(hipMemcpyAsync(p->d_tjobs.ptr, tjobs.data(), pairs * sizeof(TraceJob), hipMemcpyHostToDevice, p->stream), "H2D trace jobs") ||
             !hip_ok(hipMemcpyAsync(p->d_cig_src_off.ptr, src_off.data(), pairs * 8, hipMemcpyHostToDevice, p->stream), "H2D offsets") ||
@@ -1693,7 +1881,7 @@ extern "C" pa_batch* pa_batch_create_trace_params(const uint8_t* const* a, const
 
 // 1 if pa_batch_create_params takes these parameters, 0 if they belong to pa_align (or are invalid).
 extern "C" int pa_batch_params_supported(const pa_astarpa2_params* params) {
-    return params && engine::params_valid(*params) && apa2_supported(engine::params_from_c(*params)) ? 1 : 0;
+    return params && engine::params_valid(*params) && apa2_full_supported(engine::params_from_c(*params)) ? 1 : 0;
 }
 
 // A*PA2 for many pairs (the `simple` preset and its relatives): what a loop over pa_align(a, b, params, trace = 1) returns --
@@ -1705,9 +1893,10 @@ extern "C" pa_batch* pa_batch_create_params(const uint8_t* const* a, const size_
         return nullptr;
     }
     const engine::AstarPa2Params ap = engine::params_from_c(*params);
-    if (!apa2_supported(ap)) {
-        set_error("pa_batch_create_params: the batched band search runs Domain::Astar with NoCost / GapCost / SH, sparse 256-column blocks, "
-                  "no incremental doubling, no pruning (the `simple` preset and its relatives); use pa_align for other parameters");
+    if (!apa2_full_supported(ap)) {
+        set_error("pa_batch_create_params: the batched band search runs Domain::Astar (NoCost / GapCost / SH / GCSH, with or without pruning and "
+                  "incremental doubling) over sparse 256-column blocks with band doubling or a linear search -- the `simple` and `full` presets and "
+                  "their relatives; use pa_align for other parameters");
         return nullptr;
     }
     return batch_create(a, a_len, b, b_len, pairs, true, -1.f, ap.front.dt_trace ? (int)ap.front.max_g : 0, ap.front.dt_trace ? (int)ap.front.fr_drop : 0, params);
@@ -1754,8 +1943,20 @@ static int batch_forward(pa_batch* p) {
                 std::memset(hp, 0, 256);
                 dbg = (uint32_t*)hp;
             }
-            hipLaunchKernelGGL(apa2::apa2_kernel, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, p->d_pjobs.as<apa2::PairJob>(), p->d_order.as<int32_t>(),
-                               (int)p->pairs, p->sp, p->d_misc.as<uint32_t>(), p->d_misc.as<uint32_t>() + 1, dbg, getenv("PA_APA2_K1") ? 1 : 0);
+            if (p->astar_full) {
+                // a batch can be aligned again: the pruning state starts from scratch (every match active, the windows as built)
+                static const bool probe_stats = getenv("PA_APA2_PROBE_STATS") != nullptr;
+                if (!hip_ok(hipMemsetAsync(p->d_active.ptr, 1, std::max<size_t>(p->full_matches, 64), s), "memset active") ||
+                    (p->full_seeds && !hip_ok(hipMemcpyAsync(p->d_win.ptr, p->d_win0.ptr, p->full_seeds * sizeof(apa2::GcshSeedWindow), hipMemcpyDeviceToDevice, s), "D2D windows")) ||
+                    !hip_ok(hipMemsetAsync(p->d_probe.ptr, 0, 64, s), "memset probe stats"))
+                    return PA_E_HIP;
+                hipLaunchKernelGGL(apa2::apa2_full_kernel, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, p->d_fjobs.as<apa2::FullJob>(), p->d_order.as<int32_t>(),
+                                   (int)p->pairs, p->fsp, p->d_misc.as<uint32_t>(), p->d_misc.as<uint32_t>() + 1, dbg,
+                                   probe_stats ? p->d_probe.as<unsigned long long>() : nullptr);
+            } else {
+                hipLaunchKernelGGL(apa2::apa2_kernel, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, p->d_pjobs.as<apa2::PairJob>(), p->d_order.as<int32_t>(),
+                                   (int)p->pairs, p->sp, p->d_misc.as<uint32_t>(), p->d_misc.as<uint32_t>() + 1, dbg, getenv("PA_APA2_K1") ? 1 : 0);
+            }
             if (!hip_ok(hipGetLastError(), "apa2_kernel launch")) return PA_E_HIP;
             if (dbg) {  // diagnostics: the forward pass alone, progress markers and first results on stderr
                 std::fprintf(stderr, "[apa2] forward launched: grid %d, pairs %zu\n", grid, p->pairs);
@@ -2169,6 +2370,52 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
         std::memcpy(cigar_out[i], text.c_str(), text.size() + 1);
     }
     mark("strings to the caller");
+    return 0;
+}
+
+// Diagnostics / tests: the DEVICE form of GCSH alone.  The matches are found on the host (csrc/gcsh.hpp), one wavefront derives the contours
+// and evaluates h at nq positions (queries[2 t], queries[2 t + 1]); out[t] = h, out[nq] = number of contour layers (incl. layer 0).
+extern "C" int pa_debug_gcsh_probe(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, int32_t k, int32_t p_local, const int32_t* queries,
+                                   size_t nq, int32_t* out) {
+    if (!ensure_device()) return PA_E_HIP;
+    if (!a || !b || a_len == 0 || b_len == 0 || k < 1 || k > 31 || (!queries && nq) || !out) return PA_E_ARG;
+    engine::GcshHeuristic gh(a, (engine::I)a_len, b, (engine::I)b_len, k, p_local, false, false);
+    const size_t M = gh.by_start.size();
+    std::vector<int32_t> mi(M), mj(M);
+    for (size_t t = 0; t < M; ++t) {
+        mi[t] = gh.by_start[t].i;
+        mj[t] = gh.by_start[t].j;
+    }
+    DeviceBuf d_mi, d_mj, d_act, d_lrec, d_cell, d_job, d_q, d_out, d_err;
+    if (!d_mi.alloc(std::max<size_t>(M, 1) * 4) || !d_mj.alloc(std::max<size_t>(M, 1) * 4) || !d_act.alloc(std::max<size_t>(M, 64)) ||
+        !d_lrec.alloc((M + 2) * sizeof(apa2::GcshCell)) || !d_cell.alloc(std::max<size_t>(M, 1) * sizeof(apa2::GcshCell)) || !d_job.alloc(sizeof(apa2::FullJob)) ||
+        !d_q.alloc(std::max<size_t>(nq, 1) * 8) || !d_out.alloc((nq + 1) * 4) || !d_err.alloc(64))
+        return PA_E_NOMEM;
+    apa2::FullJob j;
+    std::memset(&j, 0, sizeof j);
+    j.n = (int32_t)a_len;
+    j.m = (int32_t)b_len;
+    j.heur = apa2::kFullHeurGcsh;
+    j.g.mi = d_mi.as<int32_t>();
+    j.g.mj = d_mj.as<int32_t>();
+    j.g.active = d_act.as<uint8_t>();
+    j.g.lrec = d_lrec.as<apa2::GcshCell>();
+    j.g.cell = d_cell.as<apa2::GcshCell>();
+    j.g.nmatch = (int32_t)M;
+    j.g.nlayers = 1;
+    j.g.n = j.n;
+    j.g.m = j.m;
+    j.g.k = k;
+    j.g.nseeds = gh.nseeds;
+    if ((M && (!hip_ok(hipMemcpy(d_mi.ptr, mi.data(), M * 4, hipMemcpyHostToDevice), "H2D") || !hip_ok(hipMemcpy(d_mj.ptr, mj.data(), M * 4, hipMemcpyHostToDevice), "H2D"))) ||
+        !hip_ok(hipMemset(d_act.ptr, 1, std::max<size_t>(M, 64)), "memset") || !hip_ok(hipMemset(d_err.ptr, 0, 64), "memset") ||
+        !hip_ok(hipMemcpy(d_job.ptr, &j, sizeof j, hipMemcpyHostToDevice), "H2D") ||
+        (nq && !hip_ok(hipMemcpy(d_q.ptr, queries, nq * 8, hipMemcpyHostToDevice), "H2D")))
+        return PA_E_HIP;
+    hipLaunchKernelGGL(apa2::gcsh_probe_kernel, dim3(1), dim3(64), 0, 0, d_job.as<apa2::FullJob>(), d_q.as<int32_t>(), (int)nq, d_out.as<int32_t>(), d_err.as<uint32_t>());
+    if (!hip_ok(hipGetLastError(), "gcsh_probe_kernel") || !hip_ok(hipDeviceSynchronize(), "sync") ||
+        !hip_ok(hipMemcpy(out, d_out.ptr, (nq + 1) * 4, hipMemcpyDeviceToHost), "D2H"))
+        return PA_E_HIP;
     return 0;
 }
 

@@ -372,8 +372,12 @@ __device__ __attribute__((noinline)) void pace_top_strip(const uint32_t* counter
 // strip takes C + 1 chunks instead of C + 2 -- 10 % of a 256-column block of the engine, of a traceback re-fill.
 // NOPASS: the caller never asks for an exact bottom row of a partial strip (job.exact_tail is 0 whenever nlanes < 64 K): the
 // pass-through chunk variants are not compiled (half the unrolled code of the strip; apa2_kernel.hpp holds four strip heights).
-template <int K, bool FILL, bool SCATTER, bool CKPT = false, bool LOCAL = false, bool LDSEQ = false, bool HALF = false, bool NOPASS = false>
-__device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, uint32_t lds_wave = 0) {
+// TAP (apa2_full_kernel.hpp; K <= 2): job.hout_arr receives the horizontal deltas that LEAVE logical lane `tap_lane` (>= 0) -- a row
+// INSIDE the strip -- instead of the bottom row: incremental doubling stores the deltas of row j_h (blocks.rs:342-469), and with the
+// tap the rows above and below j_h run as ONE strip (HMode::Output + HMode::Input, or Update + Input, of blocks.rs:406-468).  Lane l's
+// accumulators hold columns 32q - 1 - l .. 32q + 30 - l after chunk q (see run_chunk), so the bytes go out unaligned, per column.
+template <int K, bool FILL, bool SCATTER, bool CKPT = false, bool LOCAL = false, bool LDSEQ = false, bool HALF = false, bool NOPASS = false, bool TAP = false>
+__device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, uint32_t lds_wave = 0, int tap_lane = -1) {
     static_assert(!LDSEQ || (K >= 4 && !SCATTER && !FILL), "LDSEQ: tall cost-only strips");
     static_assert(!HALF || (K == 1 && !CKPT && !LDSEQ), "HALF: short K = 1 strips without checkpoints");
     constexpr int kGranScope = LOCAL ? __HIP_MEMORY_SCOPE_WORKGROUP : __HIP_MEMORY_SCOPE_AGENT;
@@ -502,7 +506,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
                 __hip_atomic_store((gu64)job.hout_gran + g, (((uint64_t)vhi << 32) | (uint64_t)vlo) + kGranuleBias,
                                    __ATOMIC_RELAXED, kGranScope);
         }
-        if (job.hout_arr) {
+        if (!TAP && job.hout_arr) {
             if (plane < 32 && plane < cols) {
                 const uint32_t tb = ((upper ? vhi : vlo) >> (30 - 2 * cj)) & 3u;  // bit1 = p, bit0 = m
                 ((gu8)job.hout_arr)[job.col0 + 32 * g + plane] = (uint8_t)((tb >> 1) | ((tb & 1u) << 1));
@@ -604,6 +608,16 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
             }
         }
 #undef PA_RUN_CHUNK
+        if (TAP && tap_lane >= 0) {
+            const int tp = HALF ? tap_lane + 32 : tap_lane;
+            const uint32_t tlo = (uint32_t)__builtin_amdgcn_readlane((int)acc_lo, tp);
+            const uint32_t thi = (uint32_t)__builtin_amdgcn_readlane((int)acc_hi, tp);
+            const int c = 32 * q - 1 - tap_lane + (plane & 31);
+            if (plane < 32 && c >= 0 && c < n) {
+                const uint32_t tb = ((upper ? thi : tlo) >> (30 - 2 * cj)) & 3u;  // bit1 = p, bit0 = m
+                ((gu8)job.hout_arr)[job.col0 + c] = (uint8_t)((tb >> 1) | ((tb & 1u) << 1));
+            }
+        }
     }
     if (alive) publish(C - 1);  // the last granule (completed by chunk Q-1 = C+1)
     if (!LOCAL && !CKPT && !FILL && (job.flags & kJobPace) && plane == 0)

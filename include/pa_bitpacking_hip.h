@@ -141,13 +141,17 @@ void pa_free_cigars(char** cigars, size_t n);
 size_t pa_batch_trace_fallbacks(const pa_batch* plan);
 
 /* ---- batched A*PA2 (band-limited alignment of many pairs) ------------------------------------------------------------ */
-/* What a loop over pa_align(a, b, params, trace = 1, ..) returns -- cost, CIGAR and statistics of AstarPa2Params::simple()
- * and its relatives (astarpa2/src/params.rs:70-96; the loop of pa-bin/src/main.rs:24-35) -- for many pairs at once: ONE
+/* What a loop over pa_align(a, b, params, trace = 1, ..) returns -- cost, CIGAR and statistics of AstarPa2Params::simple(),
+ * AstarPa2Params::full() and their relatives (astarpa2/src/params.rs:70-128; the loop of pa-bin/src/main.rs:24-35) -- for many pairs at once: ONE
  * WAVEFRONT runs a pair's whole band search on the GPU (every align_for_bounded_dist pass of domain.rs:356-541, the doubling
  * of band.rs:100-141 included, no host round trip per block, pass or pair), a second kernel walks the blocks of the
  * successful pass back (Blocks::trace with DT-trace, blocks/trace.rs:21-416).  Only the band is computed, not the matrix.
- * Supported parameters: Domain::Astar with NoCost / GapCost / SH, block_width 256, front.sparse, no incremental doubling, no
- * pruning, BandDoubling or LinearSearch (NULL otherwise: use pa_align).  Results come from pa_batch_align(); a pair the
+ * Supported parameters: Domain::Astar with NoCost / GapCost / SH / GCSH (exact matches, local pruning p), block_width 256,
+ * front.sparse, with or without incremental doubling and pruning of matches, BandDoubling or LinearSearch (NULL otherwise: use
+ * pa_align).  GCSH, pruning and incremental doubling -- the `full` preset -- run in a second kernel (csrc/apa2_full_kernel.hpp) that
+ * keeps the heuristic on the GPU: the contours are derived and probed by the pair's wavefront (pa-heuristic csh.rs:341-376,
+ * hint_contours.rs:213-272), the matches of a block are pruned by one lane per seed (prune.rs:245-292), the stored row of
+ * incremental doubling (blocks.rs:342-469) is tapped out of the block's single strip.  Results come from pa_batch_align(); a pair the
  * kernels hand back (an empty sequence, a re-fill taller than 8192 rows, a state the reference would panic on) is redone by
  * pa_align's engine transparently.  pa_batch_pair_stats: the statistics of every pair of the last pa_batch_align (timers 0).
  * pa_batch_run() on such a batch (or pa_batch_align with cigar_out == NULL) runs the band search without the traceback: the
@@ -159,6 +163,10 @@ pa_batch* pa_batch_create_params(const uint8_t* const* a, const size_t* a_len, c
                                  size_t pairs, const struct pa_astarpa2_params* params);
 int pa_batch_pair_stats(const pa_batch* plan, struct pa_astarpa2_stats* stats_out);
 int pa_batch_params_supported(const struct pa_astarpa2_params* params); /* 1: pa_batch_create_params takes them; 0: use pa_align */
+/* Diagnostics / tests: GCSH (seed length k, local pruning p_local) of one pair AS THE GPU COMPUTES IT -- the contours derived and probed
+ * by one wavefront -- at nq positions (queries[2 t] = i, queries[2 t + 1] = j): out[t] = h(i, j), out[nq] = number of contour layers. */
+int pa_debug_gcsh_probe(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, int32_t k, int32_t p_local, const int32_t* queries,
+                        size_t nq, int32_t* out);
 
 /* Many-pair mode over several GPUs from ONE process (independent pairs shard with no data-path exchange; the
  * reference runs them one after another, pa-bin/src/main.rs:24-35): a WORK QUEUE.  The pairs are sorted by estimated work

@@ -37,11 +37,22 @@ def _source_hash() -> str:
     h = hashlib.sha256()
     csrc = _DIR.parent / "astar-pairwise-aligner_amd" / "csrc"
     files = sorted(list(_DIR.glob("*.c")) + list(_DIR.glob("*.cpp")) + list(_DIR.glob("*.h")) + list(_DIR.glob("*.hpp")) + [_DIR / "Makefile"] +
-                   [csrc / n for n in ("engine.hpp", "gcsh.hpp", "engine_capi.hpp", "sweep_logic.hpp", "sweep_wave.hpp", "sweep_host.hpp", "apa2_logic.hpp", "apa2_full_logic.hpp", "gcsh_flat.hpp")] +
+                   [csrc / n for n in ("engine.hpp", "gcsh.hpp", "engine_capi.hpp", "sweep_logic.hpp", "sweep_wave.hpp", "sweep_host.hpp", "apa2_logic.hpp", "apa2_full_logic.hpp", "gcsh_dev.hpp")] +
                    [_DIR.parent / "include" / "pa_astarpa2.h"])
     for f in files:
         h.update(f.name.encode())
         h.update(f.read_bytes())
+    # the libraries are built with -march=native: a tree copied to another machine (the GPU box) must not reuse binaries built for
+    # this CPU, nor ones made by another compiler
+    try:
+        flags = next((ln for ln in Path("/proc/cpuinfo").read_text().splitlines() if ln.startswith("flags")), "")
+        h.update(" ".join(sorted(flags.split(":", 1)[-1].split())).encode())
+    except OSError:
+        pass
+    try:
+        h.update(subprocess.run(["gcc", "--version"], capture_output=True, text=True).stdout.splitlines()[0].encode())
+    except (OSError, IndexError):
+        pass
     return h.hexdigest()
 
 
@@ -387,7 +398,7 @@ def apa2_full_emu_align(a: bytes, b: bytes, params: AstarPa2ParamsC):
     """The flat per-pair program of the whole A*PA2 family (csrc/apa2_full_logic.hpp: any heuristic, incremental doubling, pruning --
     groundwork for a batched `full`, not yet run by the library) over the CPU oracle kernels.  -> (rc, cost, cigar, stats, info);
     rc 0 = ran, 1 = outside the program, 2 = gave up (info[0]); info[1] = h calls, info[2] = prune_block calls, info[3] = 3-range
-    splits, info[4] = plain initialisations, info[5] = h calls where the flat GCSH probe (gcsh_flat.hpp) disagreed with gcsh.hpp,
+    splits, info[4] = plain initialisations, info[5] = h calls where the device form of GCSH (gcsh_dev.hpp) disagreed with gcsh.hpp,
     info[6] = builds of the flat arrays."""
     global _flib
     if _flib is None:

@@ -15,7 +15,7 @@
 #include <vector>
 
 #include "../astar-pairwise-aligner_amd/csrc/apa2_full_logic.hpp"
-#include "../astar-pairwise-aligner_amd/csrc/gcsh_flat.hpp"
+#include "../astar-pairwise-aligner_amd/csrc/gcsh_dev.hpp"
 #include "cpu_backend.hpp"
 
 using namespace pa::engine;
@@ -32,25 +32,46 @@ struct FullEmuBackend {
     std::vector<std::vector<V>> col;  // slot k, absolute words
     BlockParams bp;
     uint64_t h_calls = 0, prune_calls = 0, three_range = 0, two_range = 0, flat_mismatch = 0, flat_builds = 0;
-    // the device form of the GCSH probe (gcsh_flat.hpp), cross-checked against gcsh.hpp at every call
+    // the device form of GCSH (gcsh_dev.hpp: layers as linked lists, per-seed windows), cross-checked against gcsh.hpp at every call
     GcshHeuristic* gcsh = nullptr;
-    GcshFlatStorage flat;
-    std::vector<int32_t> flat_mj;
-    std::vector<uint8_t> flat_active;
-    std::vector<GcshSeedWindow> flat_win;
+    GcshDev gd{};
+    std::vector<int32_t> gd_mi, gd_mj;
+    std::vector<uint8_t> gd_active;
+    std::vector<GcshSeedWindow> gd_win;
+    std::vector<GcshCell> gd_lrec, gd_cell;
     uint64_t prune_mismatch = 0, flat_pruned = 0;
     void rebuild_flat() {
         if (!gcsh) return;
-        flat.build(gcsh->layers);
+        gd_build_contours(gd, [](const GcshDev& g, int32_t qx, int32_t qy) { return gd_score_scalar(g, qx, qy); });
         flat_builds += 1;
+        if ((size_t)gd.nlayers != gcsh->layers.size()) flat_mismatch += 1;
     }
-    void init_flat_matches() {  // the matches and the per-seed windows as flat arrays (what a device-side prune_block works on)
+    void init_flat_matches() {  // the matches and the per-seed windows as flat arrays (what the device works on)
         if (!gcsh) return;
-        flat_mj.clear();
-        for (const auto& mt : gcsh->by_start) flat_mj.push_back(mt.j);
-        flat_active.assign(flat_mj.size(), 1);
-        flat_win.clear();
-        for (const auto& ar : gcsh->active_range) flat_win.push_back(GcshSeedWindow{(int32_t)ar.b0, (int32_t)ar.b1, -1, 0});
+        gd_mi.clear();
+        gd_mj.clear();
+        for (const auto& mt : gcsh->by_start) {
+            gd_mi.push_back(mt.i);
+            gd_mj.push_back(mt.j);
+        }
+        gd_active.assign(gd_mj.size(), 1);
+        gd_win.clear();
+        for (const auto& ar : gcsh->active_range) gd_win.push_back(GcshSeedWindow{(int32_t)ar.b0, (int32_t)ar.b1, -1, 0});
+        gd_lrec.assign(gd_mj.size() + 2, GcshCell{0, 0, -1, 0});
+        gd_cell.assign(gd_mj.size() + 1, GcshCell{0, 0, -1, 0});
+        gd.mi = gd_mi.data();
+        gd.mj = gd_mj.data();
+        gd.active = gd_active.data();
+        gd.win = gd_win.data();
+        gd.lrec = gd_lrec.data();
+        gd.cell = gd_cell.data();
+        gd.nmatch = (int32_t)gd_mj.size();
+        gd.nlayers = 1;
+        gd.n = gcsh->n;
+        gd.m = gcsh->m;
+        gd.k = gcsh->k;
+        gd.nseeds = gcsh->nseeds;
+        gd.prune = gcsh->prune_enabled ? 1 : 0;
     }
 
     FullEmuBackend(CpuBackend& c, Heuristic& h, int nblk) : cb(c), heur(h) {
@@ -63,6 +84,7 @@ struct FullEmuBackend {
         bp.simd = true;
         bp.no_ilp = false;
     }
+    int32_t uniform(int32_t x) const { return x; }
     FullRec load_rec(int32_t k) const { return rec[(size_t)k]; }
     void store_rec(int32_t k, const FullRec& r) { rec[(size_t)k] = r; }
     int32_t index(int32_t k, const FullRec& r, int32_t j) const {  // block.rs:69-122 (from the top; the first column is all +1)
@@ -90,7 +112,7 @@ struct FullEmuBackend {
         for (int32_t w = copy_end > p1 ? copy_end : p1; w < w1; ++w) col[(size_t)k][(size_t)w] = V::one();
         (void)prev;
     }
-    int32_t compute(int32_t k, int32_t i0, int32_t i1, int32_t w0, int32_t w1, int32_t mode) {
+    int32_t compute_mode(int32_t k, int32_t i0, int32_t i1, int32_t w0, int32_t w1, int32_t mode) {
         const HMode hm = mode == kHNone ? HMode::None : mode == kHInput ? HMode::Input : mode == kHUpdate ? HMode::Update : HMode::Output;
         if (w1 == w0) {  // no rows: what comes in at the top leaves at the bottom
             int32_t s = 0;
@@ -102,19 +124,29 @@ struct FullEmuBackend {
         }
         return cb.compute(i0, i1, (size_t)w0, (size_t)w1, col[(size_t)k].data() + w0, hm, bp);
     }
+    // the fused ranges of apa2_full_logic.hpp in the reference's terms (blocks.rs:662-748)
+    int32_t compute2(int32_t k, int32_t i0, int32_t i1, int32_t w0, int32_t wt, int32_t w1, bool hin, bool tap) {
+        if (!tap) return compute_mode(k, i0, i1, w0, w1, hin ? kHInput : kHNone);
+        if (hin) {
+            if (wt > w0) compute_mode(k, i0, i1, w0, wt, kHUpdate);
+        } else {
+            compute_mode(k, i0, i1, w0, wt, kHOutput);
+        }
+        return compute_mode(k, i0, i1, wt, w1, kHInput);
+    }
     int32_t h(int32_t i, int32_t j) {
         h_calls += 1;
         const int32_t v = heur.h(i, j);
-        if (gcsh && gcsh_h(flat.view(gcsh->n, gcsh->m, gcsh->k, gcsh->nseeds), i, j) != v) flat_mismatch += 1;
+        if (gcsh && gd_h_from_score(gd, i, j, gd_score_scalar(gd, gd_tx(gd, i, j), gd_ty(gd, i, j))) != v) flat_mismatch += 1;
         return v;
     }
     void prune_block(int32_t i0, int32_t i1, int32_t j0, int32_t j1) {
         prune_calls += 1;
         heur.prune_block(i0, i1, j0, j1);
         if (gcsh && gcsh->prune_enabled) {
-            flat_pruned += (uint64_t)gcsh_prune_block(flat_mj.data(), flat_active.data(), flat_win.data(), (int32_t)flat_win.size(), gcsh->k, i0, i1, j0, j1);
-            for (size_t t = 0; t < flat_active.size(); ++t)
-                if ((flat_active[t] != 0) != gcsh->by_start[t].active) prune_mismatch += 1;
+            flat_pruned += (uint64_t)gd_prune_block(gd, i0, i1, j0, j1);
+            for (size_t t = 0; t < gd_active.size(); ++t)
+                if ((gd_active[t] != 0) != gcsh->by_start[t].active) prune_mismatch += 1;
         }
     }
     void update_contours() {
@@ -128,8 +160,8 @@ struct FullEmuBackend {
 
 // rc 0 = ran; 1 = parameters outside the program (not Domain::Astar over sparse 256-column blocks with a search); 2 = the program
 // gave up (info[0] = its status).  info[1] = h calls, info[2] = prune_block calls, info[3] = 3-range splits, info[4] = plain inits,
-// info[5] = h calls where the flat (device-form) GCSH probe of gcsh_flat.hpp disagreed with gcsh.hpp, info[6] = times the flat arrays were built,
-// info[7] = match flags on which the flat prune_block (gcsh_flat.hpp) and gcsh.hpp disagreed, summed over the calls.
+// info[5] = h calls where the device form of GCSH (gcsh_dev.hpp) disagreed with gcsh.hpp (+ contour builds whose layer count differs), info[6] = times the device-form contours were built,
+// info[7] = match flags on which gcsh_dev.hpp's prune_block and gcsh.hpp disagreed, summed over the calls.
 extern "C" int pa_apa2_full_emu_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params* params,
                                       int32_t* cost_out, char** cigar_out, pa_astarpa2_stats* stats_out, int32_t* info) {
     if (!params || !params_valid(*params)) return -4;
@@ -156,8 +188,8 @@ extern "C" int pa_apa2_full_emu_align(const uint8_t* a, size_t a_len, const uint
     const int nblk = ((int)a_len + 255) / 256;
     FullEmuBackend be(cb, *heur, nblk);
     be.gcsh = dynamic_cast<GcshHeuristic*>(heur.get());
-    be.rebuild_flat();
     be.init_flat_matches();
+    be.rebuild_flat();
     FullResult res;
     if (std::getenv("PA_FULL_EMU_STEPWISE")) {
         // the orchestration a device needs: ONE pass per "launch" by a program object built afresh from the saved state, the contours

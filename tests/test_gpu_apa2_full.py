@@ -1,0 +1,152 @@
+"""Batched A*PA2 for the WHOLE family on the GPU -- AstarPa2Params::full() (GCSH with local pruning, pruning of matches between blocks,
+incremental doubling) and its relatives through pa_batch_create_params / pa_batch_align: one wavefront runs a pair's whole band search
+(csrc/apa2_full_logic.hpp over the gfx950 backend of csrc/apa2_full_kernel.hpp, the heuristic's contours derived and probed on the
+device), the traceback kernel walks the banded blocks of the successful pass.  For every pair the cost, the CIGAR string and all twelve
+statistics must equal what the host engine over the CPU oracle kernels returns for the same parameters (`oracle.cpu_align`) -- i.e.
+what a loop over pa_align / astarpa2_full returns -- and the second, independent restatement (oracle/astarpa2_restated.py)."""
+import random
+
+import numpy as np
+import pytest
+
+from tests.test_restated_engine import variants
+from tests.test_sweep_emu import KEYS
+from tests.util_seq import PA_TEST_PAIRS, gen_pair, rand_seq
+
+pytestmark = pytest.mark.gpu
+
+FULL_FAMILY = ["full", "gcsh_noprune", "gcsh_k8_p0_prune", "gcsh_k6_p3_prune_incr", "gcsh_k10_p5_nosparseh", "gap_incr", "sh12_incr", "dijkstra_incr_nodt",
+               "gap_incr_f15"]
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import astar_pairwise_aligner_amd as pa
+
+    pa.require_gpu()
+    return pa
+
+
+def check(pa, oracle, pairs, oc, verify_only_sample=None, max_fallbacks=None):
+    from tests.test_gpu_engine import gpu_params
+
+    batch = pa.Batch(pairs, params=gpu_params(pa, oc))
+    costs, cigars, fwd_ms, trace_ms = batch.align()
+    stats = batch.pair_stats()
+    idx = range(len(pairs)) if verify_only_sample is None else verify_only_sample
+    for i in idx:
+        a, b = pairs[i]
+        want_cost, want_cigar, want_stats = oracle.cpu_align(a, b, oc)
+        assert costs[i] == want_cost, (i, len(a), len(b))
+        assert cigars[i] == want_cigar, (i, len(a), len(b), cigars[i][:80], want_cigar[:80])
+        assert {k: stats[i][k] for k in KEYS} == {k: want_stats[k] for k in KEYS}, (i, len(a), len(b))
+    if max_fallbacks is not None:
+        assert batch.trace_fallbacks() <= max_fallbacks, batch.trace_fallbacks()
+    costs2, cigars2, _, _ = batch.align()  # the pruning state starts from scratch: aligning again gives the same
+    assert np.array_equal(costs, costs2) and cigars == cigars2
+    batch.close()
+    return costs, cigars, fwd_ms, trace_ms
+
+
+def test_full_preset_is_taken(pa, oracle):
+    from astar_pairwise_aligner_amd import capi
+    from tests.test_gpu_engine import gpu_params
+
+    for name in FULL_FAMILY + ["simple", "sh12"]:
+        assert capi.batch_params_supported(gpu_params(pa, variants(oracle)[name][0])), name
+    for name in ["nw", "gap_gap", "block64", "full_sparse"]:
+        assert not capi.batch_params_supported(gpu_params(pa, variants(oracle)[name][0])), name
+
+
+def test_device_heuristic_equals_host(pa, oracle):
+    """h(i, j) of GCSH as one wavefront computes it (contours derived on the device, 64 layers per probe round) against csrc/gcsh.hpp on
+    the host, at positions along the alignment, around it and all over the matrix."""
+    from astar_pairwise_aligner_amd import capi
+
+    rng = random.Random(11)
+    for n, e, k, p, seed in [(3000, 0.05, 12, 14, 1), (20000, 0.08, 12, 14, 2), (100_000, 0.05, 12, 14, 3), (8000, 0.15, 6, 3, 4), (5000, 0.02, 8, 0, 5),
+                             (2000, 0.6, 5, 2, 6), (40, 0.1, 12, 14, 7)]:
+        a, b = gen_pair(n, e, seed)
+        qs = [(0, 0), (len(a), len(b)), (0, len(b)), (len(a), 0)]
+        for _ in range(3000):
+            i = rng.randint(0, len(a))
+            j = min(len(b), max(0, i + rng.randint(-40, 40))) if rng.random() < 0.7 else rng.randint(0, len(b))
+            qs.append((i, j))
+        want, _ = oracle.gcsh_probe(a, b, k, p, qs)
+        got, layers = capi.gcsh_probe(a, b, k, p, qs)
+        bad = [(q, w, g) for q, w, g in zip(qs, want, got) if w != g]
+        assert not bad, (n, e, k, p, len(bad), bad[:5], layers)
+
+
+def test_block_boundary_sizes_full(pa, oracle):
+    pairs = []
+    for n in (1, 2, 11, 12, 13, 31, 64, 65, 255, 256, 257, 511, 512, 513, 1025, 2047, 2049, 4097):
+        for e in (0.0, 0.05, 0.4, 1.0):
+            pairs.append(gen_pair(n, e, seed=n * 7 + int(e * 100)))
+    costs, _, _, _ = check(pa, oracle, pairs, oracle.params_full())
+    for (a, b), c in zip(pairs, costs):
+        assert c == oracle.levenshtein(a, b)
+
+
+def test_pa_test_pairs_and_degenerate_inputs_full(pa, oracle):
+    pairs = [p for p in PA_TEST_PAIRS] + [(b"", b""), (b"ACGT", b""), (b"", b"ACGTA"), (b"A", b"A"), (b"A", b"C")]
+    check(pa, oracle, pairs, oracle.params_full())
+
+
+@pytest.mark.parametrize("name", FULL_FAMILY)
+def test_family_several_passes(pa, oracle, name):
+    """Several passes (three-range splits of incremental doubling, contours re-derived after pruning), bands of several strips."""
+    oc = variants(oracle)[name][0]
+    pairs = [gen_pair(n, e, seed) for n, e, seed in [(300, 0.05, 1), (3000, 0.1, 3), (10000, 0.15, 4), (30000, 0.2, 6), (20000, 0.3, 5)]]
+    for n, e, seed in [(20_000, 0.15, 4), (12_000, 0.3, 6)]:  # long indels: more passes
+        a, b = gen_pair(n, e, seed)
+        cut = len(b) // 3
+        pairs.append((a, b[:cut] + rand_seq(700, seed + 1) + b[cut:2 * cut] + b[2 * cut + 400:]))
+    costs, cigars, _, _ = check(pa, oracle, pairs, oc)
+    for (a, b), c, cg in zip(pairs, costs, cigars):
+        assert oracle.cigar_verify(cg, a, b) == c
+
+
+def test_random_pairs_random_family(pa, oracle):
+    rng = random.Random(2024)
+    vs = variants(oracle)
+    for name in FULL_FAMILY:
+        pairs = []
+        for it in range(60):
+            n = rng.choice([rng.randint(1, 300), rng.randint(300, 2500), rng.randint(2500, 9000)])
+            e = rng.choice([0.0, 0.01, 0.05, 0.1, 0.2, 0.4, 0.8])
+            a, b = gen_pair(n, e, rng.randint(1, 10**9))
+            mode = rng.random()
+            if mode < 0.25 and n > 50:
+                cut = rng.randint(0, len(b) - 1)
+                ln = rng.randint(1, max(1, min(1500, len(b) // 2)))
+                b = b[:cut] + b[cut + ln:] if rng.random() < 0.5 else b[:cut] + rand_seq(ln, it + 7) + b[cut:]
+                b = b or b"A"
+            elif mode < 0.3:
+                b = rand_seq(rng.randint(1, n + 50), it + 9)
+            pairs.append((a, b))
+        check(pa, oracle, pairs, vs[name][0])
+
+
+def test_restatement_agrees_on_the_device_results(pa, oracle):
+    """The second restatement (pure Python, shares nothing with engine.hpp or the kernels) on a sample of what the GPU returned."""
+    from oracle import astarpa2_restated as restated
+    from tests.test_gpu_engine import gpu_params
+
+    oc, kw = variants(oracle)["full"]
+    pairs = [gen_pair(n, e, seed) for n, e, seed in [(2000, 0.05, 21), (5000, 0.12, 22), (9000, 0.2, 23), (700, 0.3, 24)]]
+    batch = pa.Batch(pairs, params=gpu_params(pa, oc))
+    costs, cigars, _, _ = batch.align()
+    stats = batch.pair_stats()
+    for i, (a, b) in enumerate(pairs):
+        got = restated.align(a, b, **kw)
+        assert (int(costs[i]), cigars[i]) == got[:2]
+        assert all(stats[i][k] == got[2][k] for k in KEYS if k != "sanity_violations")
+    batch.close()
+
+
+def test_c3_pair_and_small_batch_full(pa, oracle):
+    """BASELINE C3 with the `full` parameter set: 100 kbp pairs at 5 % -- 16 of them in one batch (the batch kernels) and one alone."""
+    pairs = [gen_pair(100_000, 0.05, seed=3_000_000 + s) for s in range(16)]
+    check(pa, oracle, pairs, oracle.params_full(), verify_only_sample=[0, 5, 15], max_fallbacks=0)
+    check(pa, oracle, pairs[:1], oracle.params_full())

@@ -41,6 +41,14 @@ def source_hash() -> str:
     return h.hexdigest()
 
 
+def kernel_hash() -> str:
+    """Content hash of the headline kernel's source (csrc/strip_kernel.hpp): profiles/pmc_latest.json is stamped with it, and bench.py
+    prints PMC-derived figures only when the counters were collected over this very code."""
+    import hashlib
+
+    return hashlib.sha256((CSRC / "strip_kernel.hpp").read_bytes()).hexdigest()
+
+
 def is_stale() -> bool:
     if not LIB_PATH.exists() or not STAMP_PATH.exists():
         return True

@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = [
     "pa_align", "pa_batch_align_multi", "pa_batch_create_trace_params",
     "pa_bp_ctx_create", "pa_bp_ctx_compute", "pa_bp_ctx_fill", "pa_bp_ctx_destroy",
     "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools", "pa_align_file_params", "pa_batch_params_supported", "pa_alloc_cache_stats", "pa_free_cigars",
+    "pa_batch_full_info", "pa_debug_gcsh_probe",
 ]
 
 _lib = None
@@ -80,6 +81,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_batch_run.argtypes = [vp, vp, C.POINTER(C.c_float)]
     L.pa_batch_run.restype = C.c_int
     L.pa_batch_stats.argtypes = [vp] + [C.POINTER(C.c_double)] * 4
+    L.pa_batch_full_info.argtypes = [vp] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_double)]
+    L.pa_batch_full_info.restype = None
     L.pa_batch_shape.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.pa_batch_destroy.argtypes = [vp]
     L.pa_batch_create_banded.argtypes = [vp, vp, vp, vp, sz, C.c_float]
@@ -453,6 +456,15 @@ class Batch:
         if rc != 0:
             raise PaError(f"pa_batch_pair_stats rc={rc}: {last_error()}")
         return [{n: getattr(arr[i], n) for n, _ in _StatsC._fields_} for i in range(self.pairs)]
+
+    def full_info(self) -> dict:
+        """pa_batch_full_info: reporting for batches of the `full` family."""
+        vals = [C.c_double(0) for _ in range(4)]
+        ph = (C.c_double * 8)()
+        load().pa_batch_full_info(self._h, *[C.byref(v) for v in vals], ph)
+        d = dict(zip(("build_ms", "matches", "probes", "rounds"), (v.value for v in vals)))
+        d["phase_wave_ms"] = dict(zip(("contours", "dp", "h", "index", "prune", "init", "total"), [x for x in ph][:7]))
+        return d
 
     def trace_fallbacks(self) -> int:
         return int(load().pa_batch_trace_fallbacks(self._h))

@@ -53,7 +53,7 @@ struct FullJob {
 typedef int32_t pa_i32x4 __attribute__((ext_vector_type(4)));
 
 struct FullDevBackend {
-    const FullJob& job;
+    FullJob job;
     GcshDev g;
     uint32_t* err;
     uint32_t* dbg;
@@ -62,8 +62,43 @@ struct FullDevBackend {
     bool dirty = false;    // matches were pruned since the contours were derived
     mutable uint32_t strip_units = 0;
     uint32_t n_probe = 0, n_round = 0;  // diagnostics: h probes and the load rounds they took
+    bool timing = false;                // diagnostics (PA_APA2_PROBE_STATS): phase clocks, 100 MHz ticks
+    mutable uint64_t t_build = 0, t_dp = 0, t_h = 0, t_index = 0, t_prune = 0, t_init = 0;
+    __device__ __forceinline__ uint64_t tick() const { return timing ? wall_clock64() : 0; }
 
-    __device__ __forceinline__ FullDevBackend(const FullJob& j, uint32_t* e, uint32_t* d) : job(j), g(j.g), err(e), dbg(d) { lane = (int)(threadIdx.x & 63); }
+    __device__ __forceinline__ FullDevBackend(const FullJob& j, uint32_t* e, uint32_t* d) : err(e), dbg(d) {
+        lane = (int)(threadIdx.x & 63);
+        job.a_codes = own_sgpr(j.a_codes);
+        job.b_prof = own_sgpr(j.b_prof);
+        job.rec = own_sgpr(j.rec);
+        job.jh = own_sgpr(j.jh);
+        job.col = own_sgpr(j.col);
+        job.col_stride = own_sgpr(j.col_stride);
+        job.hrow = own_sgpr(j.hrow);
+        job.sh_h = own_sgpr(j.sh_h);
+        job.gran = own_sgpr(j.gran);
+        job.sum = own_sgpr(j.sum);
+        job.result = own_sgpr(j.result);
+        job.n = own_sgpr(j.n);
+        job.m = own_sgpr(j.m);
+        job.heur = own_sgpr(j.heur);
+        job.pad = 0;
+        g.mi = own_sgpr(j.g.mi);
+        g.mj = own_sgpr(j.g.mj);
+        g.active = own_sgpr(j.g.active);
+        g.win = own_sgpr(j.g.win);
+        g.lrec = own_sgpr(j.g.lrec);
+        g.cell = own_sgpr(j.g.cell);
+        g.nmatch = own_sgpr(j.g.nmatch);
+        g.nlayers = 1;
+        g.n = job.n;
+        g.m = job.m;
+        g.k = own_sgpr(j.g.k);
+        g.nseeds = own_sgpr(j.g.nseeds);
+        g.prune = own_sgpr(j.g.prune);
+        g.pad = 0;
+        if (g.k >= 1 && g.k < 32 && g.n < (1 << 26) - 64) div_m = (uint32_t)((1ull << 31) / (uint64_t)g.k) + 1u;
+    }
     __device__ __forceinline__ uint64_t strip_instructions() const { return (uint64_t)strip_units << 5; }
     __device__ __forceinline__ int32_t uniform(int32_t x) const { return (int32_t)rfl((uint32_t)x); }
     __device__ __forceinline__ bool failed() const { return rfl(__hip_atomic_load((const PA_GLOBAL uint32_t*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != PA_ERR_NONE; }
@@ -71,7 +106,12 @@ struct FullDevBackend {
     __device__ __forceinline__ void sync_mem() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }  // same wavefront writes, then reads
 
     // ---- block records --------------------------------------------------------------------------------------------------------
+    mutable bool rec_dirty = false;  // records stored since the last fence
     __device__ __forceinline__ FullRec load_rec(int32_t k) const {
+        if (rec_dirty) {
+            sync_mem();
+            rec_dirty = false;
+        }
         const PA_GLOBAL int32_t* p = (const PA_GLOBAL int32_t*)job.rec + (size_t)k * 8;
         const PA_GLOBAL int32_t* q = (const PA_GLOBAL int32_t*)job.jh + k;
         const int32_t x = lane < 8 ? p[lane] : (lane == 8 ? q[0] : 0);
@@ -95,11 +135,41 @@ struct FullDevBackend {
         p[0] = lo;
         p[1] = hi;
         ((PA_GLOBAL int32_t*)job.jh)[k] = r.j_h;
-        sync_mem();
+        rec_dirty = true;  // (records are read back by a later pass, not by this block)
     }
 
     // ---- Block::index (block.rs:69-122) -----------------------------------------------------------------------------------------
+    // The column of the block computed last stays in registers (lane l: word cw0 + l), when it has at most 64 words: the probes of
+    // fixed_j_range and the three look-ups of the next block then cost a masked popcount and a wave sum, no memory round trip.
+    mutable int32_t ck = -1, cw0 = 0, cw1 = 0;
+    mutable uint64_t cvp = 0, cvm = 0;
+    __device__ __forceinline__ void cache_column(int32_t k, int32_t w_from, int32_t w_end) const {
+        ck = -1;
+        if (w_end - w_from > 64 || w_end <= w_from) return;
+        const gcu32 c = (gcu32)slot(k);
+        const int32_t wi = w_from + lane;
+        cvp = ~0ull;
+        cvm = 0ull;
+        if (wi < w_end) {
+            cvp = (uint64_t)c[(size_t)wi * 4 + 0] | ((uint64_t)c[(size_t)wi * 4 + 1] << 32);
+            cvm = (uint64_t)c[(size_t)wi * 4 + 2] | ((uint64_t)c[(size_t)wi * 4 + 3] << 32);
+        }
+        ck = k;
+        cw0 = w_from;
+        cw1 = w_end;
+    }
     __device__ __forceinline__ int32_t prefix(int32_t k, int32_t w_from, int32_t w_end, int32_t j) const {
+        if (k != ck || w_from != cw0 || w_end != cw1) cache_column(k, w_from, w_end);
+        if (k == ck) {
+            const int32_t full = j >> 6, rem = j & 63;
+            const int32_t wi = w_from + lane;
+            int32_t acc = 0;
+            if (wi < full || (wi == full && rem != 0)) {  // (words at or beyond w_end read as +1 per row: cvp / cvm hold that)
+                const uint64_t mask = wi < full ? ~0ull : ((1ull << rem) - 1ull);
+                acc = __builtin_popcountll(cvp & mask) - __builtin_popcountll(cvm & mask);
+            }
+            return wsum(acc);
+        }
         const gcu32 c = (gcu32)slot(k);
         const int32_t full = j >> 6, rem = j & 63;
         int32_t acc = 0;
@@ -120,7 +190,10 @@ struct FullDevBackend {
     __device__ __forceinline__ int32_t index(int32_t k, const FullRec& r, int32_t j) const {
         if (k == 0) return j;
         if (j > r.je) return r.bot_val + (j - r.je);
-        return r.top_val + prefix(k, r.js >> 6, r.je >> 6, j);
+        const uint64_t t0 = tick();
+        const int32_t v = r.top_val + prefix(k, r.js >> 6, r.je >> 6, j);
+        t_index += tick() - t0;
+        return v;
     }
 
     // ---- the left edge of a block (blocks.rs:753-831) -----------------------------------------------------------------------------
@@ -137,12 +210,13 @@ struct FullDevBackend {
         dst[(size_t)wi * 4 + 2] = x2;
         dst[(size_t)wi * 4 + 3] = x3;
     }
-    __device__ __forceinline__ void init_plain(int32_t k, const FullRec& prev, const FullRec& cur) const {
-        const int32_t w0 = cur.js >> 6, w1 = cur.je >> 6, pw0 = prev.js >> 6, pw1 = prev.je >> 6;
-        const gu32 dst = slot(k);
-        const gcu32 src = (gcu32)slot(k > 0 ? k - 1 : 0);
-        for (int32_t wi = w0 + lane; wi < w1; wi += 64) put_word(dst, src, wi, k > 1 && wi >= pw0 && wi < pw1);
-        sync_mem();
+    // init_v_with_overlap (blocks.rs:753-767) is not a pass over memory here: the block's strip reads its left edge straight from the
+    // previous block's column (run_strip<.., TAP> with StripJob::values as the source) -- one store / fence / load round trip less.
+    mutable int32_t lazy_k = -1, lazy_pw0 = 0, lazy_pw1 = 0;
+    __device__ __forceinline__ void init_plain(int32_t k, const FullRec& prev, const FullRec&) const {
+        lazy_k = k;
+        lazy_pw0 = k > 1 ? prev.js >> 6 : 0;  // (the first column is all +1)
+        lazy_pw1 = k > 1 ? prev.je >> 6 : 0;
     }
     // words [p0, p1) of slot k stay as the older pass left them; [w0, p0) and [p1, min(w1, prev_w1)) come from the previous block
     // (the first column is all +1), the rest is V::one()
@@ -176,6 +250,9 @@ struct FullDevBackend {
         }
         if (words <= 0) return hin ? row_sum(i0, i1) : i1 - i0;  // no rows: the bottom row is the top row
         const bool tap_inside = tap && wt > w0;
+        const uint64_t t0 = tick();
+        const bool from_prev = lazy_k == k;
+        lazy_k = -1;
         int32_t done = 0;
         for (int32_t st = 0; done < words; ++st) {
             const int32_t left = words - done;
@@ -191,13 +268,13 @@ struct FullDevBackend {
             j.hin_arr = (st == 0 && hin) ? job.hrow : nullptr;
             j.hout_gran = last ? nullptr : job.gran + (size_t)(st & 1) * 8;
             j.hout_arr = job.hrow;  // (TAP: written only when tap_lane >= 0)
-            j.values = nullptr;
+            j.values = from_prev ? job.col + (size_t)(k - 1) * (size_t)job.col_stride * 4 : nullptr;  // (TAP: the source of the left edge)
             j.sum_out = last ? job.sum : nullptr;
             j.n = i1 - i0;
             j.word0 = sw0;
             j.nlanes = 2 * take;
-            j.fill_stride = 0;
-            j.fill_word0 = 0;
+            j.fill_stride = lazy_pw1;
+            j.fill_word0 = lazy_pw0;
             j.exact_tail = last ? 0 : 1;
             j.flags = 0;
             j.col0 = i0;
@@ -214,16 +291,26 @@ struct FullDevBackend {
             else if (j.nlanes <= 32) run_strip<1, false, false, false, true, false, true, true, true>(j, err, 0, tl);
             else run_strip<1, false, false, false, true, false, false, true, true>(j, err, 0, tl);
             sync_mem();
+            ck = -1;  // (the column changed)
             strip_units += (uint32_t)((((i1 - i0 + 31) >> 5) + ((kk == 1 && j.nlanes <= 32) ? 1 : 2)) * (11 + 12 * kk));
             done += take;
         }
-        return (int32_t)rfl((uint32_t)*(const PA_GLOBAL int32_t*)job.sum);
+        const int32_t ret = (int32_t)rfl((uint32_t)*(const PA_GLOBAL int32_t*)job.sum);
+        t_dp += tick() - t0;
+        return ret;
     }
 
     // ---- the heuristic -------------------------------------------------------------------------------------------------------------
-    __device__ __forceinline__ int32_t pot(int32_t i) const {  // gd_potential with the quotient back in a scalar register
+    // x / k for 0 <= x < 2^26 on the scalar unit: k is a launch constant, M = floor(2^31 / k) + 1 (Granlund-Montgomery: exact for
+    // dividends below 2^26 and k < 2^5); longer sequences take the hardware's (vector) division.
+    uint32_t div_m = 0;
+    __device__ __forceinline__ int32_t div_k(int32_t x) const {
+        if (div_m != 0u) return (int32_t)(((uint64_t)(uint32_t)x * (uint64_t)div_m) >> 31);
+        return (int32_t)rfl((uint32_t)(x / g.k));
+    }
+    __device__ __forceinline__ int32_t pot(int32_t i) const {  // gd_potential with the quotient in a scalar register
         if (i < 0 || i > g.n) return 0;
-        const int32_t before = (int32_t)rfl((uint32_t)((i + g.k - 1) / g.k));
+        const int32_t before = div_k(i + g.k - 1);
         return before < g.nseeds ? g.nseeds - before : 0;
     }
     __device__ __forceinline__ bool contains_lane(int32_t v, int32_t qx, int32_t qy) const {  // per lane: its own layer v >= 1
@@ -239,16 +326,25 @@ struct FullDevBackend {
         }
         return hit;
     }
-    // The highest layer that holds a point >= (qx, qy) (hint_contours.rs:258-272): lo is known to hold one (layer 0 holds everything),
-    // hi is known not to (or is past the last layer); 64 layers per round.
-    __device__ __forceinline__ int32_t score(int32_t qx, int32_t qy) {
+    // ---- the layer window: lane l keeps the record of layer wb + l in registers (a write-through cache of lrec) ---------------------------
+    // The contour build appends layer after layer at the top and asks, match after match, for the score just below it: almost every
+    // probe of the build finds the boundary between "holds a point >= q" and "does not" among the 64 layers of the window and never
+    // touches memory.  A probe that does not (a match off the alignment's chain) searches memory (score_mem).
+    int32_t wb = 0;           // the window's first layer
+    bool wvalid = false;
+    bool building = false;    // contour build: the window follows the top layers, a miss does not move it
+    int32_t wx = 0, wy = 0, wn = -1;  // per lane: lrec[wb + lane]
+    uint32_t n_wmiss = 0;
+
+    // The highest layer that holds a point >= (qx, qy) (hint_contours.rs:258-272), searched in memory: lo is known to hold one (layer 0
+    // holds everything), hi is known not to (or is past the last layer); 64 layers per round.
+    __device__ __forceinline__ int32_t score_mem(int32_t qx, int32_t qy) {
         const int32_t nl = g.nlayers;
         int32_t lo = 0, hi = nl;
         int32_t stride = 1;
         int32_t base = hint - 31;
         if (base > nl - 64) base = nl - 64;
         if (base < 1) base = 1;
-        n_probe += 1;
         while (hi - lo > 1) {
             n_round += 1;
             const int32_t v = base + lane * stride;
@@ -265,10 +361,45 @@ struct FullDevBackend {
             if (span <= 0) break;
             stride = (span + 63) >> 6;
             base = lo + stride;
-            if (stride == 1) base = lo + 1;
         }
-        hint = lo;
         return lo;
+    }
+    __device__ __forceinline__ int32_t score(int32_t qx, int32_t qy) {
+        n_probe += 1;
+        if (wvalid) {
+            const int32_t v = wb + lane;
+            const bool valid = v >= 1 && v < g.nlayers;
+            bool c = false;
+            if (valid) {
+                c = wx >= qx && wy >= qy;
+                if (!c && wn >= 0) {  // an older point of the layer (rare: a layer off the chain of the alignment)
+                    const PA_GLOBAL pa_i32x4* cl = (const PA_GLOBAL pa_i32x4*)g.cell;
+                    int32_t nx = wn;
+                    for (int32_t guard = g.nmatch; nx >= 0 && guard > 0; --guard) {
+                        const pa_i32x4 e = cl[nx];
+                        c = e.x >= qx && e.y >= qy;
+                        nx = c ? -1 : e.z;
+                    }
+                }
+            }
+            const uint64_t mt = __ballot(c);
+            if (mt) {
+                const int top = 63 - __builtin_clzll(mt);
+                // the layer above the highest "yes" is in the window and says no, or does not exist: the boundary
+                if (top < 63 || wb + 64 >= g.nlayers) {
+                    hint = wb + top;
+                    return hint;
+                }
+            } else if (wb <= 1) {  // layer 1 is in the window and says no (or does not exist): only layer 0 is left
+                hint = 0;
+                return 0;
+            }
+        }
+        n_wmiss += 1;
+        if (building) sync_mem();  // (the records this wavefront stored are what it loads)
+        const int32_t ans = score_mem(qx, qy);
+        hint = ans;
+        return ans;
     }
     __device__ __forceinline__ int32_t h(int32_t i, int32_t j) {
         if (job.heur == kFullHeurGap) {
@@ -277,8 +408,10 @@ struct FullDevBackend {
         }
         if (job.heur == kFullHeurSH) return (int32_t)rfl((uint32_t)((const PA_GLOBAL int32_t*)job.sh_h)[i]);
         if (job.heur != kFullHeurGcsh) return 0;
+        const uint64_t t0 = tick();
         const int32_t p = pot(i);
         const int32_t val = score(i - j - p, j - i - p);
+        t_h += tick() - t0;
         if (val == 0) {  // csh.rs:178-187, seeds.rs:84-89
             const int32_t d = (g.n - i) - (g.m - j);
             const int32_t gap = d < 0 ? -d : d;
@@ -289,16 +422,24 @@ struct FullDevBackend {
     }
 
     // Contours from the active matches, last start first (hint_contours.rs:213-255; csh.rs:525-545 reaches the same state).
+    // The layer window follows the top: a match of the alignment's chain opens a new layer, which is a register write and one store.
     __device__ __forceinline__ void build_contours() {
         g.nlayers = 1;
         hint = 0;
         dirty = false;
+        const uint64_t t0 = tick();
+        sync_mem();
         const int32_t ttx = g.n - g.m - pot(g.n), tty = g.m - g.n - pot(g.n);
         const PA_GLOBAL int32_t* mi = (const PA_GLOBAL int32_t*)g.mi;
         const PA_GLOBAL int32_t* mj = (const PA_GLOBAL int32_t*)g.mj;
         const PA_GLOBAL uint8_t* act = (const PA_GLOBAL uint8_t*)g.active;
         PA_GLOBAL pa_i32x4* lr = (PA_GLOBAL pa_i32x4*)g.lrec;
         PA_GLOBAL pa_i32x4* cl = (PA_GLOBAL pa_i32x4*)g.cell;
+        wb = 0;
+        wx = wy = 0;
+        wn = -1;
+        wvalid = true;
+        building = true;
         for (int32_t top = g.nmatch - 1; top >= 0; top -= 64) {
             const int32_t t = top - lane;  // lane 0 holds the last match of this round
             int32_t sx = 0, sy = 0, ex = 0, ey = 0;
@@ -320,16 +461,38 @@ struct FullDevBackend {
                 const int32_t px = __builtin_amdgcn_readlane(sx, l), py = __builtin_amdgcn_readlane(sy, l);
                 const int32_t v = score(qx, qy) + 1;
                 pa_i32x4 rec = {px, py, -1, 0};
+                if (v >= wb + 64) {  // (only a new layer at the top can be above the window) the window moves up by half
+                    wx = __shfl_down(wx, 32, 64);
+                    wy = __shfl_down(wy, 32, 64);
+                    wn = __shfl_down(wn, 32, 64);
+                    wb += 32;
+                }
                 if (v < g.nlayers) {  // the layer's previous newest point moves into this match's cell
-                    cl[top - l] = lr[v];
+                    if (v >= wb) {
+                        const pa_i32x4 old = {__builtin_amdgcn_readlane(wx, v - wb), __builtin_amdgcn_readlane(wy, v - wb), __builtin_amdgcn_readlane(wn, v - wb), 0};
+                        cl[top - l] = old;
+                    } else {
+                        sync_mem();
+                        cl[top - l] = lr[v];
+                    }
                     rec.z = top - l;
                 } else {
                     g.nlayers = v + 1;
                 }
                 lr[v] = rec;
-                sync_mem();
+                if (v >= wb && lane == v - wb) {
+                    wx = rec.x;
+                    wy = rec.y;
+                    wn = rec.z;
+                }
             }
         }
+        sync_mem();
+        building = false;
+        // The probes of the search sit at the band's edges, 50-150 layers below the layers of the diagonal, and alternate between
+        // the edges: a 64-layer window would be re-centred by every other probe (measured: slower than no window).  Memory it is.
+        wvalid = false;
+        t_build += tick() - t0;
     }
     __device__ __forceinline__ void update_contours() {  // csh.rs:497-554, called at the start of a pass (domain.rs:365-371)
         if (job.heur == kFullHeurGcsh && dirty) build_contours();
@@ -337,17 +500,19 @@ struct FullDevBackend {
     // prune.rs:245-292: one lane per seed of the block
     __device__ __forceinline__ void prune_block(int32_t i0, int32_t i1, int32_t j0, int32_t j1) {
         if (job.heur != kFullHeurGcsh || !g.prune) return;
-        int32_t s0 = (int32_t)rfl((uint32_t)((i0 + 1 + g.k - 1) / g.k));
-        int32_t s1 = (int32_t)rfl((uint32_t)(i1 / g.k)) + 1;
+        int32_t s0 = div_k(i0 + g.k);
+        int32_t s1 = div_k(i1) + 1;
         if (s0 < 0) s0 = 0;
         if (s1 > g.nseeds) s1 = g.nseeds;
+        const uint64_t t0 = tick();
         for (int32_t base = s0; base < s1; base += 64) {
             const int32_t s = base + lane;
             int32_t cnt = 0;
             if (s < s1) cnt = gd_prune_seed(g, s, j0, j1);
             if (__ballot(cnt > 0)) dirty = true;
         }
-        sync_mem();
+        // (no fence: the seeds of two blocks are disjoint, and the flags are read by the next contour build, which starts with one)
+        t_prune += tick() - t0;
     }
 };
 
@@ -370,7 +535,7 @@ __device__ __forceinline__ void store_full_result(const FullJob& job, const Full
 }
 
 // Pairs are claimed by ticket in the order of `order` (heaviest first); a block is four independent wavefronts.
-// probe_stats (optional): [0] += h probes, [1] += load rounds they took (diagnostics).
+// probe_stats (optional, diagnostics): [0] += h probes, [1] += load rounds they took, [2..9) += phase clocks (pa_batch_full_info).
 __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_full_kernel(const FullJob* __restrict__ jobs, const int32_t* __restrict__ order, int npairs,
                                                                          FullParams sp, uint32_t* ticket, uint32_t* err, uint32_t* dbg,
                                                                          unsigned long long* probe_stats) {
@@ -382,6 +547,8 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_full_kernel(con
         const int pair = (int)rfl((uint32_t)order[t]);
         const FullJob job = jobs[pair];
         FullDevBackend be(job, err, dbg);
+        be.timing = probe_stats != nullptr;
+        const uint64_t t_begin = be.tick();
         FullResult fr{};
         if (job.n > 0 && job.m > 0) {
             if (job.heur == kFullHeurGcsh) be.build_contours();
@@ -391,10 +558,10 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_full_kernel(con
             fr.status = kFullErrOrder;
         }
         if (rfl(*(const PA_GLOBAL uint32_t*)err) != PA_ERR_NONE && fr.status == kFullOk) fr.status = kFullErrOrder;
-        store_full_result(job, fr, be.strip_instructions());
+        store_full_result(be.job, fr, be.strip_instructions());
         if (probe_stats) {
-            atomicAdd(probe_stats, lane == 0 ? (unsigned long long)be.n_probe : 0ull);
-            atomicAdd(probe_stats + 1, lane == 0 ? (unsigned long long)be.n_round : 0ull);
+            const unsigned long long vals[9] = {be.n_probe, be.n_round, be.t_build, be.t_dp, be.t_h, be.t_index, be.t_prune, be.t_init, be.tick() - t_begin};
+            for (int q = 0; q < 9; ++q) atomicAdd(probe_stats + q, lane == 0 ? vals[q] : 0ull);
         }
     }
 }

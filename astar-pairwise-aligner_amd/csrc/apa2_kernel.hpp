@@ -41,8 +41,18 @@ __device__ __forceinline__ int32_t wsum(int32_t x) {
     return (int32_t)rfl((uint32_t)x);
 }
 
+// A descriptor fetched with one wide scalar load lives in ONE register tuple: when the register allocator spills it (and it must: the
+// strips need every scalar register), any later use of ONE field reloads all sixteen -- v_readlane after v_readlane on the vector
+// unit.  Passing every field through an empty asm gives each its own live range (round 4; seen in the ISA of apa2_full_kernel).
+template <class T>
+__device__ __forceinline__ T own_sgpr(T x) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "scalar or pointer");
+    asm volatile("" : "+s"(x));
+    return x;
+}
+
 struct DevBackend {
-    const PairJob& job;
+    PairJob job;
     HeurParams hp;
     uint32_t* err;
     uint32_t* dbg;  // diagnostics: host-mapped progress markers, or nullptr
@@ -52,7 +62,23 @@ struct DevBackend {
     mutable uint32_t strip_units = 0;  // modelled VALU instructions of the strips so far, in units of 32 (one per unrolled chunk step)
     __device__ __forceinline__ uint64_t strip_instructions() const { return (uint64_t)strip_units << 5; }
 
-    __device__ __forceinline__ DevBackend(const PairJob& j, const HeurParams& h, uint32_t* e, uint32_t* d) : job(j), hp(h), err(e), dbg(d) { lane = (int)(threadIdx.x & 63); }
+    __device__ __forceinline__ DevBackend(const PairJob& j, const HeurParams& h, uint32_t* e, uint32_t* d) : hp(h), err(e), dbg(d) {
+        lane = (int)(threadIdx.x & 63);
+        job.a_codes = own_sgpr(j.a_codes);
+        job.b_prof = own_sgpr(j.b_prof);
+        job.rec = own_sgpr(j.rec);
+        job.col = own_sgpr(j.col);
+        job.col_stride = own_sgpr(j.col_stride);
+        job.sh_h = own_sgpr(j.sh_h);
+        job.gran = own_sgpr(j.gran);
+        job.sum = own_sgpr(j.sum);
+        job.result = own_sgpr(j.result);
+        job.n = own_sgpr(j.n);
+        job.m = own_sgpr(j.m);
+        hp.n = job.n;
+        hp.m = job.m;
+        hp.sh_h = job.sh_h;
+    }
     __device__ __forceinline__ void mark(int slot_, uint32_t value) const {
         if (dbg && lane == 0) __hip_atomic_store(dbg + slot_, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -287,7 +313,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_kernel(const Pa
             res.status = kErrDegenerate;
         }
         if (rfl(*(const PA_GLOBAL uint32_t*)err) != PA_ERR_NONE && res.status == kOk) res.status = kErrDevice;
-        *job.result = res;  // (every lane stores the same 64 bytes: no lane-dependent branch at the end of the loop body either)
+        *be.job.result = res;  // (every lane stores the same 64 bytes: no lane-dependent branch at the end of the loop body either)
     }
 }
 

@@ -1504,7 +1504,7 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
         !p->d_active.alloc(std::max<size_t>(tm, 64)) || !p->d_win.alloc(std::max<size_t>(tseeds, 1) * sizeof(apa2::GcshSeedWindow)) ||
         !p->d_win0.alloc(std::max<size_t>(tseeds, 1) * sizeof(apa2::GcshSeedWindow)) ||
         !p->d_lrec.alloc((tm + 2 * std::max<size_t>(P, 1)) * sizeof(apa2::GcshCell)) || !p->d_cell.alloc(std::max<size_t>(tm, 1) * sizeof(apa2::GcshCell)) ||
-        !p->d_probe.alloc(64))
+        !p->d_probe.alloc(128))
         return false;
     if (tsh && !hip_ok(hipMemcpy(p->d_sh.ptr, shv.data(), tsh * 4, hipMemcpyHostToDevice), "H2D sh")) return false;
     if (tm) {
@@ -1948,7 +1948,7 @@ static int batch_forward(pa_batch* p) {
                 static const bool probe_stats = getenv("PA_APA2_PROBE_STATS") != nullptr;
                 if (!hip_ok(hipMemsetAsync(p->d_active.ptr, 1, std::max<size_t>(p->full_matches, 64), s), "memset active") ||
                     (p->full_seeds && !hip_ok(hipMemcpyAsync(p->d_win.ptr, p->d_win0.ptr, p->full_seeds * sizeof(apa2::GcshSeedWindow), hipMemcpyDeviceToDevice, s), "D2D windows")) ||
-                    !hip_ok(hipMemsetAsync(p->d_probe.ptr, 0, 64, s), "memset probe stats"))
+                    !hip_ok(hipMemsetAsync(p->d_probe.ptr, 0, 128, s), "memset probe stats"))
                     return PA_E_HIP;
                 hipLaunchKernelGGL(apa2::apa2_full_kernel, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, p->d_fjobs.as<apa2::FullJob>(), p->d_order.as<int32_t>(),
                                    (int)p->pairs, p->fsp, p->d_misc.as<uint32_t>(), p->d_misc.as<uint32_t>() + 1, dbg,
@@ -2210,11 +2210,13 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
     const bool cost_only_astar = p->astar && !cigar_out;
     if (P && !cost_only_astar) {
         const int grid = (int)((P + kStripBlockWaves - 1) / kStripBlockWaves);
-        if (p->dt_max_g > 0)
-            hipLaunchKernelGGL(trace_kernel<true>, dim3(grid), dim3(64 * kStripBlockWaves), kStripBlockWaves * sizeof(DtLds), s, p->d_tjobs.as<TraceJob>(), (int)P,
-                               p->d_misc.as<uint32_t>() + 1);
-        else
-            hipLaunchKernelGGL(trace_kernel<false>, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, p->d_tjobs.as<TraceJob>(), (int)P, p->d_misc.as<uint32_t>() + 1);
+        const dim3 tg(grid), tb(64 * kStripBlockWaves);
+        const TraceJob* tjp = p->d_tjobs.as<TraceJob>();
+        uint32_t* terr = p->d_misc.as<uint32_t>() + 1;
+        if (p->dt_max_g > 0 && p->astar) hipLaunchKernelGGL((trace_kernel<true, true>), tg, tb, kStripBlockWaves * sizeof(DtLds), s, tjp, (int)P, terr);
+        else if (p->dt_max_g > 0) hipLaunchKernelGGL((trace_kernel<true, false>), tg, tb, kStripBlockWaves * sizeof(DtLds), s, tjp, (int)P, terr);
+        else if (p->astar) hipLaunchKernelGGL((trace_kernel<false, true>), tg, tb, 0, s, tjp, (int)P, terr);
+        else hipLaunchKernelGGL((trace_kernel<false, false>), tg, tb, 0, s, tjp, (int)P, terr);
         if (!hip_ok(hipGetLastError(), "trace_kernel launch")) return PA_E_HIP;
     }
     if (!hip_ok(hipEventRecord(p->ev2, s), "event")) return PA_E_HIP;
@@ -2417,6 +2419,22 @@ extern "C" int pa_debug_gcsh_probe(const uint8_t* a, size_t a_len, const uint8_t
         !hip_ok(hipMemcpy(out, d_out.ptr, (nq + 1) * 4, hipMemcpyDeviceToHost), "D2H"))
         return PA_E_HIP;
     return 0;
+}
+
+// Reporting (whole-family batches, pa_batch_create_params with GCSH / pruning / incremental doubling): host milliseconds spent finding
+// the matches of the heuristic at creation, their number, and -- with PA_APA2_PROBE_STATS set -- the h probes of the last forward pass
+// and the load rounds (64 layers each) they took.
+// phase_wave_ms[0..7) (PA_APA2_PROBE_STATS): wavefront-milliseconds (summed over all wavefronts; 100 MHz clock) spent deriving contours,
+// in the DP strips, in h probes, in Block::index, in prune_block, initialising block columns, and in total.
+extern "C" void pa_batch_full_info(const pa_batch* p, double* build_ms, double* matches, double* probes, double* rounds, double* phase_wave_ms) {
+    if (build_ms) *build_ms = p ? p->full_build_ms : 0;
+    if (matches) *matches = p ? (double)p->full_matches : 0;
+    unsigned long long pr[16] = {0};
+    if (p && p->astar_full && p->d_probe.ptr) (void)hipMemcpy(pr, p->d_probe.ptr, 128, hipMemcpyDeviceToHost);
+    if (probes) *probes = (double)pr[0];
+    if (rounds) *rounds = (double)pr[1];
+    if (phase_wave_ms)
+        for (int t = 0; t < 7; ++t) phase_wave_ms[t] = (double)pr[2 + t] * 1e-5;
 }
 
 extern "C" size_t pa_batch_trace_fallbacks(const pa_batch* p) { return p ? p->trace_fallbacks : 0; }

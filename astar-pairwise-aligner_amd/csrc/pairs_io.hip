@@ -306,7 +306,23 @@ static int batch_align_queue(const uint8_t* const* a, const size_t* a_len, const
     // ... and no chunk's block-column store (traced batches: one V column per 256 columns of a, full height) beyond ~24 GB
     const double kChunkBytes = 24e9;
     std::vector<size_t> bounds{0};
-    {
+    if (ndevices > 1 && pairs > 0 && chunk * (size_t)ndevices >= pairs && !std::getenv("PA_MULTI_CHUNK")) {
+        // Few pairs: one chunk per device, and then the queue cannot correct a bad split -- contiguous slices of the heaviest-first
+        // order would hand the first device all the heavy pairs.  Deal them out longest-processing-time-first instead.
+        const size_t bins = std::min<size_t>((size_t)ndevices, pairs);
+        std::vector<std::vector<size_t>> bin(bins);
+        std::vector<uint64_t> load(bins, 0);
+        for (size_t k = 0; k < pairs; ++k) {
+            const size_t r = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+            bin[r].push_back(order[k]);
+            load[r] += work[order[k]];
+        }
+        size_t pos = 0;
+        for (size_t r = 0; r < bins; ++r) {
+            for (size_t i : bin[r]) order[pos++] = i;
+            bounds.push_back(pos);
+        }
+    } else {
         double bytes = 0;
         size_t cnt = 0;
         for (size_t k = 0; k < pairs; ++k) {

@@ -409,6 +409,17 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
             if (job.flags & kJobVInitOne) {
                 vp[k] = 0xFFFFFFFFu;
                 vm[k] = 0u;
+            } else if (TAP && job.values != nullptr) {
+                // init_v_with_overlap (blocks.rs:753-767) folded into the strip: the left edge is the PREVIOUS block's column
+                // (`values`, same word indexing) where that block has rows (words [fill_word0, fill_stride)), V::one elsewhere
+                const gcu32 g_vs = (gcu32)job.values;
+                const bool in_src = word >= job.fill_word0 && word < job.fill_stride;
+                vp[k] = 0xFFFFFFFFu;
+                vm[k] = 0u;
+                if (in_src) {
+                    vp[k] = g_vs[word * 4 + half];
+                    vm[k] = g_vs[word * 4 + 2 + half];
+                }
             } else {
                 vp[k] = g_v[word * 4 + half];
                 vm[k] = g_v[word * 4 + 2 + half];

@@ -106,7 +106,10 @@ struct DtLds {
 };
 constexpr int32_t kDtInf = 0x7FFFFFFF;
 
-template <bool DT>
+// BANDED: the blocks are the banded blocks of the batched A*PA2 (TraceJob::rec) and TraceStats are counted; the full-height
+// checkpoints of the full-DP traced batch (pa_batch_create_trace) compile without either (round 4: with both in one instance the
+// full-DP traceback of C4 had gone from 12.2 to 16.6 ms).
+template <bool DT, bool BANDED>
 // (wavefronts per SIMD asked of the register allocator, measured on C4: the DT variant 13.1 ms without the bound, 9.1 / 9.9 / 13.8 ms
 //  at 5 / 6 / 7; the re-fill variant 12.6 / 12.1 / 13.1 ms at 5 / 6 / 7)
 __global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kernel(const TraceJob* __restrict__ jobs, int npairs, uint32_t* err) {
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kerne
     const gu32 cig = (gu32)tj.cigar;
     const int n = tj.n, m = tj.m, w = tj.w;
 
-    const bool banded = tj.rec != nullptr;
+    constexpr bool banded = BANDED;
     int32_t g;
     bool failed = false;
     if (banded) {
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kerne
         if (g != 0) failed = true;  // "trace ends at distance 0"
     }
     if (lane == 0) *(gu32)tj.cigar_len = failed ? kTraceFailed : len;
-    if (tj.tstats && lane == 0) {
+    if (BANDED && tj.tstats && lane == 0) {
         gu32 ts = (gu32)tj.tstats;
         ts[0] = n_dt_try;
         ts[1] = n_dt_ok;

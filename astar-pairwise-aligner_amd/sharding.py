@@ -16,10 +16,7 @@ padded rows); with `all_ranks=False` they are gathered to rank 0 only and the ot
 """
 from __future__ import annotations
 
-import itertools
 from typing import Callable, Sequence
-
-_call_counter = itertools.count()
 
 
 def work_estimate(a_len: int, b_len: int, band_words: int | None = None) -> int:
@@ -63,7 +60,10 @@ def plan_chunks(work: Sequence[int], world: int, min_chunk: int = 256, per_rank:
     order = sorted(range(n), key=lambda i: (-work[i], i))
     chunk = max(min_chunk, n // (world * per_rank) + 1)
     if chunk * world > n:
-        chunk = (n + world - 1) // world
+        # few pairs: one chunk per rank.  Contiguous slices of the heaviest-first order would hand rank 0 all the heavy pairs (most of
+        # the n * m work of a length-skewed input), and with one chunk each the queue cannot correct that: deal them out
+        # longest-processing-time-first instead
+        return [sh for sh in plan_shards(work, min(world, n)) if sh]
     chunk = max(chunk, 1)
     return [sorted(order[k:k + chunk]) for k in range(0, n, chunk)]
 
@@ -150,7 +150,6 @@ def _sharded(pairs, compute, group, with_cigar, all_ranks, work, min_chunk):
         local = compute(list(pairs))
         return [(int(c), str(g)) for c, g in local] if with_cigar else [int(c) for c in local]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    call_id = next(_call_counter)  # (collective calls happen in the same order on every rank)
     if work is None:
         work = [work_estimate(len(a), len(b)) for a, b in pairs]
     chunks = plan_chunks(work, world, min_chunk=min_chunk)  # the same queue on every rank
@@ -159,8 +158,17 @@ def _sharded(pairs, compute, group, with_cigar, all_ranks, work, min_chunk):
     mine: list[int] = []      # pair indices in the order computed
     local: list = []
     taken: list[int] = []
+    key = None
     if store is not None:
-        key = f"pa_work_queue_{call_id}"
+        # The queue's key must be the same on every rank of THIS call whatever else the ranks did before (calls on sub-groups, calls
+        # without a store): rank 0 draws a fresh id from the store and broadcasts it.  (A per-process call counter drifts apart as soon
+        # as one rank takes part in a call another does not, and then every rank drains a queue of its own.)
+        qdev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        qid = torch.zeros(1, dtype=torch.int64, device=qdev)
+        if rank == 0:
+            qid[0] = int(store.add("pa_work_queue_ids", 1))
+        dist.broadcast(qid, src=0, group=group)
+        key = f"pa_work_queue_{int(qid.item())}"
         while True:
             c = int(store.add(key, 1)) - 1
             if c >= len(chunks):
@@ -219,6 +227,11 @@ def _sharded(pairs, compute, group, with_cigar, all_ranks, work, min_chunk):
             rl = [torch.empty_like(row) for _ in range(world)] if rank == root else None
             dist.gather(row, rl, dst=groot, group=group)
             rows = torch.cat(rl) if rank == root else None
+    if key is not None and rank == 0:  # (the gathers above were the barrier: nobody pulls from this queue any more)
+        try:
+            store.delete_key(key)
+        except Exception:
+            pass
     if not i_collect:
         return None
     heads = heads.cpu().view(world, cap, 3).numpy()

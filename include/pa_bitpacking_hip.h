@@ -163,6 +163,10 @@ pa_batch* pa_batch_create_params(const uint8_t* const* a, const size_t* a_len, c
                                  size_t pairs, const struct pa_astarpa2_params* params);
 int pa_batch_pair_stats(const pa_batch* plan, struct pa_astarpa2_stats* stats_out);
 int pa_batch_params_supported(const struct pa_astarpa2_params* params); /* 1: pa_batch_create_params takes them; 0: use pa_align */
+/* Reporting for batches of the `full` family: host ms spent on the heuristic's matches at creation, their number, and (PA_APA2_PROBE_STATS
+ * set) the h probes of the last forward pass, the 64-layer load rounds they took, and phase_wave_ms[0..7): wavefront-milliseconds (summed over
+ * wavefronts) deriving contours, in DP strips, in h probes, in Block::index, in prune_block, initialising columns, in total. */
+void pa_batch_full_info(const pa_batch* plan, double* build_ms, double* matches, double* probes, double* rounds, double* phase_wave_ms);
 /* Diagnostics / tests: GCSH (seed length k, local pruning p_local) of one pair AS THE GPU COMPUTES IT -- the contours derived and probed
  * by one wavefront -- at nq positions (queries[2 t] = i, queries[2 t + 1] = j): out[t] = h(i, j), out[nq] = number of contour layers. */
 int pa_debug_gcsh_probe(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, int32_t k, int32_t p_local, const int32_t* queries,

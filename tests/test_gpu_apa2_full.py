@@ -83,14 +83,14 @@ def test_block_boundary_sizes_full(pa, oracle):
     for n in (1, 2, 11, 12, 13, 31, 64, 65, 255, 256, 257, 511, 512, 513, 1025, 2047, 2049, 4097):
         for e in (0.0, 0.05, 0.4, 1.0):
             pairs.append(gen_pair(n, e, seed=n * 7 + int(e * 100)))
-    costs, _, _, _ = check(pa, oracle, pairs, oracle.params_full())
+    costs, _, _, _ = check(pa, oracle, pairs, oracle.params_full(), max_fallbacks=0)
     for (a, b), c in zip(pairs, costs):
         assert c == oracle.levenshtein(a, b)
 
 
 def test_pa_test_pairs_and_degenerate_inputs_full(pa, oracle):
     pairs = [p for p in PA_TEST_PAIRS] + [(b"", b""), (b"ACGT", b""), (b"", b"ACGTA"), (b"A", b"A"), (b"A", b"C")]
-    check(pa, oracle, pairs, oracle.params_full())
+    check(pa, oracle, pairs, oracle.params_full(), max_fallbacks=3)  # (the three pairs with an empty sequence go to the host engine)
 
 
 @pytest.mark.parametrize("name", FULL_FAMILY)
@@ -102,7 +102,7 @@ def test_family_several_passes(pa, oracle, name):
         a, b = gen_pair(n, e, seed)
         cut = len(b) // 3
         pairs.append((a, b[:cut] + rand_seq(700, seed + 1) + b[cut:2 * cut] + b[2 * cut + 400:]))
-    costs, cigars, _, _ = check(pa, oracle, pairs, oc)
+    costs, cigars, _, _ = check(pa, oracle, pairs, oc, max_fallbacks=0)
     for (a, b), c, cg in zip(pairs, costs, cigars):
         assert oracle.cigar_verify(cg, a, b) == c
 
@@ -125,7 +125,7 @@ def test_random_pairs_random_family(pa, oracle):
             elif mode < 0.3:
                 b = rand_seq(rng.randint(1, n + 50), it + 9)
             pairs.append((a, b))
-        check(pa, oracle, pairs, vs[name][0])
+        check(pa, oracle, pairs, vs[name][0], max_fallbacks=0)
 
 
 def test_restatement_agrees_on_the_device_results(pa, oracle):

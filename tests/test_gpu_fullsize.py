@@ -141,6 +141,48 @@ def test_c3_batch_512_pairs_astarpa2_simple(pa, oracle):
         assert {k: st[k] for k in KEYS} == {k: w[2][k] for k in KEYS}, i
 
 
+def _full_against_both_oracles(pa, oracle, pairs, restated_sample):
+    """Every pair through the batched `full` preset: cost, CIGAR string and twelve statistics equal the host engine over the CPU oracle
+    kernels (`oracle.cpu_align(params_full())`); a sample also equals the second, independent restatement (oracle/astarpa2_restated.py)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import astarpa2_restated as restated
+    from tests.test_restated_engine import variants
+    from tests.test_sweep_emu import KEYS
+
+    batch = pa.Batch(pairs, params=pa.AstarPa2Params.full())
+    costs, cigars, _, _ = batch.align()
+    stats = batch.pair_stats()
+    assert batch.trace_fallbacks() == 0
+    batch.close()
+    prm, kw = variants(oracle)["full"]
+    with ThreadPoolExecutor(max_workers=16) as ex:  # (ctypes releases the GIL: the CPU engine runs on several cores)
+        want = list(ex.map(lambda p: oracle.cpu_align(p[0], p[1], prm), pairs))
+    for i, (w, c, cg, st) in enumerate(zip(want, costs, cigars, stats)):
+        assert (int(c), cg) == (w[0], w[1]), i
+        assert {k: st[k] for k in KEYS} == {k: w[2][k] for k in KEYS}, i
+    for i in restated_sample:
+        got = restated.align(pairs[i][0], pairs[i][1], **kw)
+        assert (int(costs[i]), cigars[i]) == got[:2], i
+        assert all(stats[i][k] == got[2][k] for k in KEYS if k != "sanity_violations"), i
+    return stats
+
+
+def test_c4_full_10000_pairs_astarpa2_full(pa, oracle):
+    """C4 through the batched A*PA2 with AstarPa2Params::full() (GCSH + pruning + incremental doubling on the device): EVERY one of the
+    10 000 pairs against the CPU-kernel engine, 104 of them (every divergence class) against the second restatement as well."""
+    divs = (0.01, 0.05, 0.10, 0.15)
+    pairs = [gen_pair(10_000, divs[i % 4], seed=2_000_000 + i) for i in range(10_000)]
+    stats = _full_against_both_oracles(pa, oracle, pairs, restated_sample=range(3, 10_000, 97))
+    assert sum(s["f_max_tries"] > 1 for s in stats) > 1000  # (the 15 % pairs need a second pass: contours re-derived, three-range splits)
+
+
+def test_c3_batch_512_pairs_astarpa2_full(pa, oracle):
+    """512 pairs of 100 kbp at 5 % (BASELINE C3's pair, many of them) through the batched `full`; sixteen of them also against the restatement."""
+    pairs = [gen_pair(100_000, 0.05, seed=3_000_000 + i) for i in range(512)]
+    _full_against_both_oracles(pa, oracle, pairs, restated_sample=range(0, 512, 32))
+
+
 def test_c4_properties_suffix_and_substitutions(pa):
     a = rand_seq(50_000, seed=77)
     suffix = rand_seq(1234, seed=78)

@@ -139,6 +139,66 @@ def test_work_queue_balances_what_the_estimate_cannot_see():
     assert t[1] <= 1.25 * t[0] + 0.08, t  # busy times within 25 % (+ one chunk of slack); a static split by length: 1.5x apart
 
 
+def _subgroup_worker(rank, world, port, q):
+    """A call on a sub-group only some ranks take part in, then calls on the whole world (round 3's advisor finding: with a per-process
+    call counter the ranks then used different queue keys, every chunk was computed once per rank and the gather saw 2 n results)."""
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from astar_pairwise_aligner_amd.sharding import sharded_costs
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    solo = dist.new_group([0])  # (every rank creates the group, only rank 0 is in it)
+    pairs = [(b"ACGT" * (i + 1), b"ACGA" * (i + 1)) for i in range(40)]
+    want = [i + 1 for i in range(40)]
+    calls = []
+
+    def compute(sub):
+        calls.append(len(sub))
+        return [len(a) // 4 for a, _ in sub]
+
+    ok = True
+    if rank == 0:
+        ok = sharded_costs(pairs[:7], compute=compute, group=solo, min_chunk=2) == want[:7]
+        ok = ok and sharded_costs(pairs[:5], compute=compute, group=solo, min_chunk=2) == want[:5]
+    before = sum(calls)
+    for _ in range(3):  # world calls after the ranks' histories differ
+        ok = ok and sharded_costs(pairs, compute=compute, min_chunk=4) == want
+    q.put((rank, ok, sum(calls) - before))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_queue_key_survives_calls_on_subgroups():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert sum(n for _, _, n in res) == 3 * 40  # every pair of the three world calls computed exactly once
+
+
+def test_few_pairs_are_dealt_by_work_not_sliced():
+    from astar_pairwise_aligner_amd.sharding import plan_chunks
+
+    work = [1000, 900, 800, 10, 9, 8, 7, 6]  # fewer pairs than world * min_chunk: one chunk per rank
+    chunks = plan_chunks(work, world=4, min_chunk=256)
+    assert sorted(i for c in chunks for i in c) == list(range(8)) and len(chunks) == 4
+    loads = sorted(sum(work[i] for i in c) for c in chunks)
+    assert loads[-1] == 1000 and loads[0] >= 40 - 1000  # the three heavy pairs sit in three different chunks
+    assert sum(1 for c in chunks if any(work[i] >= 800 for i in c)) == 3
+
+
 def test_plan_shards_balanced_and_deterministic():
     sys.path.insert(0, str(ROOT))
     from astar_pairwise_aligner_amd.sharding import plan_shards

@@ -52,7 +52,7 @@ __device__ __forceinline__ T own_sgpr(T x) {
 }
 
 struct DevBackend {
-    PairJob job;
+    const PairJob& job;
     HeurParams hp;
     uint32_t* err;
     uint32_t* dbg;  // diagnostics: host-mapped progress markers, or nullptr
@@ -62,23 +62,9 @@ struct DevBackend {
     mutable uint32_t strip_units = 0;  // modelled VALU instructions of the strips so far, in units of 32 (one per unrolled chunk step)
     __device__ __forceinline__ uint64_t strip_instructions() const { return (uint64_t)strip_units << 5; }
 
-    __device__ __forceinline__ DevBackend(const PairJob& j, const HeurParams& h, uint32_t* e, uint32_t* d) : hp(h), err(e), dbg(d) {
-        lane = (int)(threadIdx.x & 63);
-        job.a_codes = own_sgpr(j.a_codes);
-        job.b_prof = own_sgpr(j.b_prof);
-        job.rec = own_sgpr(j.rec);
-        job.col = own_sgpr(j.col);
-        job.col_stride = own_sgpr(j.col_stride);
-        job.sh_h = own_sgpr(j.sh_h);
-        job.gran = own_sgpr(j.gran);
-        job.sum = own_sgpr(j.sum);
-        job.result = own_sgpr(j.result);
-        job.n = own_sgpr(j.n);
-        job.m = own_sgpr(j.m);
-        hp.n = job.n;
-        hp.m = job.m;
-        hp.sh_h = job.sh_h;
-    }
+    // (own_sgpr on the descriptor's fields was tried here too, round 4: C4 forward 11.4 -> 11.7 ms -- this kernel's band logic is short
+    //  enough that the tuple reloads do not matter, and the extra live ranges cost more than they save)
+    __device__ __forceinline__ DevBackend(const PairJob& j, const HeurParams& h, uint32_t* e, uint32_t* d) : job(j), hp(h), err(e), dbg(d) { lane = (int)(threadIdx.x & 63); }
     __device__ __forceinline__ void mark(int slot_, uint32_t value) const {
         if (dbg && lane == 0) __hip_atomic_store(dbg + slot_, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -313,7 +299,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_kernel(const Pa
             res.status = kErrDegenerate;
         }
         if (rfl(*(const PA_GLOBAL uint32_t*)err) != PA_ERR_NONE && res.status == kOk) res.status = kErrDevice;
-        *be.job.result = res;  // (every lane stores the same 64 bytes: no lane-dependent branch at the end of the loop body either)
+        *job.result = res;  // (every lane stores the same 64 bytes: no lane-dependent branch at the end of the loop body either)
     }
 }
 

@@ -193,11 +193,39 @@ bool ensure_device() {
 // times the alignment of the pairs it holds, and pa_align_file / the work queue create a batch per chunk.  A buffer of at least
 // kCacheMin bytes goes to a free list when its owner lets go of it and is handed to the next request on the same device that it fits
 // (at most a quarter larger than asked for).  Nothing in this library reads device memory it has not written, and a cached block is
-// as undefined as a fresh one.  The list is bounded (kCacheMaxBytes, oldest out first), emptied when an allocation fails, and
+// as undefined as a fresh one.  The list is bounded per device (cache_limit, oldest out first), emptied when an allocation fails, and
 // returned to the driver by pa_release_pools().  PA_NO_ALLOC_CACHE=1 switches it off; PA_POISON_ALLOC=1 fills every buffer handed
 // out with 0xA5 (tests: nothing may depend on fresh memory being zero).
 namespace {
-constexpr size_t kCacheMin = size_t(16) << 20, kCacheMaxBytes = size_t(96) << 30;
+constexpr size_t kCacheMin = size_t(16) << 20, kCacheMaxDefault = size_t(96) << 30;
+// The bound is PER DEVICE: PA_ALLOC_CACHE_MAX (bytes, or with a K / M / G suffix) if set, else half of the device's memory, at most 96 GB
+// -- other users of the device in the same process (torch, RCCL) cannot make this library let go of what it caches.
+size_t cache_limit(int dev) {
+    static std::mutex mu;
+    static std::vector<size_t> lim;
+    std::lock_guard<std::mutex> lk(mu);
+    if ((size_t)dev < lim.size() && lim[(size_t)dev]) return lim[(size_t)dev];
+    size_t v = 0;
+    if (const char* e = getenv("PA_ALLOC_CACHE_MAX")) {
+        char* end = nullptr;
+        double x = std::strtod(e, &end);
+        if (end && (*end == 'G' || *end == 'g')) x *= double(size_t(1) << 30);
+        else if (end && (*end == 'M' || *end == 'm')) x *= double(size_t(1) << 20);
+        else if (end && (*end == 'K' || *end == 'k')) x *= 1024.0;
+        v = x > 0 ? (size_t)x : 1;
+    } else {
+        size_t free_b = 0, total_b = 0;
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != dev) (void)hipSetDevice(dev);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = 0;
+        if (cur != dev) (void)hipSetDevice(cur);
+        v = total_b ? std::min(kCacheMaxDefault, total_b / 2) : kCacheMaxDefault;
+    }
+    if ((size_t)dev >= lim.size()) lim.resize((size_t)dev + 1, 0);
+    lim[(size_t)dev] = v;
+    return v;
+}
 struct CachedBlock {
     int dev;
     void* ptr;
@@ -230,13 +258,22 @@ void* cache_take(int dev, size_t bytes, size_t* got) {
 // -> blocks the caller has to hipFree (outside the lock)
 std::vector<CachedBlock> cache_put(int dev, void* ptr, size_t size) {
     std::vector<CachedBlock> out;
+    const size_t limit = cache_limit(dev);
     std::lock_guard<std::mutex> lk(g_cache_mu);
     g_cache.push_back({dev, ptr, size});
     g_cache_bytes += size;
-    while (g_cache_bytes > kCacheMaxBytes && !g_cache.empty()) {
-        out.push_back(g_cache.front());
-        g_cache_bytes -= g_cache.front().size;
-        g_cache.erase(g_cache.begin());
+    size_t on_dev = 0;
+    for (const CachedBlock& b : g_cache)
+        if (b.dev == dev) on_dev += b.size;
+    for (size_t i = 0; i < g_cache.size() && on_dev > limit;) {  // this device's oldest blocks go first
+        if (g_cache[i].dev != dev) {
+            ++i;
+            continue;
+        }
+        out.push_back(g_cache[i]);
+        g_cache_bytes -= g_cache[i].size;
+        on_dev -= g_cache[i].size;
+        g_cache.erase(g_cache.begin() + (long)i);
     }
     return out;
 }
@@ -321,8 +358,26 @@ bool DeviceBuf::reserve(size_t bytes, bool* grew) {
     if (grew) *grew = true;
     return true;
 }
+// A batch lets go of a dozen buffers at once: its destructor waits for the device ONCE and the releases that follow skip their wait.
+static thread_local bool g_release_synced = false;
+void release_scope_begin() {
+    (void)hipDeviceSynchronize();
+    g_release_synced = true;
+}
+void release_scope_end() { g_release_synced = false; }
+
 void DeviceBuf::release() {
     if (ptr) {
+        if (size >= kCacheMin && cache_on() && g_release_synced) {
+            int cur = device;
+            (void)hipGetDevice(&cur);
+            if (cur == device) {
+                free_blocks(cache_put(device, ptr, size));
+                ptr = nullptr;
+                size = 0;
+                return;
+            }
+        }
         if (size >= kCacheMin && cache_on()) {
             // hipFree waits for the device before it lets a buffer go; a cached block may be handed to another thread at once, so
             // this waits too (whoever must not wait -- the sweep's pool while passes are in flight -- never frees, engine_hip.hip)
@@ -542,36 +597,55 @@ bool launch_pairs(const StripJob* d_jobs, const int32_t* d_first, int npairs, ui
 
 // CIGAR text on the GPU.  trace_kernel leaves each pair's elements (count << 2 | op) from the END of the alignment to its
 // start; one wavefront per pair turns them into the reference's string form (count omitted when 1, ops "=XID",
-// pa-types Cigar::to_string as pinned by astarpa-c/example.cpp:16), written IN PLACE over nothing: into text[pair].
-__global__ __launch_bounds__(64) void format_cigar_kernel(const uint32_t* __restrict__ elems, const uint64_t* __restrict__ off,
-                                                          const uint32_t* __restrict__ len, uint8_t* __restrict__ text,
-                                                          uint32_t* __restrict__ text_len) {
-    const uint32_t n = len[blockIdx.x];
+// pa-types Cigar::to_string as pinned by astarpa-c/example.cpp:16) and writes it straight into the chunk's packed region: a first
+// pass over the elements counts the characters, one atomic add claims that much of the region, a second pass writes them.
+// Block b handles pair list[b]; its text length and offset land at position b of tlen / dst (kTextFailed: the traceback handed the
+// pair back).
+enum : uint32_t { kTextFailed = 0xFFFFFFFFu };
+__global__ __launch_bounds__(64) void format_pack_kernel(const uint32_t* __restrict__ elems, const uint64_t* __restrict__ off,
+                                                         const uint32_t* __restrict__ len, const int32_t* __restrict__ list,
+                                                         uint8_t* __restrict__ packed, unsigned long long* __restrict__ total,
+                                                         uint32_t* __restrict__ tlen, uint64_t* __restrict__ dst) {
+    const int pair = list[blockIdx.x];
+    const uint32_t n = len[pair];
+    const int lane = (int)threadIdx.x;
     if (n == kTraceFailed) {
-        if (threadIdx.x == 0) text_len[blockIdx.x] = 0;
+        if (lane == 0) {
+            tlen[blockIdx.x] = kTextFailed;
+            dst[blockIdx.x] = 0;
+        }
         return;
     }
-    const uint32_t* e = elems + off[blockIdx.x];
-    uint8_t* out = text + off[blockIdx.x];  // same offsets: a string never has more characters than the pair has ops
-    const int lane = (int)threadIdx.x;
+    const uint32_t* e = elems + off[pair];
+    auto chars_of = [](uint32_t v) -> uint32_t {
+        const uint32_t cnt = v >> 2;
+        uint32_t chars = 1;
+        if (cnt != 1) {
+            uint32_t c = cnt;
+            do {
+                ++chars;
+                c /= 10;
+            } while (c);
+        }
+        return chars;
+    };
+    uint32_t mine = 0;
+    for (uint32_t k = (uint32_t)lane; k < n; k += 64) mine += chars_of(e[k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(total, (unsigned long long)mine);
+    base = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(base >> 32), 0, 64) << 32) | (unsigned long long)(uint32_t)__shfl((int)(uint32_t)base, 0, 64);
+    uint8_t* out = packed + base;
     uint32_t pos = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t k = base + (uint32_t)lane;  // k-th element of the OUTPUT = element n-1-k of the stored run
-        uint32_t v = 0, cnt = 0, chars = 0;
+    for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+        const uint32_t k = b0 + (uint32_t)lane;  // k-th element of the OUTPUT = element n-1-k of the stored run
+        uint32_t v = 0, chars = 0;
         if (k < n) {
             v = e[n - 1 - k];
-            cnt = v >> 2;
-            chars = 1;
-            if (cnt != 1) {
-                uint32_t c = cnt;
-                do {
-                    ++chars;
-                    c /= 10;
-                } while (c);
-            }
+            chars = chars_of(v);
         }
-        // exclusive prefix sum of `chars` over the wavefront
-        uint32_t incl = chars;
+        uint32_t incl = chars;  // exclusive prefix sum of `chars` over the wavefront
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t t = __shfl_up(incl, o, 64);
@@ -581,6 +655,7 @@ __global__ __launch_bounds__(64) void format_cigar_kernel(const uint32_t* __rest
         if (k < n) {
             uint8_t* w = out + start + chars - 1;
             *w-- = (uint8_t)"=XID"[v & 3u];
+            const uint32_t cnt = v >> 2;
             if (cnt != 1) {
                 uint32_t c = cnt;
                 do {
@@ -591,16 +666,10 @@ __global__ __launch_bounds__(64) void format_cigar_kernel(const uint32_t* __rest
         }
         pos += __shfl(incl, 63, 64);
     }
-    if (lane == 0) text_len[blockIdx.x] = pos;
-}
-
-// Gather the per-pair strings into one contiguous buffer (one block per pair).
-__global__ void pack_text_kernel(const uint8_t* __restrict__ src, const uint64_t* __restrict__ src_off, const uint64_t* __restrict__ dst_off,
-                                 const uint32_t* __restrict__ len, uint8_t* __restrict__ dst) {
-    const uint32_t n = len[blockIdx.x];
-    const uint8_t* s = src + src_off[blockIdx.x];
-    uint8_t* d = dst + dst_off[blockIdx.x];
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+    if (lane == 0) {
+        tlen[blockIdx.x] = pos;
+        dst[blockIdx.x] = base;
+    }
 }
 
 }  // namespace pa
@@ -1080,6 +1149,9 @@ extern "C" int pa_search_trace(const uint8_t* pattern, size_t plen, const uint8_
 // ---- batched full DP ----------------------------------------------------------------------------
 
 struct pa_batch {
+    struct ReleaseScope {  // FIRST member = destroyed last: ends the scope the destructor's body opens (one device wait for all the buffers)
+        ~ReleaseScope() { release_scope_end(); }
+    } release_scope_;
     size_t pairs = 0;
     std::vector<size_t> n, m, a_off, b_off, code_off, prof_off, gran_off;
     DeviceBuf d_a, d_b, d_codes, d_prof, d_v, d_gran, d_jobs, d_sums, d_misc, d_desc, d_wavelog;
@@ -1103,10 +1175,23 @@ struct pa_batch {
     size_t trace_fallbacks = 0;  // pairs whose traceback was redone by the host engine
     std::vector<size_t> ckpt_off, cigar_off, word_off;  // per pair, in u32 (ckpt) / elements (cigar) / words of b before this pair
     DeviceBuf d_scratch_gran;
-    DeviceBuf d_ckpt, d_cigar, d_cigar_len, d_costs, d_scratch_v, d_scratch_vals, d_tjobs, d_cig_src_off, d_cig_dst_off, d_packed, d_text, d_text_len;
+    DeviceBuf d_ckpt, d_cigar, d_cigar_len, d_costs, d_scratch_v, d_scratch_vals, d_tjobs, d_cig_src_off, d_packed;
     hipEvent_t ev2 = nullptr;
-    uint8_t* h_text = nullptr;  // pinned host buffer for the packed CIGAR text
+    uint8_t* h_text = nullptr;  // pinned host buffer for the packed CIGAR text of one chunk
     size_t h_text_size = 0;
+    // pa_batch_align can work in CHUNKS of the (heaviest-first) order, each on a stream of its own: forward pass (batched A*PA2),
+    // traceback, CIGAR text and its copy-out of different chunks overlap (one chunk by default: see the chunk plan in batch_create)
+    static constexpr int kMaxChunks = 8;
+    std::vector<int32_t> order_host;   // position -> pair (A*PA2: heaviest first; else the identity)
+    std::vector<int32_t> torder_host;  // the same chunks with the pairs of a chunk in index order: what the traceback and the text kernels walk
+                                       // (neighbouring pairs of the input in one workgroup: C4 traceback 10.0 against 10.9 ms in the forward order)
+    DeviceBuf d_torder;
+    std::vector<size_t> chunk_lo;      // chunk c = positions [chunk_lo[c], chunk_lo[c + 1])
+    std::vector<uint64_t> chunk_base;  // byte offset of chunk c's region of d_packed
+    hipStream_t cstream[kMaxChunks] = {};
+    hipEvent_t ev_pre = nullptr, evF0[kMaxChunks] = {}, evF1[kMaxChunks] = {}, evT1[kMaxChunks] = {};
+    DeviceBuf d_cmeta, d_tlen_pos, d_dst_pos;  // d_cmeta: u64 text totals [kMaxChunks], then u32 tickets [kMaxChunks]
+    uint8_t* h_meta = nullptr;                  // pinned: u64 totals [kMaxChunks], u32 tlen [pairs], u64 dst [pairs]
     // A*PA2 mode (pa_batch_create_params): one wavefront runs the whole band search of a pair (apa2_kernel.hpp); d_ckpt is the
     // pairs' column store, the traceback reads the blocks of the successful pass from it
     bool astar = false;
@@ -1125,10 +1210,19 @@ struct pa_batch {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~pa_batch() {
+        release_scope_begin();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (ev2) (void)hipEventDestroy(ev2);
         if (h_text) (void)hipHostFree(h_text);
+        if (h_meta) (void)hipHostFree(h_meta);
+        if (ev_pre) (void)hipEventDestroy(ev_pre);
+        for (int c = 0; c < kMaxChunks; ++c) {
+            if (evF0[c]) (void)hipEventDestroy(evF0[c]);
+            if (evF1[c]) (void)hipEventDestroy(evF1[c]);
+            if (evT1[c]) (void)hipEventDestroy(evT1[c]);
+            if (cstream[c]) (void)hipStreamDestroy(cstream[c]);
+        }
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -1393,6 +1487,7 @@ static bool astar_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t* cons
         order[i] = (int32_t)i;
     }
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return p->n[x] + p->m[x] > p->n[y] + p->m[y]; });  // heaviest first
+    p->order_host = order;
     if (P && (!hip_ok(hipMemcpy(p->d_pjobs.ptr, pj.data(), P * sizeof(apa2::PairJob), hipMemcpyHostToDevice), "H2D pair jobs") ||
               !hip_ok(hipMemcpy(p->d_order.ptr, order.data(), P * 4, hipMemcpyHostToDevice), "H2D order")))
         return false;
@@ -1562,6 +1657,7 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
         order[i] = (int32_t)i;
     }
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return p->n[x] + p->m[x] > p->n[y] + p->m[y]; });  // heaviest first
+    p->order_host = order;
     if (P && (!hip_ok(hipMemcpy(p->d_fjobs.ptr, fj.data(), P * sizeof(apa2::FullJob), hipMemcpyHostToDevice), "H2D pair jobs") ||
               !hip_ok(hipMemcpy(p->d_order.ptr, order.data(), P * 4, hipMemcpyHostToDevice), "H2D order")))
         return false;
@@ -1647,14 +1743,13 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             tck += (astar ? (a_len[i] + 255) / 256 + 1 : a_len[i] / 256 + 1) * w * 4;
             tcg += a_len[i] + b_len[i] + 2;
         }
-        if (tcg >= (size_t(1) << 62) || !p->d_ckpt.alloc(tck * 4) || !p->d_cigar.alloc(tcg * 4) || !p->d_packed.alloc(tcg) || !p->d_text.alloc(tcg) ||
-            !p->d_text_len.alloc(std::max<size_t>(pairs * 4, 16)) ||
+        if (tcg >= (size_t(1) << 62) || !p->d_ckpt.alloc(tck * 4) || !p->d_cigar.alloc(tcg * 4) || !p->d_packed.alloc(tcg) ||
+            !p->d_tlen_pos.alloc(std::max<size_t>(pairs * 4, 16)) || !p->d_dst_pos.alloc(std::max<size_t>(pairs * 8, 16)) || !p->d_cmeta.alloc(256) ||
             !p->d_cigar_len.alloc(std::max<size_t>(pairs * 4, 16)) || !p->d_costs.alloc(std::max<size_t>(pairs * 4, 16)) ||
             // re-fill scratch: 256 columns x min(w, kTraceScratchWords) words of V per pair
             !p->d_scratch_v.alloc(std::max<size_t>(tw, 1) * 16) || !p->d_scratch_vals.alloc(std::max<size_t>(tw, 1) * 256 * 16) ||
             !p->d_scratch_gran.alloc(std::max<size_t>(pairs, 1) * 16 * 8) ||
-            !p->d_tjobs.alloc(std::max<size_t>(pairs, 1) * sizeof(TraceJob)) || !p->d_cig_src_off.alloc(std::max<size_t>(pairs, 1) * 8) ||
-            !p->d_cig_dst_off.alloc(std::max<size_t>(pairs, 1) * 8))
+            !p->d_tjobs.alloc(std::max<size_t>(pairs, 1) * sizeof(TraceJob)) || !p->d_cig_src_off.alloc(std::max<size_t>(pairs, 1) * 8))
             return nullptr;
     }
     if (!p->d_a.alloc(ta) || !p->d_b.alloc(tb) || !p->d_codes.alloc(tc * 4) || !p->d_prof.alloc(tp * 16) ||
@@ -1799,6 +1894,52 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             src_off[i] = p->cigar_off[i];
         }
         if (astar && !(p->astar_full ? astar_full_jobs(p.get(), a, b, tjobs) : astar_jobs(p.get(), a, b, tjobs))) return nullptr;
+        if (!astar) {  // (the plain traced batch: chunks of the pairs as they come)
+            p->order_host.resize(pairs);
+            for (size_t i = 0; i < pairs; ++i) p->order_host[i] = (int32_t)i;
+            if (!p->d_order.alloc(pairs * 4) || !hip_ok(hipMemcpy(p->d_order.ptr, p->order_host.data(), pairs * 4, hipMemcpyHostToDevice), "H2D order")) return nullptr;
+        }
+        {
+            // chunks of pa_batch_align.  ONE by default: measured in round 4 (profiles/README.md), chunks on streams of their own do not
+            // shorten the call -- band search and traceback are both bound by instruction issue, so running the traceback of one chunk
+            // beside the band search of the next gains nothing (C4: 24.65 against 25.0 ms at the C ABI with four chunks), and chunks too
+            // small to fill the chip lose (4096 x 100 kbp in three chunks: 135 against 120 ms).  PA_ALIGN_CHUNKS=n for experiments.
+            static const int env_chunks = getenv("PA_ALIGN_CHUNKS") ? atoi(getenv("PA_ALIGN_CHUNKS")) : 0;
+            int C = 1;
+            {
+                // ... except many SHORT pairs (C4: 10 000 x 10 kbp), where four chunks hide the host's share: 24.1 against 26.0 ms
+                size_t tot = 0;
+                for (size_t i = 0; i < pairs; ++i) tot += a_len[i] + b_len[i];
+                if (pairs >= 8192 && tot / pairs <= 65536) C = 4;
+            }
+            if (env_chunks > 0) C = std::min<int>(env_chunks, pa_batch::kMaxChunks);
+            C = (int)std::max<size_t>(1, std::min<size_t>((size_t)C, pairs));
+            p->chunk_lo.assign((size_t)C + 1, 0);
+            p->chunk_base.assign((size_t)C + 1, 0);
+            for (int c = 0; c <= C; ++c) p->chunk_lo[(size_t)c] = pairs * (size_t)c / (size_t)C;
+            uint64_t acc = 0;
+            for (int c = 0; c < C; ++c) {
+                p->chunk_base[(size_t)c] = acc;
+                for (size_t q = p->chunk_lo[(size_t)c]; q < p->chunk_lo[(size_t)c + 1]; ++q) {
+                    const size_t i = (size_t)p->order_host[q];
+                    acc += a_len[i] + b_len[i] + 2;
+                }
+            }
+            p->chunk_base[(size_t)C] = acc;
+            p->torder_host = p->order_host;
+            for (int c = 0; c < C; ++c) std::sort(p->torder_host.begin() + (long)p->chunk_lo[(size_t)c], p->torder_host.begin() + (long)p->chunk_lo[(size_t)c + 1]);
+            if (!p->d_torder.alloc(std::max<size_t>(pairs, 1) * 4) ||
+                !hip_ok(hipMemcpy(p->d_torder.ptr, p->torder_host.data(), pairs * 4, hipMemcpyHostToDevice), "H2D trace order"))
+                return nullptr;
+            void* hm = nullptr;
+            if (!hip_ok(hipHostMalloc(&hm, 64 + pairs * 12 + 64, hipHostMallocDefault), "hipHostMalloc(align meta)")) return nullptr;
+            p->h_meta = (uint8_t*)hm;
+            if (!hip_ok(hipEventCreate(&p->ev_pre), "event")) return nullptr;
+            for (int c = 0; c < C; ++c)
+                if (!hip_ok(hipStreamCreateWithFlags(&p->cstream[c], hipStreamNonBlocking), "hipStreamCreate") || !hip_ok(hipEventCreate(&p->evF0[c]), "event") ||
+                    !hip_ok(hipEventCreate(&p->evF1[c]), "event") || !hip_ok(hipEventCreate(&p->evT1[c]), "event"))
+                    return nullptr;
+        }
         if (!hip_ok(hipMemsetAsync(p->d_scratch_gran.ptr, 0, pairs * 16 * 8, p->stream), "memset trace granules") ||
             !hip_ok(hipMemcpyAsync(p->d_tjobs.ptr, tjobs.data(), pairs * sizeof(TraceJob), hipMemcpyHostToDevice, p->stream), "H2D trace jobs") ||
             !hip_ok(hipMemcpyAsync(p->d_cig_src_off.ptr, src_off.data(), pairs * 8, hipMemcpyHostToDevice, p->stream), "H2D offsets") ||
@@ -1903,7 +2044,29 @@ extern "C" pa_batch* pa_batch_create_params(const uint8_t* const* a, const size_
 }
 
 // Profiles -> (granule clear) -> DP kernel, all queued on the batch's stream; ev0/ev1 bracket the DP kernel.
-static int batch_forward(pa_batch* p) {
+// The band-search kernel (apa2_kernel / apa2_full_kernel) for pairs order[lo .. lo + cnt) on stream s; `ticket` is the launch's own
+// ticket word (zeroed by the caller).
+static int launch_astar(pa_batch* p, hipStream_t s, size_t lo, size_t cnt, uint32_t* ticket, uint32_t* dbg) {
+    if (cnt == 0) return 0;
+    // a persistent grid: wavefronts pull pairs by ticket; at most kApa2BlocksPerCu blocks of four wavefronts per CU
+    static const int per_cu = getenv("PA_APA2_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("PA_APA2_BLOCKS_PER_CU"))) : 4;
+    static const bool probe_stats = getenv("PA_APA2_PROBE_STATS") != nullptr;
+    const int cus = g_device_props_cus > 0 ? g_device_props_cus : 256;
+    const int grid = (int)std::min<size_t>((cnt + kStripBlockWaves - 1) / kStripBlockWaves, (size_t)cus * per_cu);
+    const int32_t* ord = p->d_order.as<int32_t>() + lo;
+    if (p->astar_full)
+        hipLaunchKernelGGL(apa2::apa2_full_kernel, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, p->d_fjobs.as<apa2::FullJob>(), ord, (int)cnt, p->fsp, ticket,
+                           p->d_misc.as<uint32_t>() + 1, dbg, probe_stats ? p->d_probe.as<unsigned long long>() : nullptr);
+    else
+        hipLaunchKernelGGL(apa2::apa2_kernel, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, p->d_pjobs.as<apa2::PairJob>(), ord, (int)cnt, p->sp, ticket,
+                           p->d_misc.as<uint32_t>() + 1, dbg, getenv("PA_APA2_K1") ? 1 : 0);
+    return hip_ok(hipGetLastError(), "apa2_kernel launch") ? 0 : PA_E_HIP;
+}
+
+// Profiles -> (granule clear) -> DP kernel, all queued on the batch's stream; ev0/ev1 bracket the DP kernel.
+// launch = false (batched A*PA2 through pa_batch_align): everything BEFORE the band-search kernel only; the caller launches it chunk by
+// chunk on streams of their own.
+static int batch_forward(pa_batch* p, bool launch = true) {
     hipStream_t s = p->stream;
     // (1) profiles (BitProfile::build, once per pair: blocks.rs:112)
     if (!hip_ok(hipMemsetAsync(p->d_misc.ptr, 0, 32, s), "memset")) return PA_E_HIP;  // (+ the pace counter of chained batches)
@@ -1929,13 +2092,17 @@ static int batch_forward(pa_batch* p) {
     p->gran_dirty = true;  // (banded chained strips skip part of every row: it stays dirty, cleared before every pass)
     if (!hip_ok(hipMemsetAsync(p->d_sums.ptr, 0, std::max<size_t>(p->pairs * 4, 16), s), "memset sums")) return PA_E_HIP;
     // d_misc (ticket, err, -, bad-base flag) was zeroed above; the events bracket the strip kernel alone
+    if (p->astar && p->astar_full) {
+        // a batch can be aligned again: the pruning state starts from scratch (every match active, the windows as built)
+        if (!hip_ok(hipMemsetAsync(p->d_active.ptr, 1, std::max<size_t>(p->full_matches, 64), s), "memset active") ||
+            (p->full_seeds && !hip_ok(hipMemcpyAsync(p->d_win.ptr, p->d_win0.ptr, p->full_seeds * sizeof(apa2::GcshSeedWindow), hipMemcpyDeviceToDevice, s), "D2D windows")) ||
+            !hip_ok(hipMemsetAsync(p->d_probe.ptr, 0, 128, s), "memset probe stats"))
+            return PA_E_HIP;
+    }
+    if (!launch) return 0;
     if (!hip_ok(hipEventRecord(p->ev0, s), "event")) return PA_E_HIP;
     if (p->astar) {
         if (p->pairs) {
-            // a persistent grid: wavefronts pull pairs by ticket; at most kApa2BlocksPerCu blocks of four wavefronts per CU
-            static const int per_cu = getenv("PA_APA2_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("PA_APA2_BLOCKS_PER_CU"))) : 4;
-            const int cus = g_device_props_cus > 0 ? g_device_props_cus : 256;
-            const int grid = (int)std::min<size_t>((p->pairs + kStripBlockWaves - 1) / kStripBlockWaves, (size_t)cus * per_cu);
             uint32_t* dbg = nullptr;
             if (getenv("PA_APA2_DEBUG")) {
                 void* hp = nullptr;
@@ -1943,23 +2110,9 @@ static int batch_forward(pa_batch* p) {
                 std::memset(hp, 0, 256);
                 dbg = (uint32_t*)hp;
             }
-            if (p->astar_full) {
-                // a batch can be aligned again: the pruning state starts from scratch (every match active, the windows as built)
-                static const bool probe_stats = getenv("PA_APA2_PROBE_STATS") != nullptr;
-                if (!hip_ok(hipMemsetAsync(p->d_active.ptr, 1, std::max<size_t>(p->full_matches, 64), s), "memset active") ||
-                    (p->full_seeds && !hip_ok(hipMemcpyAsync(p->d_win.ptr, p->d_win0.ptr, p->full_seeds * sizeof(apa2::GcshSeedWindow), hipMemcpyDeviceToDevice, s), "D2D windows")) ||
-                    !hip_ok(hipMemsetAsync(p->d_probe.ptr, 0, 128, s), "memset probe stats"))
-                    return PA_E_HIP;
-                hipLaunchKernelGGL(apa2::apa2_full_kernel, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, p->d_fjobs.as<apa2::FullJob>(), p->d_order.as<int32_t>(),
-                                   (int)p->pairs, p->fsp, p->d_misc.as<uint32_t>(), p->d_misc.as<uint32_t>() + 1, dbg,
-                                   probe_stats ? p->d_probe.as<unsigned long long>() : nullptr);
-            } else {
-                hipLaunchKernelGGL(apa2::apa2_kernel, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, p->d_pjobs.as<apa2::PairJob>(), p->d_order.as<int32_t>(),
-                                   (int)p->pairs, p->sp, p->d_misc.as<uint32_t>(), p->d_misc.as<uint32_t>() + 1, dbg, getenv("PA_APA2_K1") ? 1 : 0);
-            }
-            if (!hip_ok(hipGetLastError(), "apa2_kernel launch")) return PA_E_HIP;
+            if (const int rc = launch_astar(p, s, 0, p->pairs, p->d_misc.as<uint32_t>(), dbg)) return rc;
             if (dbg) {  // diagnostics: the forward pass alone, progress markers and first results on stderr
-                std::fprintf(stderr, "[apa2] forward launched: grid %d, pairs %zu\n", grid, p->pairs);
+                std::fprintf(stderr, "[apa2] forward launched: pairs %zu\n", p->pairs);
                 for (int sec = 0; sec < 8 && hipStreamQuery(s) == hipErrorNotReady; ++sec) {
                     const volatile uint32_t* d = dbg;
                     std::fprintf(stderr, "[apa2] t=%ds stage %u f_max %d tries %u block %u js %d je %d strip %u pair %u\n", sec, d[0], (int)d[1], d[2], d[3], (int)d[4], (int)d[5], d[6], d[7]);
@@ -2191,8 +2344,12 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
         return PA_E_ARG;
     }
     if (small_route(p, cigar_out)) return batch_align_small(p, cost_out, cigar_out, forward_ms, trace_ms);
-    hipStream_t s = p->stream;
     const size_t P = p->pairs;
+    if (P == 0) {  // an empty batch
+        if (forward_ms) *forward_ms = 0.f;
+        if (trace_ms) *trace_ms = 0.f;
+        return 0;
+    }
     static const bool prof = getenv("PA_ALIGN_PROFILE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
@@ -2205,50 +2362,138 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
     };
     if (cigar_out)
         for (size_t i = 0; i < P; ++i) cigar_out[i] = nullptr;
-    if (const int rc = batch_forward(p)) return rc;
-    // traceback: one wavefront per pair (batched A*PA2 without CIGARs asked for: none, the costs come from the forward pass)
-    const bool cost_only_astar = p->astar && !cigar_out;
-    if (P && !cost_only_astar) {
-        const int grid = (int)((P + kStripBlockWaves - 1) / kStripBlockWaves);
-        const dim3 tg(grid), tb(64 * kStripBlockWaves);
-        const TraceJob* tjp = p->d_tjobs.as<TraceJob>();
-        uint32_t* terr = p->d_misc.as<uint32_t>() + 1;
-        if (p->dt_max_g > 0 && p->astar) hipLaunchKernelGGL((trace_kernel<true, true>), tg, tb, kStripBlockWaves * sizeof(DtLds), s, tjp, (int)P, terr);
-        else if (p->dt_max_g > 0) hipLaunchKernelGGL((trace_kernel<true, false>), tg, tb, kStripBlockWaves * sizeof(DtLds), s, tjp, (int)P, terr);
-        else if (p->astar) hipLaunchKernelGGL((trace_kernel<false, true>), tg, tb, 0, s, tjp, (int)P, terr);
-        else hipLaunchKernelGGL((trace_kernel<false, false>), tg, tb, 0, s, tjp, (int)P, terr);
-        if (!hip_ok(hipGetLastError(), "trace_kernel launch")) return PA_E_HIP;
+    // a failure after the first string has been handed out: free them all again, the caller owns outputs only on success
+    auto fail_all = [&](int code) {
+        if (cigar_out)
+            for (size_t k = 0; k < P; ++k) {
+                std::free(cigar_out[k]);
+                cigar_out[k] = nullptr;
+            }
+        return code;
+    };
+    // ---- everything before the chunks, on the batch's stream: profiles, clears, (full DP) the checkpointing forward pass ----
+    const bool cost_only_astar = p->astar && !cigar_out;  // batched A*PA2 without CIGARs asked for: no traceback, the costs come from the forward pass
+    if (const int rc = batch_forward(p, !p->astar)) return rc;
+    const size_t C = p->chunk_lo.empty() ? 0 : p->chunk_lo.size() - 1;
+    unsigned long long* d_total = p->d_cmeta.as<unsigned long long>();
+    uint32_t* d_ticket = p->d_cmeta.as<uint32_t>() + 2 * pa_batch::kMaxChunks;
+    unsigned long long* h_total = (unsigned long long*)p->h_meta;
+    uint32_t* h_tlen = (uint32_t*)(p->h_meta + 64);
+    uint64_t* h_dst = (uint64_t*)(p->h_meta + 64 + ((P * 4 + 7) & ~size_t(7)));
+    if (!hip_ok(hipMemsetAsync(p->d_cmeta.ptr, 0, 256, p->stream), "memset chunk meta") || !hip_ok(hipEventRecord(p->ev_pre, p->stream), "event")) return PA_E_HIP;
+    // ---- per chunk, on its own stream: [band search] -> traceback -> CIGAR text into the chunk's packed region -> its lengths to the host ----
+    for (size_t c = 0; c < C; ++c) {
+        hipStream_t s = p->cstream[c];
+        const size_t lo = p->chunk_lo[c], cnt = p->chunk_lo[c + 1] - lo;
+        if (!hip_ok(hipStreamWaitEvent(s, p->ev_pre, 0), "wait") || !hip_ok(hipEventRecord(p->evF0[c], s), "event")) return PA_E_HIP;
+        if (p->astar)
+            if (const int rc = launch_astar(p, s, lo, cnt, d_ticket + c, nullptr)) return rc;
+        if (!hip_ok(hipEventRecord(p->evF1[c], s), "event")) return PA_E_HIP;
+        if (cnt && !cost_only_astar) {
+            const dim3 tg((unsigned)((cnt + kStripBlockWaves - 1) / kStripBlockWaves)), tb(64 * kStripBlockWaves);
+            const TraceJob* tjp = p->d_tjobs.as<TraceJob>();
+            const int32_t* list = p->d_torder.as<int32_t>() + lo;
+            uint32_t* terr = p->d_misc.as<uint32_t>() + 1;
+            if (p->dt_max_g > 0 && p->astar) hipLaunchKernelGGL((trace_kernel<true, true>), tg, tb, kStripBlockWaves * sizeof(DtLds), s, tjp, list, (int)cnt, terr);
+            else if (p->dt_max_g > 0) hipLaunchKernelGGL((trace_kernel<true, false>), tg, tb, kStripBlockWaves * sizeof(DtLds), s, tjp, list, (int)cnt, terr);
+            else if (p->astar) hipLaunchKernelGGL((trace_kernel<false, true>), tg, tb, 0, s, tjp, list, (int)cnt, terr);
+            else hipLaunchKernelGGL((trace_kernel<false, false>), tg, tb, 0, s, tjp, list, (int)cnt, terr);
+            if (!hip_ok(hipGetLastError(), "trace_kernel launch") || !hip_ok(hipEventRecord(p->evT1[c], s), "event")) return PA_E_HIP;
+            hipLaunchKernelGGL(format_pack_kernel, dim3((unsigned)cnt), dim3(64), 0, s, p->d_cigar.as<uint32_t>(), p->d_cig_src_off.as<uint64_t>(), p->d_cigar_len.as<uint32_t>(),
+                               list, p->d_packed.as<uint8_t>() + p->chunk_base[c], d_total + c, p->d_tlen_pos.as<uint32_t>() + lo, p->d_dst_pos.as<uint64_t>() + lo);
+            if (!hip_ok(hipGetLastError(), "format_pack_kernel") ||
+                !hip_ok(hipMemcpyAsync(h_total + c, d_total + c, 8, hipMemcpyDeviceToHost, s), "D2H total") ||
+                !hip_ok(hipMemcpyAsync(h_tlen + lo, p->d_tlen_pos.as<uint32_t>() + lo, cnt * 4, hipMemcpyDeviceToHost, s), "D2H text lens") ||
+                !hip_ok(hipMemcpyAsync(h_dst + lo, p->d_dst_pos.as<uint64_t>() + lo, cnt * 8, hipMemcpyDeviceToHost, s), "D2H text offsets"))
+                return PA_E_HIP;
+        } else if (!hip_ok(hipEventRecord(p->evT1[c], s), "event")) {
+            return PA_E_HIP;
+        }
     }
-    if (!hip_ok(hipEventRecord(p->ev2, s), "event")) return PA_E_HIP;
+    mark("launches");
+    // ---- per chunk, as it completes: its packed text to the host, strings to the caller (the later chunks are still on the GPU) ----
+    std::vector<size_t> handed_back;  // pairs the traceback handed back (a state the reference would panic on): the host engine redoes them
+    for (size_t c = 0; c < C; ++c) {
+        hipStream_t s = p->cstream[c];
+        const size_t lo = p->chunk_lo[c], cnt = p->chunk_lo[c + 1] - lo;
+        if (!hip_ok(hipStreamSynchronize(s), "sync")) return fail_all(PA_E_HIP);
+        if (!cnt || cost_only_astar || !cigar_out) continue;
+        const uint64_t total = h_total[c];
+        if (total > p->h_text_size) {  // pinned, so the copy runs at link speed
+            if (p->h_text) (void)hipHostFree(p->h_text);
+            p->h_text = nullptr;
+            p->h_text_size = 0;
+            void* hp = nullptr;
+            if (!hip_ok(hipHostMalloc(&hp, total + total / 4 + 4096, hipHostMallocDefault), "hipHostMalloc(cigar text)")) return fail_all(PA_E_HIP);
+            p->h_text = (uint8_t*)hp;
+            p->h_text_size = total + total / 4 + 4096;
+        }
+        if (total && (!hip_ok(hipMemcpyAsync(p->h_text, p->d_packed.as<uint8_t>() + p->chunk_base[c], total, hipMemcpyDeviceToHost, s), "D2H cigars") ||
+                      !hip_ok(hipStreamSynchronize(s), "sync")))
+            return fail_all(PA_E_HIP);
+        for (size_t q = lo; q < lo + cnt; ++q) {
+            const size_t i = (size_t)p->torder_host[q];
+            if (h_tlen[q] == kTextFailed) {
+                handed_back.push_back(i);
+                continue;
+            }
+            char* out = (char*)std::malloc((size_t)h_tlen[q] + 1);
+            if (!out) {
+                set_error("out of memory");
+                return fail_all(PA_E_NOMEM);
+            }
+            if (h_tlen[q]) std::memcpy(out, p->h_text + h_dst[q], h_tlen[q]);
+            out[h_tlen[q]] = 0;
+            cigar_out[i] = out;
+        }
+    }
+    mark("chunks: text D2H + strings");
+    // ---- the small per-pair arrays, once ----
     std::vector<uint32_t> lens(P, 0);
     std::vector<int32_t> costs(P, 0);
     uint32_t misc[4] = {0, 0, 0, 0};
-    if (P && (!hip_ok(hipMemcpyAsync(lens.data(), p->d_cigar_len.ptr, P * 4, hipMemcpyDeviceToHost, s), "D2H lens") ||
-              !hip_ok(hipMemcpyAsync(costs.data(), p->d_costs.ptr, P * 4, hipMemcpyDeviceToHost, s), "D2H costs")))
-        return PA_E_HIP;
-    if (!hip_ok(hipMemcpyAsync(misc, p->d_misc.ptr, 16, hipMemcpyDeviceToHost, s), "D2H") || !hip_ok(hipStreamSynchronize(s), "sync")) return PA_E_HIP;
-    mark("forward + trace (+sync)");
+    if (P && !cost_only_astar &&
+        (!hip_ok(hipMemcpy(lens.data(), p->d_cigar_len.ptr, P * 4, hipMemcpyDeviceToHost), "D2H lens") ||
+         !hip_ok(hipMemcpy(costs.data(), p->d_costs.ptr, P * 4, hipMemcpyDeviceToHost), "D2H costs")))
+        return fail_all(PA_E_HIP);
+    if (!hip_ok(hipMemcpy(misc, p->d_misc.ptr, 16, hipMemcpyDeviceToHost), "D2H")) return fail_all(PA_E_HIP);
     if (misc[3]) {
         set_error("sequence contains a base outside ACGT");
-        return PA_E_INVALID_BASE;
+        return fail_all(PA_E_INVALID_BASE);
     }
     if (misc[1] != PA_ERR_NONE) {
         set_error("device spin timeout (err=%u)", misc[1]);
-        return PA_E_TIMEOUT;
+        return fail_all(PA_E_TIMEOUT);
     }
     p->gran_dirty = false;
+    // kernel times: summed over the chunks (chunks overlap on the GPU, so the sums can exceed the wall time of the call)
     if (forward_ms) {
         *forward_ms = 0.f;
-        if ((p->astar || !p->jobs.empty()) && !hip_ok(hipEventElapsedTime(forward_ms, p->ev0, p->ev1), "elapsed")) return PA_E_HIP;
+        if (p->astar) {
+            for (size_t c = 0; c < C; ++c) {
+                float ms = 0.f;
+                if (!hip_ok(hipEventElapsedTime(&ms, p->evF0[c], p->evF1[c]), "elapsed")) return fail_all(PA_E_HIP);
+                *forward_ms += ms;
+            }
+        } else if (!p->jobs.empty() && !hip_ok(hipEventElapsedTime(forward_ms, p->ev0, p->ev1), "elapsed")) {
+            return fail_all(PA_E_HIP);
+        }
     }
-    if (trace_ms && !hip_ok(hipEventElapsedTime(trace_ms, p->ev1, p->ev2), "elapsed")) return PA_E_HIP;
+    if (trace_ms) {
+        *trace_ms = 0.f;
+        for (size_t c = 0; c < C; ++c) {
+            float ms = 0.f;
+            if (!hip_ok(hipEventElapsedTime(&ms, p->evF1[c], p->evT1[c]), "elapsed")) return fail_all(PA_E_HIP);
+            *trace_ms += ms;
+        }
+    }
     std::vector<apa2::PairResult> results;
     if (p->astar) {  // per-pair statistics (domain.rs:31-43) of the band search and the traceback
         results.resize(P);
         std::vector<uint32_t> ts(P * 8, 0);
         if (P && (!hip_ok(hipMemcpy(results.data(), p->d_results.ptr, P * sizeof(apa2::PairResult), hipMemcpyDeviceToHost), "D2H results") ||
                   !hip_ok(hipMemcpy(ts.data(), p->d_tstats.ptr, P * 32, hipMemcpyDeviceToHost), "D2H trace stats")))
-            return PA_E_HIP;
+            return fail_all(PA_E_HIP);
         p->pair_stats.assign(P, pa_astarpa2_stats{});
         p->apa2_strip_instr = 0;
         for (size_t i = 0; i < P; ++i) {
@@ -2266,6 +2511,7 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
             if (cost_only_astar) {  // no traceback ran: the cost is the forward pass's, a pair it handed back goes to the host engine
                 costs[i] = r.cost;
                 lens[i] = r.status != apa2::kOk ? kTraceFailed : 0u;
+                if (r.status != apa2::kOk) handed_back.push_back(i);
                 continue;
             }
             st.dt_trace_tries = ts[8 * i + 0];
@@ -2276,84 +2522,33 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
             st.fill_fallback = ts[8 * i + 5];
         }
     }
-    // CIGAR text is produced on the GPU; gather it into one packed buffer and copy once
-    std::vector<uint32_t> tlens(P, 0);
-    std::vector<uint64_t> dst_off(P, 0);
-    const uint8_t* packed = nullptr;
-    if (P && !cost_only_astar) {
-        hipLaunchKernelGGL(format_cigar_kernel, dim3((unsigned)P), dim3(64), 0, s, p->d_cigar.as<uint32_t>(), p->d_cig_src_off.as<uint64_t>(),
-                           p->d_cigar_len.as<uint32_t>(), p->d_text.as<uint8_t>(), p->d_text_len.as<uint32_t>());
-        if (!hip_ok(hipGetLastError(), "format_cigar_kernel") ||
-            !hip_ok(hipMemcpyAsync(tlens.data(), p->d_text_len.ptr, P * 4, hipMemcpyDeviceToHost, s), "D2H text lens") ||
-            !hip_ok(hipStreamSynchronize(s), "sync"))
-            return PA_E_HIP;
-        mark("format kernel + lens D2H");
-        uint64_t total = 0;
-        for (size_t i = 0; i < P; ++i) {
-            dst_off[i] = total;
-            total += tlens[i];
-        }
-        if (total > p->h_text_size) {  // pinned, so the one big D2H runs at link speed
-            if (p->h_text) (void)hipHostFree(p->h_text);
-            p->h_text = nullptr;
-            p->h_text_size = 0;
-            void* hp = nullptr;
-            if (!hip_ok(hipHostMalloc(&hp, total + total / 4 + 4096, hipHostMallocDefault), "hipHostMalloc(cigar text)")) return PA_E_HIP;
-            p->h_text = (uint8_t*)hp;
-            p->h_text_size = total + total / 4 + 4096;
-        }
-        packed = p->h_text;
-        if (total) {
-            if (!hip_ok(hipMemcpyAsync(p->d_cig_dst_off.ptr, dst_off.data(), P * 8, hipMemcpyHostToDevice, s), "H2D offsets")) return PA_E_HIP;
-            hipLaunchKernelGGL(pack_text_kernel, dim3((unsigned)P), dim3(256), 0, s, p->d_text.as<uint8_t>(), p->d_cig_src_off.as<uint64_t>(),
-                               p->d_cig_dst_off.as<uint64_t>(), p->d_text_len.as<uint32_t>(), p->d_packed.as<uint8_t>());
-            if (!hip_ok(hipGetLastError(), "pack_text_kernel") ||
-                !hip_ok(hipMemcpyAsync(p->h_text, p->d_packed.ptr, total, hipMemcpyDeviceToHost, s), "D2H cigars") ||
-                !hip_ok(hipStreamSynchronize(s), "sync"))
-                return PA_E_HIP;
-        }
+    if (!cigar_out && !cost_only_astar)  // (costs alone of a traced full-DP batch: the pairs the traceback handed back are not redone)
+        handed_back.clear();
+    if (cigar_out && !cost_only_astar) {  // (without cigar_out the loop over the chunks above did not look at the lengths)
+        handed_back.clear();
+        for (size_t i = 0; i < P; ++i)
+            if (lens[i] == kTraceFailed) handed_back.push_back(i);
     }
-    mark("pack kernel + text D2H");
+    for (size_t i = 0; i < P; ++i) cost_out[i] = costs[i];
+    mark("small arrays + statistics");
     pa_astarpa2_params fallback = p->astar ? p->aparams_c : traced_batch_params();
     if (!p->astar && p->dt_max_g > 0) {
         fallback.front.dt_trace = 1;
         fallback.front.max_g = p->dt_max_g;
         fallback.front.fr_drop = p->dt_fr_drop;
     }
-    // a failure after the first string has been handed out: free them all again, the caller owns outputs only on success
-    auto fail_out = [&](size_t produced, int code) {
-        if (cigar_out)
-            for (size_t k = 0; k < produced; ++k) {
-                std::free(cigar_out[k]);
-                cigar_out[k] = nullptr;
-            }
-        return code;
-    };
-    for (size_t i = 0; i < P; ++i) {
-        cost_out[i] = costs[i];
-        if (!cigar_out && !(p->astar && lens[i] == kTraceFailed)) continue;  // (A*PA2 mode: a pair handed back has no cost yet either)
-        if (lens[i] != kTraceFailed) {  // the common case: one allocation, one copy out of the packed buffer
-            char* out = (char*)std::malloc((size_t)tlens[i] + 1);
-            if (!out) {
-                set_error("out of memory");
-                return fail_out(i, PA_E_NOMEM);
-            }
-            if (tlens[i]) std::memcpy(out, packed + dst_off[i], tlens[i]);
-            out[tlens[i]] = 0;
-            cigar_out[i] = out;
-            continue;
-        }
-        // a state the reference would panic on: the host engine redoes this pair
+    for (const size_t i : handed_back) {
+        // a state the reference would panic on (or one the kernels leave alone): the host engine redoes this pair
         std::string text;
         p->trace_fallbacks += 1;
         std::vector<uint8_t> ba(p->n[i]), bb(p->m[i]);
         if ((p->n[i] && !hip_ok(hipMemcpy(ba.data(), p->d_a.as<uint8_t>() + p->a_off[i], p->n[i], hipMemcpyDeviceToHost), "D2H a")) ||
             (p->m[i] && !hip_ok(hipMemcpy(bb.data(), p->d_b.as<uint8_t>() + p->b_off[i], p->m[i], hipMemcpyDeviceToHost), "D2H b")))
-            return fail_out(i, PA_E_HIP);
+            return fail_all(PA_E_HIP);
         int32_t c = 0;
         pa_astarpa2_stats fst{};
         const int rc = align_hip(ba.data(), p->n[i], bb.data(), p->m[i], fallback, !cost_only_astar, false, &c, &text, &fst);
-        if (rc != 0) return fail_out(i, rc);
+        if (rc != 0) return fail_all(rc);
         if (p->astar) {
             p->pair_stats[i] = fst;
             if (results[i].status != apa2::kOk) costs[i] = c;  // the forward pass itself handed the pair back
@@ -2361,17 +2556,18 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
         }
         if (c != costs[i]) {
             set_error("traceback fallback disagrees with the batched cost (pair %zu: %d vs %d)", i, c, costs[i]);
-            return fail_out(i, PA_E_INTERNAL);
+            return fail_all(PA_E_INTERNAL);
         }
         if (!cigar_out) continue;
+        std::free(cigar_out[i]);
         cigar_out[i] = (char*)std::malloc(text.size() + 1);
         if (!cigar_out[i]) {
             set_error("out of memory");
-            return fail_out(i, PA_E_NOMEM);
+            return fail_all(PA_E_NOMEM);
         }
         std::memcpy(cigar_out[i], text.c_str(), text.size() + 1);
     }
-    mark("strings to the caller");
+    mark("pairs handed back");
     return 0;
 }
 

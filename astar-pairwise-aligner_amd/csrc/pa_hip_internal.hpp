@@ -20,6 +20,8 @@ bool hip_ok(hipError_t e, const char* what);
 bool ensure_device();
 
 void release_alloc_cache();  // the cached device blocks back to the driver (pa_release_pools)
+void release_scope_begin();  // one device wait now; DeviceBuf::release calls of this thread skip theirs until release_scope_end()
+void release_scope_end();
 
 struct DeviceBuf {
     void* ptr = nullptr;

@@ -112,9 +112,12 @@ constexpr int32_t kDtInf = 0x7FFFFFFF;
 template <bool DT, bool BANDED>
 // (wavefronts per SIMD asked of the register allocator, measured on C4: the DT variant 13.1 ms without the bound, 9.1 / 9.9 / 13.8 ms
 //  at 5 / 6 / 7; the re-fill variant 12.6 / 12.1 / 13.1 ms at 5 / 6 / 7)
-__global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kernel(const TraceJob* __restrict__ jobs, int npairs, uint32_t* err) {
-    const int pair = (int)rfl((uint32_t)(blockIdx.x * kStripBlockWaves + (threadIdx.x >> 6)));
-    if (pair >= npairs) return;
+__global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kernel(const TraceJob* __restrict__ jobs, const int32_t* __restrict__ list, int npairs, uint32_t* err) {
+    // `list`: the pairs of this launch (a chunk of the batch: pa_batch_align runs the chunks on streams of their own, so that the
+    // traceback of one overlaps the forward pass of the next and the copy-out of the one before)
+    const int slot_ = (int)rfl((uint32_t)(blockIdx.x * kStripBlockWaves + (threadIdx.x >> 6)));
+    if (slot_ >= npairs) return;
+    const int pair = (int)rfl((uint32_t)list[slot_]);
     const int lane = (int)(threadIdx.x & 63);
     const TraceJob tj = jobs[pair];
     extern __shared__ unsigned char pa_trace_lds[];

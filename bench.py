@@ -134,49 +134,68 @@ def main():
 
         divs = (0.01, 0.05, 0.10, 0.15)
         c4s = [generate_pair(10_000, divs[i % 4], seed=1_000_000 + i) for i in range(args.c4_pairs)]
-        sharded_align(c4s[: 64 * world])  # warm-up (buffers, pinned staging)
+        from astar_pairwise_aligner_amd.sharding import default_align
+
+        busy = [0.0]
+
+        def timed_align(sub):  # (how long this rank's GPU was given work: the queue's balance, next to the wall time)
+            tb = time.perf_counter()
+            r = default_align(sub)
+            busy[0] += time.perf_counter() - tb
+            return r
+
+        sharded_align(c4s[: 64 * world], all_ranks=False)  # warm-up (buffers, pinned staging)
         barrier()
         t0s = time.perf_counter()
-        res = sharded_align(c4s)
+        res = sharded_align(c4s, compute=timed_align, all_ranks=False)  # gathered to rank 0 only: the other ranks return None
         barrier()
         dts = time.perf_counter() - t0s
+        busy_all = [busy[0]]
         if dist is not None:
             tt = torch.tensor([dts], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dts = float(tt.item())
-        c4_sharded = {
-            "workload": f"C4 strong scaling: {args.c4_pairs} x 10 kbp pairs (1/5/10/15 %), global alignment with traceback, over {world} GPU(s), "
-                        "chunks pulled from a queue (one counter in the process group's store), every rank ends with all (cost, CIGAR) results",
-            "pairs_per_sec": round(args.c4_pairs / dts, 1),
-            "ms": round(dts * 1e3, 2),
-            "n_gpus": world,
-            "scaling": "strong",
-            "cost_checksum": int(sum(c for c, _ in res)),
-            "cigar_bytes": int(sum(len(g) for _, g in res)),
-        }
+            bt_ = torch.zeros(world, dtype=torch.float64, device="cuda")
+            bt_[rank] = busy[0]
+            dist.all_reduce(bt_, op=dist.ReduceOp.SUM)
+            busy_all = [float(x) for x in bt_.tolist()]
+        if rank == 0:
+            c4_sharded = {
+                "workload": f"C4 strong scaling: {args.c4_pairs} x 10 kbp pairs (1/5/10/15 %), global alignment with traceback, over {world} GPU(s), "
+                            "chunks pulled from a queue (one counter in the process group's store), (cost, CIGAR) of every pair gathered to rank 0",
+                "pairs_per_sec": round(args.c4_pairs / dts, 1),
+                "ms": round(dts * 1e3, 2),
+                "n_gpus": world,
+                "scaling": "strong",
+                "rank_busy_s": [round(x, 4) for x in busy_all],
+                "cost_checksum": int(sum(c for c, _ in res)),
+                "cigar_bytes": int(sum(len(g) for _, g in res)),
+            }
         # the same queue with band-limited work per pair (batched A*PA2 `simple`): what the work of a pair is depends on its divergence
         try:
             from astar_pairwise_aligner_amd.sharding import astarpa2_align
 
             run_a = astarpa2_align(pa.AstarPa2Params.simple())
-            sharded_align(c4s[: 64 * world], compute=run_a)
+            sharded_align(c4s[: 64 * world], compute=run_a, all_ranks=False)
             barrier()
             t0a = time.perf_counter()
-            res_a = sharded_align(c4s, compute=run_a)
+            res_a = sharded_align(c4s, compute=run_a, all_ranks=False)
             barrier()
             dta = time.perf_counter() - t0a
             if dist is not None:
                 tt = torch.tensor([dta], dtype=torch.float64, device="cuda")
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 dta = float(tt.item())
-            assert [c for c, _ in res_a] == [c for c, _ in res], "sharded A*PA2 costs differ from the sharded full DP"
-            c4_sharded["astarpa2_simple"] = {"pairs_per_sec": round(args.c4_pairs / dta, 1), "ms": round(dta * 1e3, 2),
-                                             "cigar_bytes": int(sum(len(g) for _, g in res_a))}
+            if rank == 0:
+                assert [c for c, _ in res_a] == [c for c, _ in res], "sharded A*PA2 costs differ from the sharded full DP"
+                c4_sharded["astarpa2_simple"] = {"pairs_per_sec": round(args.c4_pairs / dta, 1), "ms": round(dta * 1e3, 2),
+                                                 "cigar_bytes": int(sum(len(g) for _, g in res_a))}
             del res_a
         except AssertionError:
             raise
         except Exception as e:  # (reporting only)
-            c4_sharded["astarpa2_simple"] = {"error": str(e)}
+            if rank == 0:
+                c4_sharded["astarpa2_simple"] = {"error": str(e)}
         del res, c4s
 
     if rank != 0:
@@ -578,13 +597,23 @@ def main():
                 tcount *= 2
             best_t = min(probe, key=probe.get)
             eff = probe[1] / probe[best_t]
+            # a CPU quota lets short bursts run on more cores than it sustains: the longer samples below are sized by the quota
+            quota = None
+            try:
+                q, per = (cgroup or "").split()[:2]
+                quota = float(q) / float(per) if q != "max" else None
+            except (ValueError, IndexError):
+                pass
+            if quota is not None and quota < eff:
+                eff = quota
+                best_t = max(1, min(best_t, int(quota + 0.999)))
             nb = {"os_cpu_count": os.cpu_count(), "sched_affinity": affinity, "cgroup_cpu_max": cgroup, "cpu": cpu_model, "kind": "port",
-                  "threads_used": best_t, "effective_cores": round(eff, 1),
+                  "threads_used": best_t, "effective_cores": round(eff, 1), "cgroup_quota_cores": quota,
                   "scaling_probe_pairs_per_sec": {str(k): round(len(probe_jobs) / v, 1) for k, v in probe.items()},
-                  "note": "effective_cores = speed-up of threads_used threads over one thread on 384 C4 pairs through the CPU-kernel A*PA2 engine; "
-                          "the all-core figures below are what THIS process gets from the host it runs on, not a full socket"}
+                  "note": "effective_cores = min(best speed-up of the scaling probe over one thread, CPU quota of the cgroup); "
+                          "the figures below are what THIS process gets from the host it runs on, not a full socket"}
             # (a) full DP, cost only (the headline workload): whole 100 kbp pairs, about 5 s
-            njobs = max(best_t, int(5.0 * eff * out["cpu_baseline"]["value"] * 1e9 / (args.n * args.n)))
+            njobs = max(best_t, int(4.0 * eff * out["cpu_baseline"]["value"] * 1e9 / (args.n * args.n)))
             jobs = [pairs[i % len(pairs)] for i in range(njobs)]
             t = time.perf_counter()
             got_cpu = oracle.cpu_many(jobs, None, best_t)

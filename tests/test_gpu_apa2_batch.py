@@ -149,7 +149,7 @@ def test_cost_only_run(pa, oracle):
 def test_unsupported_parameters_are_refused(pa, oracle):
     from tests.test_gpu_engine import gpu_params
 
-    for oc in (oracle.params_full(), oracle.params_nw()):
+    for oc in (oracle.params_nw(), oracle.make_params(domain="gap_gap", heuristic="none", start="gap")):
         with pytest.raises(pa.PaError):
             pa.Batch([gen_pair(500, 0.1, 1)], params=gpu_params(pa, oc))
 

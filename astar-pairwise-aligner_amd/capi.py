@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "pa_align", "pa_batch_align_multi", "pa_batch_create_trace_params",
     "pa_bp_ctx_create", "pa_bp_ctx_compute", "pa_bp_ctx_fill", "pa_bp_ctx_destroy",
     "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools", "pa_align_file_params", "pa_batch_params_supported", "pa_alloc_cache_stats", "pa_free_cigars",
-    "pa_batch_full_info", "pa_debug_gcsh_probe",
+    "pa_batch_full_info", "pa_debug_gcsh_probe", "pa_debug_gcsh_matches",
 ]
 
 _lib = None
@@ -189,6 +189,19 @@ def gcsh_probe(a: bytes, b: bytes, k: int, p: int, queries) -> tuple[list[int], 
     if rc != 0:
         raise PaError(f"pa_debug_gcsh_probe rc={rc}: {last_error()}")
     return out[:-1].tolist(), int(out[-1])
+
+
+def gcsh_matches(a: bytes, b: bytes, k: int, p: int) -> list[tuple[int, int]]:
+    """pa_debug_gcsh_matches (diagnostics): the matches GCSH keeps for this pair as the GPU finds them (csrc/gcsh_build_kernel.hpp), by start."""
+    L = load()
+    L.pa_debug_gcsh_matches.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]
+    L.pa_debug_gcsh_matches.restype = C.c_long
+    cap = len(a) // max(1, k) * 2 + 4096
+    out = np.zeros((cap, 2), np.int32)
+    n = L.pa_debug_gcsh_matches(_buf(a), len(a), _buf(b), len(b), k, p, _p(out), cap)
+    if n < 0:
+        raise PaError(f"pa_debug_gcsh_matches rc={n}: {last_error()}")
+    return [tuple(x) for x in out[:n].tolist()]
 
 
 def release_pools() -> None:

@@ -550,11 +550,11 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_full_kernel(con
         be.timing = probe_stats != nullptr;
         const uint64_t t_begin = be.tick();
         FullResult fr{};
-        if (job.n > 0 && job.m > 0) {
+        if (job.n > 0 && job.m > 0 && !(job.heur == kFullHeurGcsh && job.g.nmatch < 0)) {  // (nmatch < 0: the matches could not be built on the device)
             if (job.heur == kFullHeurGcsh) be.build_contours();
             PairProgFull<FullDevBackend> prog(be, sp, job.n, job.m);
             prog.run(&fr);
-        } else {  // an empty sequence: left to the host engine
+        } else {  // an empty sequence (or no matches): left to the host engine
             fr.status = kFullErrOrder;
         }
         if (rfl(*(const PA_GLOBAL uint32_t*)err) != PA_ERR_NONE && fr.status == kFullOk) fr.status = kFullErrOrder;

@@ -5,6 +5,7 @@
 #include "trace_kernel.hpp"
 #include "apa2_kernel.hpp"
 #include "apa2_full_kernel.hpp"
+#include "gcsh_build_kernel.hpp"
 
 #include <sched.h>
 
@@ -1203,7 +1204,11 @@ struct pa_batch {
     apa2::FullParams fsp{};
     DeviceBuf d_fjobs, d_jh, d_hrow, d_mi, d_mj, d_active, d_win, d_win0, d_lrec, d_cell, d_probe;
     size_t full_matches = 0, full_seeds = 0;
-    double full_build_ms = 0;  // host time spent on the matches of the heuristic (reporting)
+    double full_build_ms = 0;  // host time spent on the matches of the heuristic (reporting; 0 when the GPU finds them)
+    // the matches found on the GPU (gcsh_build_kernel.hpp), inside every pa_batch_align / pa_batch_run
+    bool device_build = false;
+    DeviceBuf d_bjobs, d_bscratch, d_bstatus, d_bticket;
+    hipEvent_t evB0 = nullptr, evB1 = nullptr;
     std::vector<pa_astarpa2_stats> pair_stats;  // of the last pa_batch_align
     double apa2_strip_instr = 0;  // modelled VALU instructions of the DP strips of the last pa_batch_align (reporting)
     double cells = 0, word_updates = 0, algo_bytes = 0;
@@ -1217,6 +1222,8 @@ struct pa_batch {
         if (h_text) (void)hipHostFree(h_text);
         if (h_meta) (void)hipHostFree(h_meta);
         if (ev_pre) (void)hipEventDestroy(ev_pre);
+        if (evB0) (void)hipEventDestroy(evB0);
+        if (evB1) (void)hipEventDestroy(evB1);
         for (int c = 0; c < kMaxChunks; ++c) {
             if (evF0[c]) (void)hipEventDestroy(evF0[c]);
             if (evF1[c]) (void)hipEventDestroy(evF1[c]);
@@ -1558,13 +1565,17 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
         seed_off[i] = tseeds;
         if (gcsh) tseeds += p->n[i] >= (size_t)hk ? (p->n[i] - hk) / hk + 1 : 0;
     }
-    // ---- host threads: the matches (GCSH) / the per-column table (SH) of every pair ----
+    // The matches of GCSH are found on the GPU, inside every alignment call (gcsh_build_kernel.hpp), when the look-ahead of local
+    // pruning fits its LDS arrays; PA_GCSH_HOST_BUILD=1 finds them on host threads at creation instead (tests compare the two).
+    static const bool host_build_env = getenv("PA_GCSH_HOST_BUILD") != nullptr && getenv("PA_GCSH_HOST_BUILD")[0] != '0';
+    p->device_build = gcsh && !host_build_env && ap.heuristic_p >= 0 && ap.heuristic_p <= apa2::kBuildMaxP && hk <= 31;
+    // ---- host threads: the matches (GCSH, unless the GPU finds them) / the per-column table (SH) of every pair ----
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::vector<int32_t>> pmi(gcsh ? P : 0), pmj(gcsh ? P : 0);
-    std::vector<apa2::GcshSeedWindow> win(tseeds);
+    std::vector<apa2::GcshSeedWindow> win(p->device_build ? 0 : tseeds);
     std::vector<int32_t> shv(tsh);
     std::atomic<bool> bad_base{false};
-    if (gcsh || sh)
+    if ((gcsh && !p->device_build) || sh)
         parallel_pairs(P, [&](size_t i) {
             const engine::I n = (engine::I)p->n[i], m = (engine::I)p->m[i];
             if (n == 0 || m == 0) return;
@@ -1584,14 +1595,27 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
                 win[seed_off[i] + s] = apa2::GcshSeedWindow{(int32_t)gh.active_range[s].b0, (int32_t)gh.active_range[s].b1, -1, 0};
         });
     size_t tm = 0;
+    std::vector<size_t> cap(P, 0), tsz(P, 0);
+    size_t ttab = 0;
     for (size_t i = 0; i < P; ++i) {
         match_off[i] = tm;
-        if (gcsh) tm += pmi[i].size();
+        if (gcsh && !p->device_build) tm += pmi[i].size();
+        if (p->device_build) {
+            // room for the candidates of a pair: every seed once and half of them again, plus 2048 (a pair that needs more -- a
+            // repeat-rich sequence -- is flagged by the kernel and goes to the host engine)
+            const size_t ns = p->n[i] >= (size_t)hk ? (p->n[i] - hk) / hk + 1 : 0;
+            cap[i] = ns + ns / 2 + 2048;
+            size_t t2 = 64;
+            while (t2 < 2 * ns + 1) t2 *= 2;
+            tsz[i] = t2;
+            ttab += t2;
+            tm += cap[i];
+        }
     }
     match_off[P] = tm;
     p->full_matches = tm;
     p->full_seeds = tseeds;
-    p->full_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    p->full_build_ms = p->device_build ? 0.0 : std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (!p->d_rec.alloc(std::max<size_t>(tr, 1) * sizeof(sweep::BlockRec)) || !p->d_jh.alloc(std::max<size_t>(tr, 1) * 4) ||
         !p->d_results.alloc(std::max<size_t>(P, 1) * sizeof(apa2::PairResult)) || !p->d_fjobs.alloc(std::max<size_t>(P, 1) * sizeof(apa2::FullJob)) ||
         !p->d_order.alloc(std::max<size_t>(P, 1) * 4) || !p->d_tstats.alloc(std::max<size_t>(P, 1) * 32) || !p->d_sh.alloc(std::max<size_t>(tsh, 1) * 4) ||
@@ -1612,7 +1636,62 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
             !hip_ok(hipMemcpy(p->d_mj.ptr, mj.data(), tm * 4, hipMemcpyHostToDevice), "H2D matches"))
             return false;
     }
-    if (tseeds && !hip_ok(hipMemcpy(p->d_win0.ptr, win.data(), tseeds * sizeof(apa2::GcshSeedWindow), hipMemcpyHostToDevice), "H2D seed windows")) return false;
+    if (tseeds && !p->device_build && !hip_ok(hipMemcpy(p->d_win0.ptr, win.data(), tseeds * sizeof(apa2::GcshSeedWindow), hipMemcpyHostToDevice), "H2D seed windows")) return false;
+    std::vector<apa2::GcshBuildJob> bj(p->device_build ? P : 0);
+    if (p->device_build) {
+        // scratch of the build kernel, one slice per pair: u32 keys / next_same / cnt / fill per seed, the table, five ints and two bytes
+        // per candidate slot
+        const size_t words = 4 * tseeds + P + ttab + 4 * tm, bytes = words * 4 + 2 * tm + 64;
+        if (!p->d_bscratch.alloc(bytes) || !p->d_bjobs.alloc(std::max<size_t>(P, 1) * sizeof(apa2::GcshBuildJob)) || !p->d_bstatus.alloc(std::max<size_t>(P, 1) * 4) ||
+            !p->d_bticket.alloc(64) || !hip_ok(hipEventCreate(&p->evB0), "event") || !hip_ok(hipEventCreate(&p->evB1), "event"))
+            return false;
+        int32_t* w32 = p->d_bscratch.as<int32_t>();
+        uint8_t* w8 = (uint8_t*)(w32 + words);
+        size_t o32 = 0, o8 = 0;
+        for (size_t i = 0; i < P; ++i) {
+            const size_t ns = p->n[i] >= (size_t)hk ? (p->n[i] - hk) / hk + 1 : 0;
+            apa2::GcshBuildJob& x = bj[i];
+            std::memset(&x, 0, sizeof x);
+            x.a = p->d_a.as<uint8_t>() + p->a_off[i];
+            x.b = p->d_b.as<uint8_t>() + p->b_off[i];
+            x.keys = (uint32_t*)(w32 + o32);
+            o32 += ns;
+            x.next_same = w32 + o32;
+            o32 += ns;
+            x.cnt = w32 + o32;
+            o32 += ns + 1;
+            x.fill = w32 + o32;
+            o32 += ns;
+            x.slot = w32 + o32;
+            o32 += tsz[i];
+            x.tmp_s = w32 + o32;
+            o32 += cap[i];
+            x.tmp_j = w32 + o32;
+            o32 += cap[i];
+            x.gpos = w32 + o32;
+            o32 += cap[i];
+            x.cj = w32 + o32;
+            o32 += cap[i];
+            x.flag = w8 + o8;
+            o8 += cap[i];
+            x.keptg = w8 + o8;
+            o8 += cap[i];
+            x.mi = p->d_mi.as<int32_t>() + match_off[i];
+            x.mj = p->d_mj.as<int32_t>() + match_off[i];
+            x.win0 = p->d_win0.as<apa2::GcshSeedWindow>() + seed_off[i];
+            x.nmatch_out = &p->d_fjobs.as<apa2::FullJob>()[i].g.nmatch;
+            x.status = p->d_bstatus.as<uint32_t>() + i;
+            x.n = (int32_t)p->n[i];
+            x.m = (int32_t)p->m[i];
+            x.k = hk;
+            x.p = (int32_t)ap.heuristic_p;
+            x.nseeds = (int32_t)ns;
+            x.tsize = (int32_t)tsz[i];
+            x.cap = (int32_t)cap[i];
+        }
+        if (P && !hip_ok(hipMemcpy(p->d_bjobs.ptr, bj.data(), P * sizeof(apa2::GcshBuildJob), hipMemcpyHostToDevice), "H2D build jobs")) return false;
+    }
+    const bool launch_build = p->device_build && P;
     std::vector<apa2::FullJob> fj(P);
     std::vector<int32_t> order(P);
     for (size_t i = 0; i < P; ++i) {
@@ -1661,6 +1740,15 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
     if (P && (!hip_ok(hipMemcpy(p->d_fjobs.ptr, fj.data(), P * sizeof(apa2::FullJob), hipMemcpyHostToDevice), "H2D pair jobs") ||
               !hip_ok(hipMemcpy(p->d_order.ptr, order.data(), P * 4, hipMemcpyHostToDevice), "H2D order")))
         return false;
+    if (launch_build) {
+        // The matches of GCSH are part of the batch like the sequences they are derived from: found here, once, by the GPU (one wavefront
+        // per pair, 16 KB of LDS each: eight to a CU), on the batch's stream -- the first alignment call queues behind it.
+        const int cus = g_device_props_cus > 0 ? g_device_props_cus : 256;
+        const int grid = (int)std::min<size_t>(P, (size_t)cus * 8);
+        if (!hip_ok(hipMemsetAsync(p->d_bticket.ptr, 0, 64, p->stream), "memset") || !hip_ok(hipEventRecord(p->evB0, p->stream), "event")) return false;
+        hipLaunchKernelGGL(apa2::gcsh_build_kernel, dim3(grid), dim3(64), 0, p->stream, p->d_bjobs.as<apa2::GcshBuildJob>(), (int)P, p->d_bticket.as<uint32_t>());
+        if (!hip_ok(hipGetLastError(), "gcsh_build_kernel launch") || !hip_ok(hipEventRecord(p->evB1, p->stream), "event")) return false;
+    }
     return true;
 }
 
@@ -2571,6 +2659,81 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
     return 0;
 }
 
+// Diagnostics / tests: the matches of GCSH (seed length k, local pruning p_local) of one pair AS THE GPU FINDS THEM (gcsh_build_kernel.hpp),
+// by start: out_ij[2 t], out_ij[2 t + 1] for t < min(count, cap_out).  Returns the count, or -(100 + status) when the kernel gave up.
+extern "C" long pa_debug_gcsh_matches(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, int32_t k, int32_t p_local, int32_t* out_ij, size_t cap_out) {
+    if (!ensure_device()) return PA_E_HIP;
+    if (!a || !b || a_len == 0 || b_len == 0 || k < 1 || k > 31 || p_local < 0 || p_local > apa2::kBuildMaxP) return PA_E_ARG;
+    const size_t ns = a_len >= (size_t)k ? (a_len - k) / k + 1 : 0, cap = ns + ns / 2 + 2048;
+    size_t tsz = 64;
+    while (tsz < 2 * ns + 1) tsz *= 2;
+    DeviceBuf d_a, d_b, d_w, d_mi, d_mj, d_win, d_job, d_out;
+    const size_t words = 4 * ns + 1 + tsz + 4 * cap;
+    if (!d_a.alloc(a_len + 64) || !d_b.alloc(b_len + 64) || !d_w.alloc(words * 4 + 2 * cap + 64) || !d_mi.alloc(cap * 4) || !d_mj.alloc(cap * 4) ||
+        !d_win.alloc(std::max<size_t>(ns, 1) * sizeof(apa2::GcshSeedWindow)) || !d_job.alloc(sizeof(apa2::GcshBuildJob)) || !d_out.alloc(64))
+        return PA_E_NOMEM;
+    apa2::GcshBuildJob x;
+    std::memset(&x, 0, sizeof x);
+    int32_t* w32 = d_w.as<int32_t>();
+    size_t o = 0;
+    x.a = d_a.as<uint8_t>();
+    x.b = d_b.as<uint8_t>();
+    x.keys = (uint32_t*)(w32 + o), o += ns;
+    x.next_same = w32 + o, o += ns;
+    x.cnt = w32 + o, o += ns + 1;
+    x.fill = w32 + o, o += ns;
+    x.slot = w32 + o, o += tsz;
+    x.tmp_s = w32 + o, o += cap;
+    x.tmp_j = w32 + o, o += cap;
+    x.gpos = w32 + o, o += cap;
+    x.cj = w32 + o, o += cap;
+    x.flag = (uint8_t*)(w32 + words);
+    x.keptg = x.flag + cap;
+    x.mi = d_mi.as<int32_t>();
+    x.mj = d_mj.as<int32_t>();
+    x.win0 = d_win.as<apa2::GcshSeedWindow>();
+    x.nmatch_out = d_out.as<int32_t>();
+    x.status = d_out.as<uint32_t>() + 1;
+    x.n = (int32_t)a_len;
+    x.m = (int32_t)b_len;
+    x.k = k;
+    x.p = p_local;
+    x.nseeds = (int32_t)ns;
+    x.tsize = (int32_t)tsz;
+    x.cap = (int32_t)cap;
+    DeviceBuf d_clk;
+    static const bool clocks = getenv("PA_BUILD_CLOCKS") != nullptr;
+    if (clocks) {
+        if (!d_clk.alloc(128) || !hip_ok(hipMemset(d_clk.ptr, 0, 128), "memset")) return PA_E_HIP;
+        x.clocks = d_clk.as<unsigned long long>();
+    }
+    int32_t res[4] = {0, 0, 0, 0};
+    if (!hip_ok(hipMemcpy(d_a.ptr, a, a_len, hipMemcpyHostToDevice), "H2D") || !hip_ok(hipMemcpy(d_b.ptr, b, b_len, hipMemcpyHostToDevice), "H2D") ||
+        !hip_ok(hipMemset(d_out.ptr, 0, 64), "memset") || !hip_ok(hipMemcpy(d_job.ptr, &x, sizeof x, hipMemcpyHostToDevice), "H2D"))
+        return PA_E_HIP;
+    hipLaunchKernelGGL(apa2::gcsh_build_kernel, dim3(1), dim3(64), 0, 0, d_job.as<apa2::GcshBuildJob>(), 1, d_out.as<uint32_t>() + 8);
+    if (!hip_ok(hipGetLastError(), "gcsh_build_kernel") || !hip_ok(hipDeviceSynchronize(), "sync") || !hip_ok(hipMemcpy(res, d_out.ptr, 16, hipMemcpyDeviceToHost), "D2H"))
+        return PA_E_HIP;
+    if (clocks) {
+        unsigned long long c[16] = {0};
+        (void)hipMemcpy(c, d_clk.ptr, 128, hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "[gcsh build] n %zu m %zu k %d p %d: A %.3f  B %.3f  C %.3f  D %.3f  E %.3f  F %.3f ms; %llu candidates, %llu kept alone, %llu searches in E; status %d\n", a_len, b_len,
+                     k, p_local, c[0] * 1e-5, c[1] * 1e-5, c[2] * 1e-5, c[3] * 1e-5, c[4] * 1e-5, c[5] * 1e-5, c[6], c[7], c[8], res[1]);
+    }
+    if (res[1] != 0) return -(100 + (long)res[1]);
+    const size_t cnt = (size_t)std::max(res[0], 0), take = std::min(cnt, cap_out);
+    if (take && out_ij) {
+        std::vector<int32_t> mi(take), mj(take);
+        if (!hip_ok(hipMemcpy(mi.data(), d_mi.ptr, take * 4, hipMemcpyDeviceToHost), "D2H") || !hip_ok(hipMemcpy(mj.data(), d_mj.ptr, take * 4, hipMemcpyDeviceToHost), "D2H"))
+            return PA_E_HIP;
+        for (size_t t = 0; t < take; ++t) {
+            out_ij[2 * t] = mi[t];
+            out_ij[2 * t + 1] = mj[t];
+        }
+    }
+    return (long)cnt;
+}
+
 // Diagnostics / tests: the DEVICE form of GCSH alone.  The matches are found on the host (csrc/gcsh.hpp), one wavefront derives the contours
 // and evaluates h at nq positions (queries[2 t], queries[2 t + 1]); out[t] = h, out[nq] = number of contour layers (incl. layer 0).
 extern "C" int pa_debug_gcsh_probe(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, int32_t k, int32_t p_local, const int32_t* queries,
@@ -2625,6 +2788,16 @@ extern "C" int pa_debug_gcsh_probe(const uint8_t* a, size_t a_len, const uint8_t
 extern "C" void pa_batch_full_info(const pa_batch* p, double* build_ms, double* matches, double* probes, double* rounds, double* phase_wave_ms) {
     if (build_ms) *build_ms = p ? p->full_build_ms : 0;
     if (matches) *matches = p ? (double)p->full_matches : 0;
+    if (p && p->device_build && p->pairs) {  // the GPU found them: the build kernel's time in the last call (negative = on the device), their number
+        float ms = 0.f;
+        if (build_ms && p->evB0 && hipEventElapsedTime(&ms, p->evB0, p->evB1) == hipSuccess) *build_ms = -(double)ms;
+        std::vector<apa2::FullJob> fj(p->pairs);
+        if (matches && hipMemcpy(fj.data(), p->d_fjobs.ptr, p->pairs * sizeof(apa2::FullJob), hipMemcpyDeviceToHost) == hipSuccess) {
+            double tot = 0;
+            for (const auto& j : fj) tot += j.g.nmatch > 0 ? j.g.nmatch : 0;
+            *matches = tot;
+        }
+    }
     unsigned long long pr[16] = {0};
     if (p && p->astar_full && p->d_probe.ptr) (void)hipMemcpy(pr, p->d_probe.ptr, 128, hipMemcpyDeviceToHost);
     if (probes) *probes = (double)pr[0];

@@ -78,6 +78,48 @@ def test_device_heuristic_equals_host(pa, oracle):
         assert not bad, (n, e, k, p, len(bad), bad[:5], layers)
 
 
+def test_device_built_matches_equal_host(pa, oracle):
+    """The matches GCSH keeps -- seeds, exact k-mer matches in the reference's push order, the transform filter, local pruning with its
+    `next_match_per_diag` -- as csrc/gcsh_build_kernel.hpp finds them on the GPU against csrc/gcsh.hpp on the host, match for match:
+    random pairs at every divergence, low-complexity and repetitive sequences (chains of seeds with the same k-mer, many candidates per
+    row, matches that survive local pruning only through a match kept before them), k from 4 to 20, p from 0 to 14."""
+    from astar_pairwise_aligner_amd import capi
+
+    rng = random.Random(77)
+    cases = []
+    for n, e, k, p, seed in [(3000, 0.05, 12, 14, 1), (20000, 0.08, 12, 14, 2), (100_000, 0.05, 12, 14, 3), (8000, 0.15, 6, 3, 4), (5000, 0.02, 8, 0, 5),
+                             (2000, 0.6, 5, 2, 6), (40, 0.1, 12, 14, 7), (10_000, 0.15, 12, 14, 8), (10_000, 0.25, 12, 14, 9), (30_000, 0.12, 10, 7, 10),
+                             (6000, 0.1, 6, 14, 11), (9000, 0.1, 20, 5, 12), (12, 0.0, 12, 14, 13), (11, 0.0, 12, 14, 14), (25, 0.0, 12, 1, 15)]:
+        cases.append((gen_pair(n, e, seed), k, p))
+    must = len(cases)
+    for it in range(60):  # repeats: tandem copies of a unit with a few edits -- chains of seeds with one k-mer, several candidates per row
+        short = it < 30  # short enough for the kernel's candidate buffers (the others may be refused: such a pair goes to the host engine)
+        unit = rand_seq(rng.randint(20, 120) if short else rng.randint(3, 40), it + 100)
+        a = (unit * 400)[: rng.randint(100, 900) if short else rng.randint(1000, 4000)]
+        b = bytearray(a)
+        for _ in range(rng.randint(0, len(b) // 20)):
+            q = rng.randrange(len(b))
+            b[q] = rng.choice(b"ACGT")
+        cut = rng.randint(0, len(b) // 2)
+        cases.append(((a, bytes(b[:cut] + b[cut + rng.randint(0, 30):]) or b"A"), rng.choice([4, 5, 8, 12]), rng.choice([0, 1, 3, 14])))
+        must += 1 if short else 0
+    refused, multi, gentle_done = 0, 0, 0
+    for t, ((a, b), k, p) in enumerate(cases):
+        want = sorted(oracle.gcsh_probe(a, b, k, p, [(0, 0)])[1])
+        try:
+            got = capi.gcsh_matches(a, b, k, p)
+        except capi.PaError as e:
+            # only repeats may be refused: candidate buffers outgrown (rc -101) or more than 64 kept matches within reach of one search
+            # (rc -102); such a pair goes to the host engine
+            assert t >= 15 and ("rc=-101" in str(e) or "rc=-102" in str(e)), (t, len(a), len(b), k, p, str(e))
+            refused += 1
+            continue
+        assert got == want, (len(a), len(b), k, p, len(got), len(want), [x for x in got if x not in set(want)][:5], [x for x in want if x not in set(got)][:5])
+        multi += len(want) > len(a) // k  # more matches than seeds: rows with several candidates
+        gentle_done += 15 <= t < must
+    assert multi >= 3 and gentle_done >= 12 and refused <= 45, (multi, gentle_done, refused)
+
+
 def test_block_boundary_sizes_full(pa, oracle):
     pairs = []
     for n in (1, 2, 11, 12, 13, 31, 64, 65, 255, 256, 257, 511, 512, 513, 1025, 2047, 2049, 4097):

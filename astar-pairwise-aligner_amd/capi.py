@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "pa_align", "pa_batch_align_multi", "pa_batch_create_trace_params",
     "pa_bp_ctx_create", "pa_bp_ctx_compute", "pa_bp_ctx_fill", "pa_bp_ctx_destroy",
     "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools", "pa_align_file_params", "pa_batch_params_supported", "pa_alloc_cache_stats", "pa_free_cigars",
-    "pa_batch_full_info", "pa_debug_gcsh_probe", "pa_debug_gcsh_matches",
+    "pa_batch_full_info", "pa_debug_gcsh_probe", "pa_debug_gcsh_matches", "pa_batch_window_retries",
 ]
 
 _lib = None
@@ -106,6 +106,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_batch_align.restype = C.c_int
     L.pa_batch_trace_fallbacks.argtypes = [vp]
     L.pa_batch_trace_fallbacks.restype = C.c_size_t
+    L.pa_batch_window_retries.argtypes = [vp]
+    L.pa_batch_window_retries.restype = C.c_size_t
     L.pa_pairs_read.argtypes = [C.c_char_p]
     L.pa_pairs_read.restype = vp
     L.pa_pairs_count.argtypes = [vp]
@@ -481,6 +483,10 @@ class Batch:
 
     def trace_fallbacks(self) -> int:
         return int(load().pa_batch_trace_fallbacks(self._h))
+
+    def window_retries(self) -> int:
+        """Pairs whose band left their window of the block-column store and were aligned again with full-height columns."""
+        return int(load().pa_batch_window_retries(self._h))
 
     def stats(self) -> dict:
         vals = [C.c_double(0) for _ in range(4)]

@@ -40,14 +40,15 @@ struct FullJob {
     BlockRec* rec;            // [nblk + 2] persistent block records (the traceback reads them: trace_kernel.hpp)
     int32_t* jh;              // [nblk + 2] row of the stored horizontal differences per block (Block::j_h), kNone: none
     uint32_t* col;            // column store: slot k = col + k * col_stride * 4, indexed by absolute word
-    int64_t col_stride;
+    int64_t col_stride;       // words per slot: the pair's window (sweep_logic.hpp SlotGeom)
     uint8_t* hrow;            // [n] the stored row: one byte per column, bit0 = +1, bit1 = -1 (blocks.rs:103-105)
     const int32_t* sh_h;      // SH: h(i) for i = 0..n
     uint64_t* gran;           // 2 rows x 8 granules, zero between uses
     int32_t* sum;             // scratch: bottom-row sum of the last strip
     PairResult* result;
     GcshDev g;                // GCSH
-    int32_t n, m, heur, pad;
+    int32_t n, m, heur;
+    uint32_t slot_ratio;      // SlotGeom::ratio
 };
 
 typedef int32_t pa_i32x4 __attribute__((ext_vector_type(4)));
@@ -82,7 +83,7 @@ struct FullDevBackend {
         job.n = own_sgpr(j.n);
         job.m = own_sgpr(j.m);
         job.heur = own_sgpr(j.heur);
-        job.pad = 0;
+        job.slot_ratio = own_sgpr(j.slot_ratio);
         g.mi = own_sgpr(j.g.mi);
         g.mj = own_sgpr(j.g.mj);
         g.active = own_sgpr(j.g.active);
@@ -101,8 +102,25 @@ struct FullDevBackend {
     }
     __device__ __forceinline__ uint64_t strip_instructions() const { return (uint64_t)strip_units << 5; }
     __device__ __forceinline__ int32_t uniform(int32_t x) const { return (int32_t)rfl((uint32_t)x); }
-    __device__ __forceinline__ bool failed() const { return rfl(__hip_atomic_load((const PA_GLOBAL uint32_t*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != PA_ERR_NONE; }
-    __device__ __forceinline__ gu32 slot(int32_t k) const { return (gu32)job.col + (size_t)k * (size_t)job.col_stride * 4; }
+    mutable bool win_fail = false;  // a block left the window of the column store: the pair runs again with full-height slots
+    __device__ __forceinline__ bool failed() const {
+        return win_fail || rfl(__hip_atomic_load((const PA_GLOBAL uint32_t*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != PA_ERR_NONE;
+    }
+    __device__ __forceinline__ sweep::SlotGeom geom() const { return sweep::SlotGeom{job.n, job.m, (int32_t)job.col_stride, job.slot_ratio}; }
+    // slot k, addressed by ABSOLUTE word (the pointer is moved back by the window's first word)
+    // (a block's logic asks for slots k and k - 1 a dozen times: the last two answers are kept)
+    mutable int32_t sk0 = -1, sk1 = -1;
+    mutable gu32 sp0 = nullptr, sp1 = nullptr;
+    __device__ __forceinline__ gu32 slot(int32_t k) const {
+        if (k == sk0) return sp0;
+        if (k == sk1) return sp1;
+        const gu32 q = (gu32)job.col + ((int64_t)k * job.col_stride - (int64_t)sweep::slot_off(geom(), k)) * 4;
+        sk1 = sk0;
+        sp1 = sp0;
+        sk0 = k;
+        sp0 = q;
+        return q;
+    }
     __device__ __forceinline__ void sync_mem() const { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }  // same wavefront writes, then reads
 
     // ---- block records --------------------------------------------------------------------------------------------------------
@@ -249,6 +267,10 @@ struct FullDevBackend {
             sync_mem();
         }
         if (words <= 0) return hin ? row_sum(i0, i1) : i1 - i0;  // no rows: the bottom row is the top row
+        if (win_fail || !sweep::slot_holds(geom(), k, w0, w1)) {
+            win_fail = true;
+            return 0;
+        }
         const bool tap_inside = tap && wt > w0;
         const uint64_t t0 = tick();
         const bool from_prev = lazy_k == k;
@@ -263,12 +285,12 @@ struct FullDevBackend {
             StripJob j;
             j.a_codes = job.a_codes;
             j.b_prof = job.b_prof;
-            j.v = job.col + (size_t)k * (size_t)job.col_stride * 4;
+            j.v = (uint32_t*)slot(k);
             j.hin_gran = st > 0 ? job.gran + (size_t)((st - 1) & 1) * 8 : nullptr;
             j.hin_arr = (st == 0 && hin) ? job.hrow : nullptr;
             j.hout_gran = last ? nullptr : job.gran + (size_t)(st & 1) * 8;
             j.hout_arr = job.hrow;  // (TAP: written only when tap_lane >= 0)
-            j.values = from_prev ? job.col + (size_t)(k - 1) * (size_t)job.col_stride * 4 : nullptr;  // (TAP: the source of the left edge)
+            j.values = from_prev ? (uint32_t*)slot(k > 0 ? k - 1 : 0) : nullptr;  // (TAP: the source of the left edge)
             j.sum_out = last ? job.sum : nullptr;
             j.n = i1 - i0;
             j.word0 = sw0;
@@ -516,9 +538,10 @@ struct FullDevBackend {
     }
 };
 
-__device__ __forceinline__ void store_full_result(const FullJob& job, const FullResult& fr, uint64_t strip_instr) {
+__device__ __forceinline__ void store_full_result(const FullJob& job, const FullResult& fr, uint64_t strip_instr, bool win_fail) {
     PairResult res;
     res.status = fr.status == kFullOk ? kOk : (fr.status == kFullErrPasses ? kErrTooManyPasses : (fr.status == kFullErrH0 ? kErrH0 : kErrRangeOrder));
+    if (win_fail) res.status = kErrWindow;
     res.cost = fr.cost;
     res.f_max = fr.f_max;
     res.f_max_tries = fr.f_max_tries;
@@ -558,7 +581,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_full_kernel(con
             fr.status = kFullErrOrder;
         }
         if (rfl(*(const PA_GLOBAL uint32_t*)err) != PA_ERR_NONE && fr.status == kFullOk) fr.status = kFullErrOrder;
-        store_full_result(be.job, fr, be.strip_instructions());
+        store_full_result(be.job, fr, be.strip_instructions(), be.win_fail);
         if (probe_stats) {
             const unsigned long long vals[9] = {be.n_probe, be.n_round, be.t_build, be.t_dp, be.t_h, be.t_index, be.t_prune, be.t_init, be.tick() - t_begin};
             for (int q = 0; q < 9; ++q) atomicAdd(probe_stats + q, lane == 0 ? vals[q] : 0ull);

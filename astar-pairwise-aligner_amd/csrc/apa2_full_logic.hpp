@@ -30,6 +30,7 @@
 //                                                  (!hin, !tap) = None; (hin, !tap) = Input; (!hin, tap) = Output over [w0, wt) then
 //                                                  Input over [wt, w1); (hin, tap) = Update over [w0, wt) then Input over [wt, w1)
 //   int32_t h(i, j); void prune_block(i0, i1, j0, j1); void update_contours()
+//   bool failed()                                  the backend could not compute the last block (the search stops; device only)
 //   int32_t uniform(x)                             x, known to be the same in every lane (device: back into a scalar register)
 #pragma once
 #include <math.h>
@@ -67,7 +68,7 @@ struct FullResult {
     int32_t last_block_idx, blocks_len;
 };
 
-enum : int32_t { kFullOk = 0, kFullErrOrder = 1, kFullErrRange = 2, kFullErrPasses = 3, kFullErrH0 = 4, kFullErrSplit = 5 };
+enum : int32_t { kFullOk = 0, kFullErrOrder = 1, kFullErrRange = 2, kFullErrPasses = 3, kFullErrH0 = 4, kFullErrSplit = 5, kFullErrBackend = 6 };
 
 template <class B>
 struct PairProgFull {
@@ -273,6 +274,10 @@ struct PairProgFull {
                 cur = old;
             } else {
                 if (!compute_next_block(k, prev, old, s, e, i0, i1, &cur)) return false;
+                if (be.failed()) {  // (device: a strip error, or the block left the pair's window of the column store)
+                    err = kFullErrBackend;
+                    return false;
+                }
                 be.store_rec(k, cur);  // (the block is overwritten in place: a pass that ends at this block's fixed range leaves it like this)
             }
             last_block_idx = k;

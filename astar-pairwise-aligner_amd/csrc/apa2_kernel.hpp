@@ -27,7 +27,9 @@ struct PairJob {
     const uint32_t* b_prof;   // BitProfile words of b, u32 view
     BlockRec* rec;            // [nblk + 1] persistent block records
     uint32_t* col;            // column store: slot k (block k's right-edge column) = col + k * col_stride * 4, indexed by absolute word
-    int64_t col_stride;       // words per slot (ceil(m / 64))
+    int64_t col_stride;       // words per slot: the pair's window (sweep_logic.hpp SlotGeom), ceil(m / 64) = the full column
+    uint32_t slot_ratio;      // SlotGeom::ratio
+    uint32_t pad0;
     const int32_t* sh_h;      // SH: h(i) for i = 0..n, else nullptr
     uint64_t* gran;           // 2 rows x 8 granules, zero between uses
     int32_t* sum;             // scratch: bottom-row sum of the last strip
@@ -72,7 +74,22 @@ struct DevBackend {
     __device__ __forceinline__ int32_t uniform(int32_t x) const { return (int32_t)rfl((uint32_t)x); }  // back to a scalar register
     __device__ __forceinline__ bool failed() const { return rfl(__hip_atomic_load((const PA_GLOBAL uint32_t*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != PA_ERR_NONE; }
 
-    __device__ __forceinline__ gu32 slot(int32_t k) const { return (gu32)job.col + (size_t)k * (size_t)job.col_stride * 4; }
+    mutable bool win_fail = false;  // a block left the window of the column store
+    __device__ __forceinline__ sweep::SlotGeom geom() const { return sweep::SlotGeom{job.n, job.m, (int32_t)job.col_stride, job.slot_ratio}; }
+    // slot k, addressed by ABSOLUTE word (the pointer is moved back by the window's first word)
+    // (a block's logic asks for slots k and k - 1 a dozen times: the last two answers are kept)
+    mutable int32_t sk0 = -1, sk1 = -1;
+    mutable gu32 sp0 = nullptr, sp1 = nullptr;
+    __device__ __forceinline__ gu32 slot(int32_t k) const {
+        if (k == sk0) return sp0;
+        if (k == sk1) return sp1;
+        const gu32 q = (gu32)job.col + ((int64_t)k * job.col_stride - (int64_t)sweep::slot_off(geom(), k)) * 4;
+        sk1 = sk0;
+        sp1 = sp0;
+        sk0 = k;
+        sp0 = q;
+        return q;
+    }
 
     __device__ __forceinline__ BlockRec load_rec(int32_t k) const {
         const PA_GLOBAL int32_t* p = (const PA_GLOBAL int32_t*)job.rec + (size_t)k * 8;
@@ -131,6 +148,10 @@ struct DevBackend {
     __device__ __forceinline__ int32_t compute(int32_t k, const BlockRec& prev, const BlockRec& cur, int32_t i0, int32_t i1) const {
         const int32_t w0 = cur.js >> 6, w1 = cur.je >> 6, words = w1 - w0;
         if (words <= 0) return i1 - i0;  // no rows: the bottom row is the top row (+1 per column)
+        if (!sweep::slot_holds(geom(), k, w0, w1)) {
+            win_fail = true;
+            return 0;
+        }
         const int32_t pw0 = prev.js >> 6, pw1 = prev.je >> 6;
         const gu32 dst = slot(k);
         const gcu32 src = (gcu32)slot(k - 1);
@@ -162,7 +183,7 @@ struct DevBackend {
             StripJob j;
             j.a_codes = job.a_codes;
             j.b_prof = job.b_prof;
-            j.v = job.col + (size_t)k * (size_t)job.col_stride * 4;
+            j.v = (uint32_t*)dst;
             j.hin_gran = st > 0 ? job.gran + (size_t)((st - 1) & 1) * 8 : nullptr;
             j.hin_arr = nullptr;
             j.hout_gran = last ? nullptr : job.gran + (size_t)(st & 1) * 8;
@@ -298,7 +319,8 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_kernel(const Pa
             res = PairResult{};
             res.status = kErrDegenerate;
         }
-        if (rfl(*(const PA_GLOBAL uint32_t*)err) != PA_ERR_NONE && res.status == kOk) res.status = kErrDevice;
+        if (be.win_fail) res.status = kErrWindow;
+        else if (rfl(*(const PA_GLOBAL uint32_t*)err) != PA_ERR_NONE && res.status == kOk) res.status = kErrDevice;
         *job.result = res;  // (every lane stores the same 64 bytes: no lane-dependent branch at the end of the loop body either)
     }
 }

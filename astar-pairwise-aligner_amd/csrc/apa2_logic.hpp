@@ -65,6 +65,7 @@ enum : int32_t {
     kErrTooManyPasses = 6,   // the search did not end within kMaxPasses passes
     kErrDevice = 7,          // a backend failure (strip error word)
     kErrDegenerate = 8,      // |a| == 0 or |b| == 0
+    kErrWindow = 9,          // a block's rows left the pair's window of the column store: the pair runs again with full-height slots
 };
 constexpr int32_t kMaxPasses = 1 << 20;
 // A pass whose bound exceeds |a| + |b| covers the whole matrix and must succeed; a search that gets this far beyond it has met a

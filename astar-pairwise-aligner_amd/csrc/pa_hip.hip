@@ -198,8 +198,9 @@ bool ensure_device() {
 // returned to the driver by pa_release_pools().  PA_NO_ALLOC_CACHE=1 switches it off; PA_POISON_ALLOC=1 fills every buffer handed
 // out with 0xA5 (tests: nothing may depend on fresh memory being zero).
 namespace {
-constexpr size_t kCacheMin = size_t(16) << 20, kCacheMaxDefault = size_t(96) << 30;
-// The bound is PER DEVICE: PA_ALLOC_CACHE_MAX (bytes, or with a K / M / G suffix) if set, else half of the device's memory, at most 96 GB
+constexpr size_t kCacheMin = size_t(16) << 20, kCacheMaxDefault = size_t(16) << 30;
+// The bound is PER DEVICE: PA_ALLOC_CACHE_MAX (bytes, or with a K / M / G suffix) if set, else half of the device's memory, at most 16 GB
+// (round 4: with band-proportional block columns a 4096 x 100 kbp A*PA2 batch holds 5 GB, not 40)
 // -- other users of the device in the same process (torch, RCCL) cannot make this library let go of what it caches.
 size_t cache_limit(int dev) {
     static std::mutex mu;
@@ -1196,6 +1197,11 @@ struct pa_batch {
     // A*PA2 mode (pa_batch_create_params): one wavefront runs the whole band search of a pair (apa2_kernel.hpp); d_ckpt is the
     // pairs' column store, the traceback reads the blocks of the successful pass from it
     bool astar = false;
+    // the block-column store is band-proportional: slot width per pair in words (sweep_logic.hpp SlotGeom); a pair whose band leaves its
+    // window is aligned again with full-height slots (second round of pa_batch_align)
+    std::vector<uint32_t> win_words, slot_ratio;
+    int window_override = -1;  // -1: the policy below; 0: full columns; > 0: that many words
+    size_t window_retries = 0;
     pa_astarpa2_params aparams_c{};
     apa2::SearchParams sp{};
     DeviceBuf d_rec, d_results, d_pjobs, d_order, d_tstats, d_sh;
@@ -1479,7 +1485,9 @@ static bool astar_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t* cons
         j.b_prof = p->d_prof.as<uint32_t>() + p->prof_off[i] * 4;
         j.rec = p->d_rec.as<sweep::BlockRec>() + rec_off[i];
         j.col = p->d_ckpt.as<uint32_t>() + p->ckpt_off[i];
-        j.col_stride = (int64_t)w;
+        j.col_stride = (int64_t)p->win_words[i];
+        j.slot_ratio = p->slot_ratio[i];
+        j.pad0 = 0;
         j.sh_h = p->sp.heur == sweep::kHeurSH ? p->d_sh.as<int32_t>() + sh_off[i] : nullptr;
         j.gran = p->d_scratch_gran.as<uint64_t>() + i * 16;
         j.sum = p->d_sums.as<int32_t>() + i;
@@ -1490,7 +1498,10 @@ static bool astar_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t* cons
         t.rec = j.rec;
         t.res = j.result;
         t.tstats = p->d_tstats.as<uint32_t>() + 8 * i;
-        t.final_v = p->d_ckpt.as<uint32_t>() + p->ckpt_off[i] + nblk * w * 4;
+        t.final_v = p->d_ckpt.as<uint32_t>() + p->ckpt_off[i] + nblk * (size_t)p->win_words[i] * 4;  // (unused: banded blocks go through the slots)
+        t.win = (int32_t)p->win_words[i];
+        t.slot_ratio = p->slot_ratio[i];
+        (void)w;
         order[i] = (int32_t)i;
     }
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return p->n[x] + p->m[x] > p->n[y] + p->m[y]; });  // heaviest first
@@ -1499,6 +1510,18 @@ static bool astar_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t* cons
               !hip_ok(hipMemcpy(p->d_order.ptr, order.data(), P * 4, hipMemcpyHostToDevice), "H2D order")))
         return false;
     return true;
+}
+
+// Words per slot of a pair's block-column store.  Measured on the CPU-kernel engine (round 4): `simple` on 100 kbp at 5 % ends with bands of
+// 133 words within 69 words of the main diagonal, 10 kbp at 15 % with 37 within 20; `full` (GCSH) on 100 kbp at 5 % with 12 within 7.
+// The windows below hold those with room to spare; what does not fit (15 % on 100 kbp: 260 words) is aligned again with full columns.
+static size_t window_words(size_t n, size_t m, bool gcsh, int override_) {
+    const size_t wtot = std::max<size_t>((m + 63) / 64, 1);
+    static const int env = getenv("PA_APA2_WINDOW") ? atoi(getenv("PA_APA2_WINDOW")) : -1;
+    const int o = override_ >= 0 ? override_ : env;
+    if (o == 0) return wtot;
+    size_t W = o > 0 ? (size_t)o : (gcsh ? 64 : ((2 * ((std::max(n, m) + 1249) / 1250) + 32 + 7) & ~size_t(7)));
+    return std::min(W, wtot);
 }
 
 // Host threads for per-pair host work of a batch (the matches of GCSH, the SH tables): as many as the process may run on.
@@ -1703,7 +1726,8 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
         j.rec = p->d_rec.as<sweep::BlockRec>() + rec_off[i];
         j.jh = p->d_jh.as<int32_t>() + rec_off[i];
         j.col = p->d_ckpt.as<uint32_t>() + p->ckpt_off[i];
-        j.col_stride = (int64_t)w;
+        j.col_stride = (int64_t)p->win_words[i];
+        j.slot_ratio = p->slot_ratio[i];
         j.hrow = p->d_hrow.as<uint8_t>() + col_off[i];
         j.sh_h = sh ? p->d_sh.as<int32_t>() + sh_off[i] : nullptr;
         j.gran = p->d_scratch_gran.as<uint64_t>() + i * 16;
@@ -1732,7 +1756,10 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
         t.rec = j.rec;
         t.res = j.result;
         t.tstats = p->d_tstats.as<uint32_t>() + 8 * i;
-        t.final_v = p->d_ckpt.as<uint32_t>() + p->ckpt_off[i] + nblk * w * 4;
+        t.final_v = p->d_ckpt.as<uint32_t>() + p->ckpt_off[i] + nblk * (size_t)p->win_words[i] * 4;  // (unused: banded blocks go through the slots)
+        t.win = (int32_t)p->win_words[i];
+        t.slot_ratio = p->slot_ratio[i];
+        (void)w;
         order[i] = (int32_t)i;
     }
     std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return p->n[x] + p->m[x] > p->n[y] + p->m[y]; });  // heaviest first
@@ -1753,7 +1780,8 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
 }
 
 static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len, size_t pairs,
-                              bool trace, float band_hint = -1.f, int dt_max_g = 0, int dt_fr_drop = 0, const pa_astarpa2_params* astar = nullptr) {
+                              bool trace, float band_hint = -1.f, int dt_max_g = 0, int dt_fr_drop = 0, const pa_astarpa2_params* astar = nullptr,
+                              int window_override = -1) {
     if (!ensure_device()) return nullptr;
     static const bool cprof = getenv("PA_ALIGN_PROFILE") != nullptr;  // diagnostics: where the creation time goes
     auto cnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1771,6 +1799,12 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
         p->astar = true;
         p->aparams_c = *astar;
         p->astar_full = !apa2_supported(engine::params_from_c(*astar));  // GCSH / pruning / incremental doubling: apa2_full_kernel.hpp
+        p->window_override = window_override;
+        const bool gcsh = engine::params_from_c(*astar).heuristic == engine::HeuristicKind::GCSH;
+        for (size_t i = 0; i < pairs; ++i) {
+            p->win_words.push_back((uint32_t)window_words(a_len[i], b_len[i], gcsh, window_override));
+            p->slot_ratio.push_back(a_len[i] ? (uint32_t)std::min<uint64_t>(((uint64_t)b_len[i] << 20) / (uint64_t)a_len[i], 0xFFFFFFFFull) : 0u);
+        }
     }
     p->dt_max_g = dt_max_g;
     p->dt_fr_drop = dt_fr_drop;
@@ -1828,7 +1862,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             p->word_off.push_back(tw);
             tw += std::min<size_t>(std::max<size_t>(w, 1), (size_t)kTraceScratchWords);
             // u32: one V column per 256 columns of a (slot 0 unused); A*PA2 mode: slots 0 .. ceil(n / 256)
-            tck += (astar ? (a_len[i] + 255) / 256 + 1 : a_len[i] / 256 + 1) * w * 4;
+            tck += astar ? ((a_len[i] + 255) / 256 + 1) * (size_t)p->win_words[i] * 4 : (a_len[i] / 256 + 1) * w * 4;
             tcg += a_len[i] + b_len[i] + 2;
         }
         if (tcg >= (size_t(1) << 62) || !p->d_ckpt.alloc(tck * 4) || !p->d_cigar.alloc(tcg * 4) || !p->d_packed.alloc(tcg) ||
@@ -1979,6 +2013,8 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             t.cigar_cap = (uint32_t)std::min<size_t>(a_len[i] + b_len[i] + 2, 0xFFFFFFF0u);
             t.dt_max_g = dt_max_g;
             t.dt_fr_drop = dt_fr_drop;
+            t.win = t.w;
+            t.slot_ratio = 0;
             src_off[i] = p->cigar_off[i];
         }
         if (astar && !(p->astar_full ? astar_full_jobs(p.get(), a, b, tjobs) : astar_jobs(p.get(), a, b, tjobs))) return nullptr;
@@ -1998,7 +2034,8 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
                 // ... except many SHORT pairs (C4: 10 000 x 10 kbp), where four chunks hide the host's share: 24.1 against 26.0 ms
                 size_t tot = 0;
                 for (size_t i = 0; i < pairs; ++i) tot += a_len[i] + b_len[i];
-                if (pairs >= 8192 && tot / pairs <= 65536) C = 4;
+                // (the batched A*PA2 only: the full-DP traced batch has one forward launch and loses 2 ms to the chunks)
+                if (astar && pairs >= 8192 && tot / pairs <= 65536) C = 4;
             }
             if (env_chunks > 0) C = std::min<int>(env_chunks, pa_batch::kMaxChunks);
             C = (int)std::max<size_t>(1, std::min<size_t>((size_t)C, pairs));
@@ -2554,26 +2591,30 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
         return fail_all(PA_E_TIMEOUT);
     }
     p->gran_dirty = false;
-    // kernel times: summed over the chunks (chunks overlap on the GPU, so the sums can exceed the wall time of the call)
+    // kernel times.  With several chunks the kernels of different chunks run side by side: the figures are the SPANS from the first start to
+    // the last end of each phase (equal to the kernel times when there is one chunk), and the two spans overlap.
+    auto span = [&](hipEvent_t* from, hipEvent_t* to, float* out) -> bool {
+        float best = 0.f;
+        for (size_t c0 = 0; c0 < C; ++c0)
+            for (size_t c1 = 0; c1 < C; ++c1) {
+                float ms = 0.f;
+                if (!hip_ok(hipEventElapsedTime(&ms, from[c0], to[c1]), "elapsed")) return false;
+                if (ms > best) best = ms;
+            }
+        *out = best;
+        return true;
+    };
     if (forward_ms) {
         *forward_ms = 0.f;
         if (p->astar) {
-            for (size_t c = 0; c < C; ++c) {
-                float ms = 0.f;
-                if (!hip_ok(hipEventElapsedTime(&ms, p->evF0[c], p->evF1[c]), "elapsed")) return fail_all(PA_E_HIP);
-                *forward_ms += ms;
-            }
+            if (!span(p->evF0, p->evF1, forward_ms)) return fail_all(PA_E_HIP);
         } else if (!p->jobs.empty() && !hip_ok(hipEventElapsedTime(forward_ms, p->ev0, p->ev1), "elapsed")) {
             return fail_all(PA_E_HIP);
         }
     }
     if (trace_ms) {
         *trace_ms = 0.f;
-        for (size_t c = 0; c < C; ++c) {
-            float ms = 0.f;
-            if (!hip_ok(hipEventElapsedTime(&ms, p->evF1[c], p->evT1[c]), "elapsed")) return fail_all(PA_E_HIP);
-            *trace_ms += ms;
-        }
+        if (!span(p->evF1, p->evT1, trace_ms)) return fail_all(PA_E_HIP);
     }
     std::vector<apa2::PairResult> results;
     if (p->astar) {  // per-pair statistics (domain.rs:31-43) of the band search and the traceback
@@ -2610,6 +2651,67 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
             st.fill_fallback = ts[8 * i + 5];
         }
     }
+    // ---- second round: pairs whose band left their window of the column store, again with full-height slots ----
+    if (p->astar) {
+        std::vector<size_t> redo;
+        for (size_t i = 0; i < P; ++i)
+            if (results[i].status == apa2::kErrWindow) redo.push_back(i);
+        for (size_t r0 = 0; r0 < redo.size();) {
+            // (a chunk's full-height store stays below ~24 GB)
+            size_t r1 = r0;
+            double bytes = 0;
+            while (r1 < redo.size()) {
+                const size_t i = redo[r1];
+                const double need = ((double)p->n[i] / 256.0 + 2.0) * (double)((p->m[i] + 63) / 64) * 16.0;
+                if (r1 > r0 && bytes + need > 24e9) break;
+                bytes += need;
+                r1 += 1;
+            }
+            const size_t R = r1 - r0;
+            std::vector<std::vector<uint8_t>> ra(R), rb(R);
+            std::vector<const uint8_t*> ap(R), bp(R);
+            std::vector<size_t> al(R), bl(R);
+            for (size_t q = 0; q < R; ++q) {
+                const size_t i = redo[r0 + q];
+                ra[q].resize(p->n[i]);
+                rb[q].resize(p->m[i]);
+                if ((p->n[i] && !hip_ok(hipMemcpy(ra[q].data(), p->d_a.as<uint8_t>() + p->a_off[i], p->n[i], hipMemcpyDeviceToHost), "D2H a")) ||
+                    (p->m[i] && !hip_ok(hipMemcpy(rb[q].data(), p->d_b.as<uint8_t>() + p->b_off[i], p->m[i], hipMemcpyDeviceToHost), "D2H b")))
+                    return fail_all(PA_E_HIP);
+                ap[q] = ra[q].data();
+                bp[q] = rb[q].data();
+                al[q] = p->n[i];
+                bl[q] = p->m[i];
+            }
+            std::unique_ptr<pa_batch> sub(batch_create(ap.data(), al.data(), bp.data(), bl.data(), R, true, -1.f, p->dt_max_g, p->dt_fr_drop, &p->aparams_c, 0));
+            if (!sub) return fail_all(PA_E_HIP);
+            std::vector<int32_t> c2(R, 0);
+            std::vector<char*> g2(R, nullptr);
+            const int rc2 = pa_batch_align(sub.get(), c2.data(), cigar_out ? g2.data() : nullptr, nullptr, nullptr);
+            if (rc2 != 0) return fail_all(rc2);
+            for (size_t q = 0; q < R; ++q) {
+                const size_t i = redo[r0 + q];
+                costs[i] = c2[q];
+                lens[i] = 0;
+                results[i].status = apa2::kOk;
+                if (q < sub->pair_stats.size()) p->pair_stats[i] = sub->pair_stats[q];
+                if (cigar_out) {
+                    std::free(cigar_out[i]);
+                    cigar_out[i] = g2[q];
+                }
+            }
+            p->trace_fallbacks += sub->trace_fallbacks;
+            p->window_retries += R;
+            r0 = r1;
+        }
+        if (!redo.empty()) {  // (they are not the host engine's)
+            std::vector<size_t> keep;
+            for (const size_t i : handed_back)
+                if (results[i].status != apa2::kOk || lens[i] == kTraceFailed) keep.push_back(i);
+            handed_back.swap(keep);
+        }
+    }
+    mark("second round (windows)");
     if (!cigar_out && !cost_only_astar)  // (costs alone of a traced full-DP batch: the pairs the traceback handed back are not redone)
         handed_back.clear();
     if (cigar_out && !cost_only_astar) {  // (without cigar_out the loop over the chunks above did not look at the lengths)
@@ -2807,6 +2909,9 @@ extern "C" void pa_batch_full_info(const pa_batch* p, double* build_ms, double* 
 }
 
 extern "C" size_t pa_batch_trace_fallbacks(const pa_batch* p) { return p ? p->trace_fallbacks : 0; }
+// Pairs (summed over all pa_batch_align calls) whose band left their window of the block-column store and that were aligned again with
+// full-height slots.
+extern "C" size_t pa_batch_window_retries(const pa_batch* p) { return p ? p->window_retries : 0; }
 
 extern "C" int pa_batch_pair_stats(const pa_batch* p, pa_astarpa2_stats* stats_out) {
     if (!p || !p->astar || !stats_out || p->pair_stats.size() != p->pairs) {

@@ -51,6 +51,32 @@ struct HeurParams {
     const int32_t* sh_h;  // kHeurSH: h(i, *) for i = 0..n (engine.hpp SeedHeuristicH::h_by_i)
 };
 
+// ---- the block-column store of the batched A*PA2 kernels: band-proportional slots --------------------------------------------
+// The reference keeps, per block, the V words of the block's rows only (astarpa2/src/block.rs:8-21, blocks.rs:280-340).  The batch
+// kernels keep slot k of a pair as a WINDOW of `win` words around the main diagonal -- absolute words [off, off + win), off from the
+// block's column by a fixed-point slope -- so that a pair costs (blocks x win) words instead of (blocks x all rows); words are still
+// addressed by their absolute index (the slot pointer is moved back by `off`).  A block whose rows leave the window makes the pair
+// run again with full-height slots (pa_batch_align's second round).  win >= words of b: off = 0, the full column.
+struct SlotGeom {
+    int32_t n, m;      // |a|, |b|
+    int32_t win;       // words per slot
+    uint32_t ratio;    // floor(m * 2^20 / n): rows per column of the main diagonal
+};
+PA_HD int32_t slot_off(const SlotGeom& g, int32_t k) {
+    const int32_t wtot = (g.m + 63) >> 6;
+    if (g.win >= wtot) return 0;
+    const int64_t col = (int64_t)k * 256 < (int64_t)g.n ? (int64_t)k * 256 : (int64_t)g.n;
+    const int32_t dw = (int32_t)(((uint64_t)col * (uint64_t)g.ratio) >> 26);  // row of the diagonal / 64
+    int32_t off = dw - g.win / 2;
+    if (off > wtot - g.win) off = wtot - g.win;
+    if (off < 0) off = 0;
+    return off;
+}
+PA_HD bool slot_holds(const SlotGeom& g, int32_t k, int32_t w0, int32_t w1) {  // words [w0, w1) inside slot k's window
+    const int32_t off = slot_off(g, k);
+    return w0 >= off && w1 <= off + g.win;
+}
+
 PA_HD int32_t iabs32(int32_t x) { return x < 0 ? -x : x; }
 PA_HD int32_t imin32(int32_t a, int32_t b) { return a < b ? a : b; }
 PA_HD int32_t imax32(int32_t a, int32_t b) { return a > b ? a : b; }

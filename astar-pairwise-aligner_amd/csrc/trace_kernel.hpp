@@ -44,6 +44,8 @@ struct TraceJob {
     const sweep::BlockRec* rec;
     const apa2::PairResult* res;
     uint32_t* tstats;              // out (optional): TraceStats counters dt_trace_{tries, success, fallback}, fill_{tries, success, fallback}
+    int32_t win;                   // banded: words per slot of the column store (sweep_logic.hpp SlotGeom; >= w: full columns)
+    uint32_t slot_ratio;           // banded: SlotGeom::ratio
 };
 enum : uint32_t { kTraceFailed = 0xFFFFFFFFu };
 // Re-fills of up to 128 words (8192 rows, four strips) stay on the GPU; a pair with a taller one (an indel of more than
@@ -165,8 +167,12 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kerne
     const gu32 vals = (gu32)tj.scratch_vals;
     const gu32 sv = (gu32)tj.scratch_v;
     gcu32 fcols = (gcu32)vals;  // where the filled columns live
+    const sweep::SlotGeom geom{n, m, banded ? tj.win : w, banded ? tj.slot_ratio : 0u};
+    auto slot_ptr = [&](int kb) -> gcu32 {  // slot kb of the column store, addressed by absolute word
+        return (gcu32)tj.ckpt + ((int64_t)kb * (int64_t)geom.win - (int64_t)(banded ? sweep::slot_off(geom, kb) : 0)) * 4;
+    };
     auto ckpt_col = [&](int i0) -> gcu32 {  // the stored column at i0 (a multiple of 256); column 0 is V::one
-        return i0 == 0 ? (gcu32) nullptr : (gcu32)tj.ckpt + (size_t)(i0 >> 8) * (size_t)w * 4;
+        return i0 == 0 ? (gcu32) nullptr : slot_ptr(i0 >> 8);
     };
     // rows [js, je) and top value of stored block kb (its right-edge column is at column min(256 kb, n))
     struct BlkMeta {
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kerne
             f_jhi = lm.je;
             f_words = (lm.je - lm.js) >> 6;
             f_T0 = lm.top - 1;
-            fcols = (gcu32)tj.final_v + (size_t)(lm.js >> 6) * 4;
+            fcols = (banded ? slot_ptr((n + 255) >> 8) : (gcu32)tj.final_v) + (size_t)(lm.js >> 6) * 4;
         }
         if (!(f_i0 < to_i && to_i <= f_i1)) {
             fcols = (gcu32)vals;

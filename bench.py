@@ -491,10 +491,15 @@ def main():
             }
             if preset == "full":
                 fi = ba.full_info()
-                # the matches of GCSH (seeds, k-mer matches, local pruning) are found by host threads when the batch is created, i.e.
-                # OUTSIDE the timed align(); the contours are derived, probed and pruned on the GPU inside it.  Both rates are given.
-                leg["host_match_building_ms"] = round(fi["build_ms"], 1)
+                # the matches of GCSH (seeds, k-mer matches, local pruning) are part of the BATCH: found once when it is created -- by the GPU
+                # (csrc/gcsh_build_kernel.hpp), or by host threads with PA_GCSH_HOST_BUILD=1 -- i.e. OUTSIDE the timed align(); the contours are
+                # derived, probed and pruned on the GPU inside it.  pairs_per_sec is the resident rate, ..._incl_create_again everything.
+                if fi["build_ms"] < 0:
+                    leg["gpu_match_building_ms"] = round(-fi["build_ms"], 2)
+                else:
+                    leg["host_match_building_ms"] = round(fi["build_ms"], 1)
                 leg["matches"] = fi["matches"]
+                leg["pairs_per_sec_align_plus_match_building"] = round(len(ps) / (best[0] + abs(fi["build_ms"]) * 1e-3), 1)
             ba.close()
             t = time.perf_counter()
             bb2 = pa.Batch(ps, params=mk())  # the large device buffers come back from the library's cache

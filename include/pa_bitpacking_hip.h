@@ -139,6 +139,10 @@ int pa_batch_align(pa_batch* plan, int32_t* cost_out, char** cigar_out, float* f
 void pa_free_cigars(char** cigars, size_t n);
 /* Pairs (summed over all pa_batch_align calls of this plan) whose traceback was redone by the host engine. */
 size_t pa_batch_trace_fallbacks(const pa_batch* plan);
+/* Batched A*PA2: the block-column store of a pair is a window of words around the main diagonal per 256-column block (the reference keeps the
+ * block's rows only: astarpa2/src/block.rs:8-21), sized from the lengths (PA_APA2_WINDOW=<words> overrides, 0 = full columns).  Pairs
+ * (summed over all pa_batch_align calls of this plan) whose band left the window and that were aligned again with full-height columns. */
+size_t pa_batch_window_retries(const pa_batch* plan);
 
 /* ---- batched A*PA2 (band-limited alignment of many pairs) ------------------------------------------------------------ */
 /* What a loop over pa_align(a, b, params, trace = 1, ..) returns -- cost, CIGAR and statistics of AstarPa2Params::simple(),

@@ -85,6 +85,7 @@ struct FullEmuBackend {
         bp.no_ilp = false;
     }
     int32_t uniform(int32_t x) const { return x; }
+    bool failed() const { return false; }
     FullRec load_rec(int32_t k) const { return rec[(size_t)k]; }
     void store_rec(int32_t k, const FullRec& r) { rec[(size_t)k] = r; }
     int32_t index(int32_t k, const FullRec& r, int32_t j) const {  // block.rs:69-122 (from the top; the first column is all +1)

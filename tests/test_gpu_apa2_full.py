@@ -192,3 +192,63 @@ def test_c3_pair_and_small_batch_full(pa, oracle):
     pairs = [gen_pair(100_000, 0.05, seed=3_000_000 + s) for s in range(16)]
     check(pa, oracle, pairs, oracle.params_full(), verify_only_sample=[0, 5, 15], max_fallbacks=0)
     check(pa, oracle, pairs[:1], oracle.params_full())
+
+
+@pytest.mark.parametrize("name", ["simple", "full", "sh12", "gap_incr"])
+def test_band_proportional_columns_and_the_second_round(pa, oracle, name, monkeypatch):
+    """The block-column store of a pair is a window around the main diagonal (pa_bitpacking_hip.h).  With a window far too small for the
+    pairs (PA_APA2_WINDOW=4 words) most of them leave it and are aligned again with full columns: same cost, CIGAR string and statistics;
+    with the default windows none of these pairs does, and a long indel (the band wanders off the diagonal) does."""
+    from tests.test_gpu_engine import gpu_params
+
+    oc = variants(oracle)[name][0]
+    pairs = [gen_pair(n, e, seed) for n, e, seed in [(300, 0.05, 1), (3000, 0.1, 3), (10000, 0.15, 4), (30000, 0.08, 6), (20000, 0.03, 5), (9000, 0.3, 8)]]
+    a = rand_seq(40_000, seed=17)
+    indel = (a, a[:10_000] + a[16_000:])  # 6000 columns deleted: the alignment runs ~94 words off the diagonal of the rectangle
+    want = [oracle.cpu_align(x, y, oc) for x, y in pairs + [indel]]
+
+    def run(ps):
+        batch = pa.Batch(ps, params=gpu_params(pa, oc))
+        costs, cigars, _, _ = batch.align()
+        stats = batch.pair_stats()
+        out = (batch.window_retries(), batch.trace_fallbacks())
+        batch.close()
+        return costs, cigars, stats, out
+
+    def same(costs, cigars, stats, idx):
+        for t, i in enumerate(idx):
+            assert (int(costs[t]), cigars[t]) == want[i][:2], (name, i)
+            assert {k: stats[t][k] for k in KEYS} == {k: want[i][2][k] for k in KEYS}, (name, i)
+
+    costs, cigars, stats, (retries, fallbacks) = run(pairs)
+    same(costs, cigars, stats, range(len(pairs)))
+    assert fallbacks == 0
+    costs, cigars, stats, (retries_indel, fallbacks) = run(pairs + [indel])
+    same(costs, cigars, stats, range(len(pairs) + 1))
+    assert fallbacks == 0 and retries_indel >= retries
+    monkeypatch.setenv("PA_APA2_WINDOW", "4")
+    # (the library reads the variable once per process: this part runs in a child)
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import oracle
+        import astar_pairwise_aligner_amd as pa
+        from tests.test_gpu_engine import gpu_params
+        from tests.test_restated_engine import variants
+        from tests.util_seq import gen_pair
+        oc = variants(oracle)[%r][0]
+        pairs = [gen_pair(n, e, seed) for n, e, seed in [(300, 0.05, 1), (3000, 0.1, 3), (10000, 0.15, 4), (30000, 0.08, 6), (20000, 0.03, 5), (9000, 0.3, 8)]]
+        b = pa.Batch(pairs, params=gpu_params(pa, oc))
+        costs, cigars, _, _ = b.align()
+        for (x, y), c, g in zip(pairs, costs, cigars):
+            w = oracle.cpu_align(x, y, oc)
+            assert (int(c), g) == w[:2]
+        assert b.window_retries() >= 4 and b.trace_fallbacks() == 0, (b.window_retries(), b.trace_fallbacks())
+        print("ok", b.window_retries())
+    """) % (str(__import__("pathlib").Path(__file__).resolve().parent.parent), name)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]

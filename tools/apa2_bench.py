@@ -35,7 +35,7 @@ def bench(pairs, label, reps=3):
           f"strip VALU instructions (model) {strip_instr:.3e} = {strip_instr/(best[1]*1e-3)/1e9:.0f} G/s  fallbacks {bt.trace_fallbacks()}  tries {sum(s['f_max_tries'] for s in st)/len(st):.2f}", flush=True)
     if PRESET == "full":
         fi = bt.full_info()
-        print(f"   full: host match building {fi['build_ms']:.1f} ms for {fi['matches']:.0f} matches; h probes {fi['probes']:.3e}, load rounds {fi['rounds']:.3e}; wavefront-ms by phase {({k: round(v, 1) for k, v in fi['phase_wave_ms'].items()})}", flush=True)
+        print(f"   full: match building {abs(fi['build_ms']):.1f} ms ({'GPU' if fi['build_ms'] < 0 else 'host threads'}) for {fi['matches']:.0f} matches; h probes {fi['probes']:.3e}, load rounds {fi['rounds']:.3e}; wavefront-ms by phase {({k: round(v, 1) for k, v in fi['phase_wave_ms'].items()})}", flush=True)
     bt.close()
     t = time.perf_counter()
     pa.Batch(pairs, params=params()).close()

@@ -1,12 +1,12 @@
 // apa2_full_logic.hpp -- the per-pair band search of the WHOLE A*PA2 family as one flat program: any heuristic behind `h(i, j)`
 // (NoCost, GapCost, SH, GCSH), incremental doubling with its stored row of horizontal differences, pruning of matches between blocks.
 //
-// STATUS: host-side groundwork for a batched `astarpa2_full`.  Nothing in the shipped library includes this
-// header yet; it is exercised by oracle/apa2_full_emu.cpp over the CPU kernels and csrc/gcsh.hpp, and compared with the host engine
-// and with the second restatement (tests/test_apa2_full_emu.py).  apa2_logic.hpp is the program the GPU runs today for the `simple`
-// family; this one generalises it in the form a device backend needs: flat per-block records, block columns addressed by absolute
-// word in per-block slots (so "keep the words an older pass fixed" is "leave them where they are"), compute calls over word ranges
-// with an explicit mode for the horizontal differences at the top, and the heuristic / pruning behind four backend calls.
+// Backends: csrc/apa2_full_kernel.hpp (gfx950: pa_batch_create_params with AstarPa2Params::full() and its relatives, round 4) and
+// oracle/apa2_full_emu.cpp (tests only: the CPU kernels and csrc/gcsh.hpp, compared with the host engine and the second restatement in
+// tests/test_apa2_full_emu.py).  apa2_logic.hpp is the program of the `simple` family (wave-parallel scans instead of probes); this one
+// covers the whole family: flat per-block records, block columns addressed by absolute word in per-block slots (so "keep the words an
+// older pass fixed" is "leave them where they are"), compute calls over word ranges with the stored row of horizontal differences read
+// at the top and / or tapped on the way, and the heuristic / pruning behind four backend calls.
 //
 // What it restates:
 //   domain.rs:117-246   j_range for Domain::Astar with the literal probing loops (GCSH is not monotone along a column, so the

@@ -39,8 +39,8 @@ typedef struct pa_astarpa2_params { /* AstarPa2Params, params.rs:8-42 */
     int32_t heuristic_p; /* HeuristicParams.p: local-pruning look-ahead of GCSH, 0 = off */
     int32_t doubling;
     int32_t doubling_start;
-    float factor; /* BandDoubling */
-    float delta;  /* LinearSearch */
+    float factor; /* BandDoubling: must be finite and > 1 (a band that does not grow never ends the search: rejected as invalid) */
+    float delta;  /* LinearSearch: 1 <= delta <= 2^30 */
     int32_t block_width;
     pa_block_params front;
     int32_t sparse_h;

@@ -2556,21 +2556,37 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
         if (total && (!hip_ok(hipMemcpyAsync(p->h_text, p->d_packed.as<uint8_t>() + p->chunk_base[c], total, hipMemcpyDeviceToHost, s), "D2H cigars") ||
                       !hip_ok(hipStreamSynchronize(s), "sync")))
             return fail_all(PA_E_HIP);
-        for (size_t q = lo; q < lo + cnt; ++q) {
+        // strings to the caller: one malloc + one copy per pair; for tens of megabytes of text (4096 x 100 kbp: 70 MB) on several threads
+        std::atomic<bool> oom{false};
+        auto make = [&](size_t q) {
             const size_t i = (size_t)p->torder_host[q];
-            if (h_tlen[q] == kTextFailed) {
-                handed_back.push_back(i);
-                continue;
-            }
+            if (h_tlen[q] == kTextFailed) return;
             char* out = (char*)std::malloc((size_t)h_tlen[q] + 1);
             if (!out) {
-                set_error("out of memory");
-                return fail_all(PA_E_NOMEM);
+                oom = true;
+                return;
             }
             if (h_tlen[q]) std::memcpy(out, p->h_text + h_dst[q], h_tlen[q]);
             out[h_tlen[q]] = 0;
             cigar_out[i] = out;
+        };
+        if (total >= (size_t(8) << 20) && cnt >= 64 && host_threads() > 1) {
+            const unsigned nt = std::min<unsigned>(host_threads(), 8);
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t)
+                th.emplace_back([&, t] {
+                    for (size_t q = lo + t; q < lo + cnt; q += nt) make(q);
+                });
+            for (auto& t : th) t.join();
+        } else {
+            for (size_t q = lo; q < lo + cnt; ++q) make(q);
         }
+        if (oom) {
+            set_error("out of memory");
+            return fail_all(PA_E_NOMEM);
+        }
+        for (size_t q = lo; q < lo + cnt; ++q)
+            if (h_tlen[q] == kTextFailed) handed_back.push_back((size_t)p->torder_host[q]);
     }
     mark("chunks: text D2H + strings");
     // ---- the small per-pair arrays, once ----

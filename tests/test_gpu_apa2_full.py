@@ -252,3 +252,45 @@ def test_band_proportional_columns_and_the_second_round(pa, oracle, name, monkey
     """) % (str(__import__("pathlib").Path(__file__).resolve().parent.parent), name)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]
+
+
+def test_matches_from_host_threads_give_the_same(pa, oracle):
+    """PA_GCSH_HOST_BUILD=1: the matches of GCSH come from host threads at creation (csrc/gcsh.hpp) instead of the GPU's build kernel -- also
+    what a parameter set with a look-ahead beyond the kernel's LDS arrays (p > 14) gets.  Same cost, CIGAR string and statistics."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import oracle
+        import astar_pairwise_aligner_amd as pa
+        from tests.test_gpu_engine import gpu_params
+        from tests.test_sweep_emu import KEYS
+        from tests.util_seq import gen_pair
+        pairs = [gen_pair(n, e, seed) for n, e, seed in [(300, 0.05, 1), (3000, 0.1, 3), (10000, 0.15, 4), (30000, 0.08, 6), (9000, 0.3, 8)]]
+        for oc in (oracle.params_full(), oracle.make_params(domain="astar", heuristic="gcsh", k=10, p=20, doubling="band", start="h0", factor=2.0,
+                                                             block_width=256, sparse=True, incremental_doubling=True, dt_trace=True, max_g=40,
+                                                             fr_drop=10, sparse_h=True, prune=True)):
+            b = pa.Batch(pairs, params=gpu_params(pa, oc))
+            costs, cigars, _, _ = b.align()
+            st = b.pair_stats()
+            assert b.full_info()["build_ms"] > 0  # (positive: host threads)
+            for i, (x, y) in enumerate(pairs):
+                w = oracle.cpu_align(x, y, oc)
+                assert (int(costs[i]), cigars[i]) == w[:2] and all(st[i][k] == w[2][k] for k in KEYS), i
+            assert b.trace_fallbacks() == 0
+        print("ok")
+    """) % str(__import__("pathlib").Path(__file__).resolve().parent.parent)
+    import os
+
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, PA_GCSH_HOST_BUILD="1"))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]
+    # ... and p = 20 without the variable: the library itself falls back to the host's threads for that parameter set
+    from tests.test_gpu_engine import gpu_params
+
+    oc = oracle.make_params(domain="astar", heuristic="gcsh", k=10, p=20, doubling="band", start="h0", factor=2.0, block_width=256, sparse=True,
+                            incremental_doubling=True, dt_trace=True, max_g=40, fr_drop=10, sparse_h=True, prune=True)
+    pairs = [gen_pair(4000, 0.1, 5), gen_pair(700, 0.02, 6)]
+    check(pa, oracle, pairs, oc, max_fallbacks=0)

@@ -298,7 +298,9 @@ static bool poison_fill(void* ptr, size_t size) {
     return hip_ok(hipMemsetAsync(ptr, 0xA5, size, st), "poison") && hip_ok(hipStreamSynchronize(st), "poison sync");
 }
 
+void pinned_release_all();
 void release_alloc_cache() {
+    pinned_release_all();
     std::vector<CachedBlock> all;
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
@@ -360,6 +362,105 @@ bool DeviceBuf::reserve(size_t bytes, bool* grew) {
     if (grew) *grew = true;
     return true;
 }
+// Pinned host buffers (the packed CIGAR text of a batch, its per-pair lengths) are POOLED for the life of the process: hipHostMalloc /
+// hipHostFree of a few tens of megabytes cost 5-25 ms each, which a batch that lives for one alignment (the work queue's chunks, pa_align_file)
+// paid twice (round 4: `close` of the C4 batch 12-50 ms).  At most kPinnedPoolMax bytes are kept; pa_release_pools() frees them.
+namespace {
+constexpr size_t kPinnedPoolMax = size_t(1) << 30;
+struct PinnedBlock {
+    void* ptr;
+    size_t size;
+};
+std::mutex& g_pin_mu = *new std::mutex;
+std::vector<PinnedBlock>& g_pin = *new std::vector<PinnedBlock>;
+size_t g_pin_bytes = 0;
+}  // namespace
+void* pinned_take(size_t bytes, size_t* got) {
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        size_t best = g_pin.size();
+        for (size_t i = 0; i < g_pin.size(); ++i)
+            if (g_pin[i].size >= bytes && (best == g_pin.size() || g_pin[i].size < g_pin[best].size)) best = i;
+        if (best != g_pin.size()) {
+            void* p = g_pin[best].ptr;
+            *got = g_pin[best].size;
+            g_pin_bytes -= g_pin[best].size;
+            g_pin.erase(g_pin.begin() + (long)best);
+            return p;
+        }
+    }
+    void* hp = nullptr;
+    if (!hip_ok(hipHostMalloc(&hp, bytes, hipHostMallocDefault), "hipHostMalloc(pinned pool)")) return nullptr;
+    *got = bytes;
+    return hp;
+}
+void pinned_give(void* ptr, size_t size) {
+    if (!ptr) return;
+    std::vector<PinnedBlock> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        g_pin.push_back({ptr, size});
+        g_pin_bytes += size;
+        while (g_pin_bytes > kPinnedPoolMax && !g_pin.empty()) {
+            drop.push_back(g_pin.front());
+            g_pin_bytes -= g_pin.front().size;
+            g_pin.erase(g_pin.begin());
+        }
+    }
+    for (const PinnedBlock& b : drop) (void)hipHostFree(b.ptr);
+}
+// ... and so are the chunk streams of pa_batch_align (hipStreamDestroy costs ~3 ms each: a C4 batch of four chunks spent 12 ms of its
+// `close` there); per device, idle when they are handed back (the batch's destructor has waited for the device).
+namespace {
+std::vector<std::pair<int, hipStream_t>>& g_streams = *new std::vector<std::pair<int, hipStream_t>>;
+}
+hipStream_t stream_take() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (size_t i = 0; i < g_streams.size(); ++i)
+            if (g_streams[i].first == dev) {
+                hipStream_t s = g_streams[i].second;
+                g_streams.erase(g_streams.begin() + (long)i);
+                return s;
+            }
+    }
+    hipStream_t s = nullptr;
+    if (!hip_ok(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
+    return s;
+}
+void stream_give(hipStream_t s) {
+    if (!s) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        if (g_streams.size() < 64) {
+            g_streams.emplace_back(dev, s);
+            return;
+        }
+    }
+    (void)hipStreamDestroy(s);
+}
+void pinned_release_all() {
+    {
+        std::vector<std::pair<int, hipStream_t>> st;
+        {
+            std::lock_guard<std::mutex> lk(g_pin_mu);
+            st.swap(g_streams);
+        }
+        for (auto& x : st) (void)hipStreamDestroy(x.second);
+    }
+    std::vector<PinnedBlock> all;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        all.swap(g_pin);
+        g_pin_bytes = 0;
+    }
+    for (const PinnedBlock& b : all) (void)hipHostFree(b.ptr);
+}
+
 // A batch lets go of a dozen buffers at once: its destructor waits for the device ONCE and the releases that follow skip their wait.
 static thread_local bool g_release_synced = false;
 void release_scope_begin() {
@@ -1152,7 +1253,12 @@ extern "C" int pa_search_trace(const uint8_t* pattern, size_t plen, const uint8_
 
 struct pa_batch {
     struct ReleaseScope {  // FIRST member = destroyed last: ends the scope the destructor's body opens (one device wait for all the buffers)
-        ~ReleaseScope() { release_scope_end(); }
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~ReleaseScope() {
+            release_scope_end();
+            if (getenv("PA_ALIGN_PROFILE"))
+                std::fprintf(stderr, "[pa_batch_destroy] buffers released %.3f ms after the batch was created\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
     } release_scope_;
     size_t pairs = 0;
     std::vector<size_t> n, m, a_off, b_off, code_off, prof_off, gran_off;
@@ -1194,6 +1300,7 @@ struct pa_batch {
     hipEvent_t ev_pre = nullptr, evF0[kMaxChunks] = {}, evF1[kMaxChunks] = {}, evT1[kMaxChunks] = {};
     DeviceBuf d_cmeta, d_tlen_pos, d_dst_pos;  // d_cmeta: u64 text totals [kMaxChunks], then u32 tickets [kMaxChunks]
     uint8_t* h_meta = nullptr;                  // pinned: u64 totals [kMaxChunks], u32 tlen [pairs], u64 dst [pairs]
+    size_t h_meta_size = 0;
     // A*PA2 mode (pa_batch_create_params): one wavefront runs the whole band search of a pair (apa2_kernel.hpp); d_ckpt is the
     // pairs' column store, the traceback reads the blocks of the successful pass from it
     bool astar = false;
@@ -1221,12 +1328,15 @@ struct pa_batch {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~pa_batch() {
+        static const bool prof = getenv("PA_ALIGN_PROFILE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         release_scope_begin();
+        if (prof) std::fprintf(stderr, "[pa_batch_destroy] device wait %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (ev2) (void)hipEventDestroy(ev2);
-        if (h_text) (void)hipHostFree(h_text);
-        if (h_meta) (void)hipHostFree(h_meta);
+        pinned_give(h_text, h_text_size);
+        pinned_give(h_meta, h_meta_size);
         if (ev_pre) (void)hipEventDestroy(ev_pre);
         if (evB0) (void)hipEventDestroy(evB0);
         if (evB1) (void)hipEventDestroy(evB1);
@@ -1234,8 +1344,9 @@ struct pa_batch {
             if (evF0[c]) (void)hipEventDestroy(evF0[c]);
             if (evF1[c]) (void)hipEventDestroy(evF1[c]);
             if (evT1[c]) (void)hipEventDestroy(evT1[c]);
-            if (cstream[c]) (void)hipStreamDestroy(cstream[c]);
+            stream_give(cstream[c]);
         }
+        if (prof) std::fprintf(stderr, "[pa_batch_destroy] events, streams, pinned %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -2056,12 +2167,11 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             if (!p->d_torder.alloc(std::max<size_t>(pairs, 1) * 4) ||
                 !hip_ok(hipMemcpy(p->d_torder.ptr, p->torder_host.data(), pairs * 4, hipMemcpyHostToDevice), "H2D trace order"))
                 return nullptr;
-            void* hm = nullptr;
-            if (!hip_ok(hipHostMalloc(&hm, 64 + pairs * 12 + 64, hipHostMallocDefault), "hipHostMalloc(align meta)")) return nullptr;
-            p->h_meta = (uint8_t*)hm;
+            p->h_meta = (uint8_t*)pinned_take(64 + pairs * 12 + 64, &p->h_meta_size);
+            if (!p->h_meta) return nullptr;
             if (!hip_ok(hipEventCreate(&p->ev_pre), "event")) return nullptr;
             for (int c = 0; c < C; ++c)
-                if (!hip_ok(hipStreamCreateWithFlags(&p->cstream[c], hipStreamNonBlocking), "hipStreamCreate") || !hip_ok(hipEventCreate(&p->evF0[c]), "event") ||
+                if (!(p->cstream[c] = stream_take()) || !hip_ok(hipEventCreate(&p->evF0[c]), "event") ||
                     !hip_ok(hipEventCreate(&p->evF1[c]), "event") || !hip_ok(hipEventCreate(&p->evT1[c]), "event"))
                     return nullptr;
         }
@@ -2544,14 +2654,13 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
         if (!hip_ok(hipStreamSynchronize(s), "sync")) return fail_all(PA_E_HIP);
         if (!cnt || cost_only_astar || !cigar_out) continue;
         const uint64_t total = h_total[c];
-        if (total > p->h_text_size) {  // pinned, so the copy runs at link speed
-            if (p->h_text) (void)hipHostFree(p->h_text);
-            p->h_text = nullptr;
-            p->h_text_size = 0;
-            void* hp = nullptr;
-            if (!hip_ok(hipHostMalloc(&hp, total + total / 4 + 4096, hipHostMallocDefault), "hipHostMalloc(cigar text)")) return fail_all(PA_E_HIP);
-            p->h_text = (uint8_t*)hp;
-            p->h_text_size = total + total / 4 + 4096;
+        if (total > p->h_text_size) {  // pinned, so the copy runs at link speed; from the process-wide pool
+            pinned_give(p->h_text, p->h_text_size);
+            p->h_text = (uint8_t*)pinned_take(total + total / 4 + 4096, &p->h_text_size);
+            if (!p->h_text) {
+                p->h_text_size = 0;
+                return fail_all(PA_E_HIP);
+            }
         }
         if (total && (!hip_ok(hipMemcpyAsync(p->h_text, p->d_packed.as<uint8_t>() + p->chunk_base[c], total, hipMemcpyDeviceToHost, s), "D2H cigars") ||
                       !hip_ok(hipStreamSynchronize(s), "sync")))

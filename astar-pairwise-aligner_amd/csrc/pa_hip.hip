@@ -1330,6 +1330,14 @@ struct pa_batch {
     ~pa_batch() {
         static const bool prof = getenv("PA_ALIGN_PROFILE") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
+        if (prof) {  // (diagnostics: which of the batch's streams is still busy)
+            std::fprintf(stderr, "[pa_batch_destroy] busy: batch stream %d", stream && hipStreamQuery(stream) == hipErrorNotReady);
+            for (int c = 0; c < kMaxChunks; ++c)
+                if (cstream[c]) std::fprintf(stderr, " chunk%d %d", c, hipStreamQuery(cstream[c]) == hipErrorNotReady);
+            std::fprintf(stderr, "\n");
+            if (stream) (void)hipStreamSynchronize(stream);
+            std::fprintf(stderr, "[pa_batch_destroy] batch stream wait %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
         release_scope_begin();
         if (prof) std::fprintf(stderr, "[pa_batch_destroy] device wait %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (ev0) (void)hipEventDestroy(ev0);

@@ -108,13 +108,18 @@ struct DtLds {
 };
 constexpr int32_t kDtInf = 0x7FFFFFFF;
 
+// Wavefronts per SIMD asked of the register allocator, per instance (PA_TRACE_WAVES_DT_BANDED overrides the banded DT instance at build time).
+#ifndef PA_TRACE_WAVES_DT_BANDED
+#define PA_TRACE_WAVES_DT_BANDED 5
+#endif
+#define PA_TRACE_WAVES(DT_, BANDED_) ((DT_) ? ((BANDED_) ? PA_TRACE_WAVES_DT_BANDED : 5) : 6)
 // BANDED: the blocks are the banded blocks of the batched A*PA2 (TraceJob::rec) and TraceStats are counted; the full-height
 // checkpoints of the full-DP traced batch (pa_batch_create_trace) compile without either (round 4: with both in one instance the
 // full-DP traceback of C4 had gone from 12.2 to 16.6 ms).
 template <bool DT, bool BANDED>
 // (wavefronts per SIMD asked of the register allocator, measured on C4: the DT variant 13.1 ms without the bound, 9.1 / 9.9 / 13.8 ms
 //  at 5 / 6 / 7; the re-fill variant 12.6 / 12.1 / 13.1 ms at 5 / 6 / 7)
-__global__ __launch_bounds__(64 * kStripBlockWaves, DT ? 5 : 6) void trace_kernel(const TraceJob* __restrict__ jobs, const int32_t* __restrict__ list, int npairs, uint32_t* err) {
+__global__ __launch_bounds__(64 * kStripBlockWaves, PA_TRACE_WAVES(DT, BANDED)) void trace_kernel(const TraceJob* __restrict__ jobs, const int32_t* __restrict__ list, int npairs, uint32_t* err) {
     // `list`: the pairs of this launch (a chunk of the batch: pa_batch_align runs the chunks on streams of their own, so that the
     // traceback of one overlaps the forward pass of the next and the copy-out of the one before)
     const int slot_ = (int)rfl((uint32_t)(blockIdx.x * kStripBlockWaves + (threadIdx.x >> 6)));

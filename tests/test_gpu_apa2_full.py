@@ -294,3 +294,31 @@ def test_matches_from_host_threads_give_the_same(pa, oracle):
                             incremental_doubling=True, dt_trace=True, max_g=40, fr_drop=10, sparse_h=True, prune=True)
     pairs = [gen_pair(4000, 0.1, 5), gen_pair(700, 0.02, 6)]
     check(pa, oracle, pairs, oc, max_fallbacks=0)
+
+
+def test_pairs_the_match_builder_refuses_go_to_the_host_engine(pa, oracle):
+    """A tandem repeat has more candidate matches than the GPU's match builder keeps room for (and more kept matches within reach of one
+    search than its ring holds): the builder flags the pair, the band search hands it back, the host engine aligns it -- inside the same
+    batch as ordinary pairs, with the same results as the CPU-kernel engine for all of them."""
+    from astar_pairwise_aligner_amd import capi
+    from tests.test_gpu_engine import gpu_params
+
+    unit = rand_seq(7, seed=3)
+    a = (unit * 600)[:3000]
+    b = bytearray(a)
+    for q in (100, 900, 1700, 2500):
+        b[q] = ord("A") if b[q] != ord("A") else ord("C")
+    rep = (a, bytes(b[:1200] + b[1230:]))
+    with pytest.raises(capi.PaError):
+        capi.gcsh_matches(rep[0], rep[1], 12, 14)  # (the builder alone refuses it)
+    pairs = [gen_pair(2000, 0.05, 1), rep, gen_pair(5000, 0.1, 2), (rep[1], rep[0]), gen_pair(300, 0.2, 3)]
+    oc = oracle.params_full()
+    batch = pa.Batch(pairs, params=gpu_params(pa, oc))
+    costs, cigars, _, _ = batch.align()
+    stats = batch.pair_stats()
+    assert 1 <= batch.trace_fallbacks() <= 2
+    batch.close()
+    for i, (x, y) in enumerate(pairs):
+        w = oracle.cpu_align(x, y, oc)
+        assert (int(costs[i]), cigars[i]) == w[:2], i
+        assert {k: stats[i][k] for k in KEYS} == {k: w[2][k] for k in KEYS}, i

@@ -1,6 +1,7 @@
 """GPU soak for the batched A*PA2 (pa_batch_create_params): random parameter variants and batches of random pairs -- lengths 1 to
 60 000, divergence 0 to 80 %, long indels, unrelated pairs, empty sequences -- against the host engine over the CPU oracle kernels:
 cost, CIGAR string and all twelve statistics of every pair.  The CPU side runs on a thread pool (ctypes releases the GIL).
+Parameter sets: the `simple` family of tests/test_sweep_emu.py and (round 4) `full` and its relatives.
 Usage: python tests/tools/fuzz_apa2.py [seconds] [seed]"""
 import os
 import random
@@ -19,8 +20,14 @@ pa.require_gpu()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 vs = variants(oracle)
+# ... and the `full` family (round 4: GCSH with local pruning, pruning of matches, incremental doubling in the batch kernels)
+from tests.test_restated_engine import variants as all_variants  # noqa: E402
+
+for _name in ("full", "gcsh_noprune", "gcsh_k8_p0_prune", "gcsh_k6_p3_prune_incr", "gcsh_k10_p5_nosparseh", "gap_incr", "sh12_incr",
+              "dijkstra_incr_nodt", "gap_incr_f15"):
+    vs[_name] = all_variants(oracle)[_name][0]
 t0 = time.time()
-n_pairs = n_batches = bad = fallbacks = 0
+n_pairs = n_batches = bad = fallbacks = retries = 0
 pool = ThreadPoolExecutor(max_workers=min(32, os.cpu_count() or 1))
 while time.time() - t0 < budget:
     name = rng.choice(list(vs))
@@ -52,6 +59,7 @@ while time.time() - t0 < budget:
     costs, cigars, _, _ = bt.align()
     stats = bt.pair_stats()
     fallbacks += bt.trace_fallbacks()
+    retries += bt.window_retries()
     bt.close()
     want = list(pool.map(lambda p: oracle.cpu_align(p[0], p[1], vs[name]), pairs))
     n_batches += 1
@@ -60,5 +68,6 @@ while time.time() - t0 < budget:
         if not ((int(c), g) == (w[0], w[1]) and all(st[k] == w[2][k] for k in KEYS)):
             bad += 1
             print("MISMATCH", name, len(a), len(b), int(c), w[0], g == w[1], {k: (st[k], w[2][k]) for k in KEYS if st[k] != w[2][k]}, flush=True)
-print(f"{n_pairs} pairs in {n_batches} batches through the batched A*PA2, {fallbacks} handed to the host engine, {bad} mismatches, {time.time() - t0:.0f} s")
+print(f"{n_pairs} pairs in {n_batches} batches through the batched A*PA2 ({len(vs)} parameter sets), {fallbacks} handed to the host engine, "
+      f"{retries} aligned again with full block columns (their band left the window), {bad} mismatches, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)

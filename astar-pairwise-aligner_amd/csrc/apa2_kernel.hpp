@@ -37,21 +37,12 @@ struct PairJob {
     int32_t n, m;
 };
 
-__device__ __forceinline__ int32_t wsum(int32_t x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return (int32_t)rfl((uint32_t)x);
-}
+__device__ __forceinline__ int32_t wsum(int32_t x) { return wave_add(x); }
 
 // A descriptor fetched with one wide scalar load lives in ONE register tuple: when the register allocator spills it (and it must: the
 // strips need every scalar register), any later use of ONE field reloads all sixteen -- v_readlane after v_readlane on the vector
 // unit.  Passing every field through an empty asm gives each its own live range (round 4; seen in the ISA of apa2_full_kernel).
-template <class T>
-__device__ __forceinline__ T own_sgpr(T x) {
-    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "scalar or pointer");
-    asm volatile("" : "+s"(x));
-    return x;
-}
+using pa::own_sgpr;  // (strip_kernel.hpp)
 
 struct DevBackend {
     const PairJob& job;
@@ -244,12 +235,7 @@ struct DevBackend {
                 mm = (uint64_t)c[(size_t)wi * 4 + 2] | ((uint64_t)c[(size_t)wi * 4 + 3] << 32);
             }
             const int32_t val = valid ? __builtin_popcountll(p) - __builtin_popcountll(mm) : 0;
-            int32_t incl = val;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int32_t t = __shfl_up(incl, o, 64);
-                if (lane >= o) incl += t;
-            }
+            const int32_t incl = wave_scan_add(val);
             const int32_t P = base + incl - val;  // value at the first row of word wi
             // f drops by at most 2 per row: a word whose first row is more than 126 above the bound holds no row within it
             const bool cand = valid && (P + hval(i, wi << 6, sh_i) - 126 <= f_max);

@@ -249,8 +249,8 @@ __device__ __forceinline__ bool prune_with_kept(const BuildCtx& cx, int32_t si, 
         }
         const bool in = lane >= d0 && lane < d1;
         const int32_t f = in ? fr : kBuildNeg;
-        const int32_t up = __shfl_down(f, 1, 64);   // fr[d + 1] (lane 63: itself, never in range)
-        const int32_t dn = __shfl_up(f, 1, 64);     // fr[d - 1]
+        const int32_t up = __builtin_amdgcn_update_dpp(f, f, 0x130, 0xf, 0xf, false);  // wave_shl:1 = fr[d + 1] (lane 63: itself, never in range)
+        const int32_t dn = __builtin_amdgcn_update_dpp(f, f, 0x138, 0xf, 0xf, false);  // wave_shr:1 = fr[d - 1]
         int32_t v = nx;
         if (lane + 1 >= d0 && lane + 1 < d1 && lane < 63 && v < up) v = up;           // next[d] = max(.., fr[d + 1])
         if (in && v < f + 1) v = f + 1;                                                // max(.., fr[d] + 1)
@@ -369,12 +369,7 @@ __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __re
                 };
                 int32_t mine = 0;
                 for (int32_t s = head; s >= 0; s = next_same[s]) mine += ok_at(s) ? 1 : 0;
-                int32_t incl = mine;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int32_t t = __shfl_up(incl, o, 64);
-                    if (lane >= o) incl += t;
-                }
+                const int32_t incl = wave_scan_add(mine);
                 const int32_t total = __builtin_amdgcn_readlane(incl, 63);
                 if (ncand + total > jb.cap) {
                     status = kBuildOverflow;
@@ -407,12 +402,7 @@ __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __re
                 for (int32_t base = 0; base <= jb.nseeds; base += 64) {
                     const int32_t s = base + lane;
                     const int32_t v = s < jb.nseeds ? cnt[s] : 0;
-                    int32_t incl = v;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const int32_t t = __shfl_up(incl, o, 64);
-                        if (lane >= o) incl += t;
-                    }
+                    const int32_t incl = wave_scan_add(v);
                     if (s <= jb.nseeds) cnt[s] = carry + incl - v;
                     carry += __builtin_amdgcn_readlane(incl, 63);
                 }
@@ -432,7 +422,7 @@ __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __re
                     int32_t before = 0;
                     bool last = true;
                     for (int l = 0; l < 64; ++l) {
-                        const int32_t sl = __shfl(s, l, 64);
+                        const int32_t sl = __builtin_amdgcn_readlane(s, l);
                         if (sl == s && l < lane) before += 1;
                         if (sl == s && l > lane) last = false;
                     }
@@ -533,12 +523,7 @@ __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __re
                             g1 = cnt[s + 1];
                             for (int32_t q = g0; q < g1; ++q) kc += keptg[q];
                         }
-                        int32_t incl = kc;
-#pragma unroll
-                        for (int o = 1; o < 64; o <<= 1) {
-                            const int32_t t = __shfl_up(incl, o, 64);
-                            if (lane >= o) incl += t;
-                        }
+                        const int32_t incl = wave_scan_add(kc);
                         if (s < jb.nseeds) {
                             int32_t o = carry2 + incl - kc;
                             PA_GLOBAL pa_i32x4_b* wp = (PA_GLOBAL pa_i32x4_b*)jb.win0;

@@ -430,10 +430,8 @@ hipStream_t stream_take() {
     if (!hip_ok(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
     return s;
 }
-void stream_give(hipStream_t s) {
+void stream_give(hipStream_t s, int dev) {  // dev: the device the stream was created on (a batch may be destroyed from a thread bound to another)
     if (!s) return;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
     {
         std::lock_guard<std::mutex> lk(g_pin_mu);
         if (g_streams.size() < 64) {
@@ -734,11 +732,10 @@ __global__ __launch_bounds__(64) void format_pack_kernel(const uint32_t* __restr
     };
     uint32_t mine = 0;
     for (uint32_t k = (uint32_t)lane; k < n; k += 64) mine += chars_of(e[k]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    mine = (uint32_t)wave_add((int32_t)mine);
     unsigned long long base = 0;
     if (lane == 0) base = atomicAdd(total, (unsigned long long)mine);
-    base = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(base >> 32), 0, 64) << 32) | (unsigned long long)(uint32_t)__shfl((int)(uint32_t)base, 0, 64);
+    base = ((unsigned long long)rfl((uint32_t)(base >> 32)) << 32) | (unsigned long long)rfl((uint32_t)base);
     uint8_t* out = packed + base;
     uint32_t pos = 0;
     for (uint32_t b0 = 0; b0 < n; b0 += 64) {
@@ -748,12 +745,7 @@ __global__ __launch_bounds__(64) void format_pack_kernel(const uint32_t* __restr
             v = e[n - 1 - k];
             chars = chars_of(v);
         }
-        uint32_t incl = chars;  // exclusive prefix sum of `chars` over the wavefront
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
+        const uint32_t incl = (uint32_t)wave_scan_add((int32_t)chars);  // inclusive prefix sum of `chars` over the wavefront
         const uint32_t start = pos + incl - chars;
         if (k < n) {
             uint8_t* w = out + start + chars - 1;
@@ -767,7 +759,7 @@ __global__ __launch_bounds__(64) void format_pack_kernel(const uint32_t* __restr
                 } while (c);
             }
         }
-        pos += __shfl(incl, 63, 64);
+        pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
     if (lane == 0) {
         tlen[blockIdx.x] = pos;
@@ -1294,6 +1286,8 @@ struct pa_batch {
     std::vector<int32_t> torder_host;  // the same chunks with the pairs of a chunk in index order: what the traceback and the text kernels walk
                                        // (neighbouring pairs of the input in one workgroup: C4 traceback 10.0 against 10.9 ms in the forward order)
     DeviceBuf d_torder;
+    DeviceBuf d_tlist;     // the traceback's own order: each chunk's pairs by descending cost (trace_order_kernel)
+    uint32_t max_nm = 1;   // the longest |a| + |b| of the batch: no cost is larger
     std::vector<size_t> chunk_lo;      // chunk c = positions [chunk_lo[c], chunk_lo[c + 1])
     std::vector<uint64_t> chunk_base;  // byte offset of chunk c's region of d_packed
     hipStream_t cstream[kMaxChunks] = {};
@@ -1352,7 +1346,7 @@ struct pa_batch {
             if (evF0[c]) (void)hipEventDestroy(evF0[c]);
             if (evF1[c]) (void)hipEventDestroy(evF1[c]);
             if (evT1[c]) (void)hipEventDestroy(evT1[c]);
-            stream_give(cstream[c]);
+            stream_give(cstream[c], d_a.device);
         }
         if (prof) std::fprintf(stderr, "[pa_batch_destroy] events, streams, pinned %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (stream) (void)hipStreamDestroy(stream);
@@ -2148,14 +2142,9 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             // beside the band search of the next gains nothing (C4: 24.65 against 25.0 ms at the C ABI with four chunks), and chunks too
             // small to fill the chip lose (4096 x 100 kbp in three chunks: 135 against 120 ms).  PA_ALIGN_CHUNKS=n for experiments.
             static const int env_chunks = getenv("PA_ALIGN_CHUNKS") ? atoi(getenv("PA_ALIGN_CHUNKS")) : 0;
+            // (Until the traceback started its expensive pairs first, four chunks paid for many SHORT pairs -- C4: 24.1 against 26.0 ms --
+            //  by cutting the traceback's tail; with the ordering one chunk is ahead there too: 22.3 against 22.9 ms.)
             int C = 1;
-            {
-                // ... except many SHORT pairs (C4: 10 000 x 10 kbp), where four chunks hide the host's share: 24.1 against 26.0 ms
-                size_t tot = 0;
-                for (size_t i = 0; i < pairs; ++i) tot += a_len[i] + b_len[i];
-                // (the batched A*PA2 only: the full-DP traced batch has one forward launch and loses 2 ms to the chunks)
-                if (astar && pairs >= 8192 && tot / pairs <= 65536) C = 4;
-            }
             if (env_chunks > 0) C = std::min<int>(env_chunks, pa_batch::kMaxChunks);
             C = (int)std::max<size_t>(1, std::min<size_t>((size_t)C, pairs));
             p->chunk_lo.assign((size_t)C + 1, 0);
@@ -2172,9 +2161,10 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
             p->chunk_base[(size_t)C] = acc;
             p->torder_host = p->order_host;
             for (int c = 0; c < C; ++c) std::sort(p->torder_host.begin() + (long)p->chunk_lo[(size_t)c], p->torder_host.begin() + (long)p->chunk_lo[(size_t)c + 1]);
-            if (!p->d_torder.alloc(std::max<size_t>(pairs, 1) * 4) ||
+            if (!p->d_torder.alloc(std::max<size_t>(pairs, 1) * 4) || !p->d_tlist.alloc(std::max<size_t>(pairs, 1) * 4) ||
                 !hip_ok(hipMemcpy(p->d_torder.ptr, p->torder_host.data(), pairs * 4, hipMemcpyHostToDevice), "H2D trace order"))
                 return nullptr;
+            for (size_t i = 0; i < pairs; ++i) p->max_nm = (uint32_t)std::max<size_t>(p->max_nm, std::min<size_t>(a_len[i] + b_len[i], 0x7FFFFFFFu));
             p->h_meta = (uint8_t*)pinned_take(64 + pairs * 12 + 64, &p->h_meta_size);
             if (!p->h_meta) return nullptr;
             if (!hip_ok(hipEventCreate(&p->ev_pre), "event")) return nullptr;
@@ -2633,14 +2623,23 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
             if (const int rc = launch_astar(p, s, lo, cnt, d_ticket + c, nullptr)) return rc;
         if (!hip_ok(hipEventRecord(p->evF1[c], s), "event")) return PA_E_HIP;
         if (cnt && !cost_only_astar) {
-            const dim3 tg((unsigned)((cnt + kStripBlockWaves - 1) / kStripBlockWaves)), tb(64 * kStripBlockWaves);
+            static const int tbw = [] { const char* e = getenv("PA_TRACE_BLOCK_WAVES"); const int v = e ? atoi(e) : kStripBlockWaves; return v >= 1 && v <= kStripBlockWaves ? v : kStripBlockWaves; }();
+            const dim3 tg((unsigned)((cnt + tbw - 1) / tbw)), tb(64 * tbw);
             const TraceJob* tjp = p->d_tjobs.as<TraceJob>();
             const int32_t* list = p->d_torder.as<int32_t>() + lo;
             uint32_t* terr = p->d_misc.as<uint32_t>() + 1;
-            if (p->dt_max_g > 0 && p->astar) hipLaunchKernelGGL((trace_kernel<true, true>), tg, tb, kStripBlockWaves * sizeof(DtLds), s, tjp, list, (int)cnt, terr);
-            else if (p->dt_max_g > 0) hipLaunchKernelGGL((trace_kernel<true, false>), tg, tb, kStripBlockWaves * sizeof(DtLds), s, tjp, list, (int)cnt, terr);
-            else if (p->astar) hipLaunchKernelGGL((trace_kernel<false, true>), tg, tb, 0, s, tjp, list, (int)cnt, terr);
-            else hipLaunchKernelGGL((trace_kernel<false, false>), tg, tb, 0, s, tjp, list, (int)cnt, terr);
+            // the traceback starts its most expensive pairs first (PA_TRACE_ORDER=0: index order, for comparison)
+            static const bool by_cost = [] { const char* e = getenv("PA_TRACE_ORDER"); return !(e && atoi(e) == 0); }();
+            const int32_t* tlist = list;
+            if (by_cost && cnt > (size_t)tbw) {
+                hipLaunchKernelGGL(trace_order_kernel, dim3(1), dim3(1024), 0, s, tjp, list, (int)cnt, p->d_tlist.as<int32_t>() + lo, p->max_nm);
+                if (!hip_ok(hipGetLastError(), "trace_order_kernel launch")) return PA_E_HIP;
+                tlist = p->d_tlist.as<int32_t>() + lo;
+            }
+            if (p->dt_max_g > 0 && p->astar) hipLaunchKernelGGL((trace_kernel<true, true>), tg, tb, tbw * sizeof(DtLds), s, tjp, tlist, (int)cnt, terr);
+            else if (p->dt_max_g > 0) hipLaunchKernelGGL((trace_kernel<true, false>), tg, tb, tbw * sizeof(DtLds), s, tjp, tlist, (int)cnt, terr);
+            else if (p->astar) hipLaunchKernelGGL((trace_kernel<false, true>), tg, tb, 0, s, tjp, tlist, (int)cnt, terr);
+            else hipLaunchKernelGGL((trace_kernel<false, false>), tg, tb, 0, s, tjp, tlist, (int)cnt, terr);
             if (!hip_ok(hipGetLastError(), "trace_kernel launch") || !hip_ok(hipEventRecord(p->evT1[c], s), "event")) return PA_E_HIP;
             hipLaunchKernelGGL(format_pack_kernel, dim3((unsigned)cnt), dim3(64), 0, s, p->d_cigar.as<uint32_t>(), p->d_cig_src_off.as<uint64_t>(), p->d_cigar_len.as<uint32_t>(),
                                list, p->d_packed.as<uint8_t>() + p->chunk_base[c], d_total + c, p->d_tlen_pos.as<uint32_t>() + lo, p->d_dst_pos.as<uint64_t>() + lo);
@@ -2821,7 +2820,7 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
             std::vector<int32_t> c2(R, 0);
             std::vector<char*> g2(R, nullptr);
             const int rc2 = pa_batch_align(sub.get(), c2.data(), cigar_out ? g2.data() : nullptr, nullptr, nullptr);
-            if (rc2 != 0) return fail_all(rc2);
+            if (rc2 != 0) return fail_all(rc2);  // (pa_batch_align hands out no strings when it fails)
             for (size_t q = 0; q < R; ++q) {
                 const size_t i = redo[r0 + q];
                 costs[i] = c2[q];
@@ -3020,6 +3019,16 @@ extern "C" int pa_debug_gcsh_probe(const uint8_t* a, size_t a_len, const uint8_t
 // and the load rounds (64 layers each) they took.
 // phase_wave_ms[0..7) (PA_APA2_PROBE_STATS): wavefront-milliseconds (summed over all wavefronts; 100 MHz clock) spent deriving contours,
 // in the DP strips, in h probes, in Block::index, in prune_block, initialising block columns, and in total.
+#ifdef PA_TRACE_CLOCKS
+// Experiments (-DPA_TRACE_CLOCKS): the traceback kernels' clocks since the last call, then zeroed.
+extern "C" int pa_debug_trace_clocks(double* out10) {
+    unsigned long long v[10] = {0};
+    if (!hip_ok(hipDeviceSynchronize(), "sync") || !hip_ok(hipMemcpyFromSymbol(v, HIP_SYMBOL(pa::g_trace_clk), sizeof(v)), "trace clocks")) return PA_E_HIP;
+    for (int i = 0; i < 10; ++i) out10[i] = (double)v[i];
+    unsigned long long z[10] = {0};
+    return hip_ok(hipMemcpyToSymbol(HIP_SYMBOL(pa::g_trace_clk), z, sizeof(z)), "trace clocks") ? 0 : PA_E_HIP;
+}
+#endif
 extern "C" void pa_batch_full_info(const pa_batch* p, double* build_ms, double* matches, double* probes, double* rounds, double* phase_wave_ms) {
     if (build_ms) *build_ms = p ? p->full_build_ms : 0;
     if (matches) *matches = p ? (double)p->full_matches : 0;

@@ -132,6 +132,49 @@ __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t old_, uint32_t src) {
 
 __device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
+// A scalar value gets a live range of its own (see apa2_kernel.hpp, where the note on descriptors fetched by one wide scalar load is).
+template <class T>
+__device__ __forceinline__ T own_sgpr(T x) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "scalar or pointer");
+    asm volatile("" : "+s"(x));
+    return x;
+}
+
+// Wavefront sums, minima and prefix sums on the DPP data path: six dependent VALU instructions whose second operand comes from another
+// lane of the row (row_shr:1/2/4/8: a scan inside each row of 16), then from lane 15 of the row before (row_bcast:15 into rows 1 and 3)
+// and from lane 31 (row_bcast:31 into rows 2 and 3).  __shfl_xor / __shfl_up compile to ds_bpermute_b32 -- six dependent round trips
+// through the LDS crossbar (~0.7 us for one sum of a lone wavefront, measured in the traceback's DT levels).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int32_t dpp_or_zero(int32_t x) {  // lanes without a source lane (and rows outside ROW_MASK) read 0
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int32_t dpp_or_self(int32_t x) {  // ... read their own value
+    return __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int32_t wave_scan_add(int32_t x) {  // inclusive prefix sum over the 64 lanes
+    x += dpp_or_zero<0x111, 0xf>(x);
+    x += dpp_or_zero<0x112, 0xf>(x);
+    x += dpp_or_zero<0x114, 0xf>(x);
+    x += dpp_or_zero<0x118, 0xf>(x);
+    x += dpp_or_zero<0x142, 0xa>(x);
+    x += dpp_or_zero<0x143, 0xc>(x);
+    return x;
+}
+__device__ __forceinline__ int32_t wave_add(int32_t x) {  // sum over the 64 lanes, wavefront-uniform
+    return __builtin_amdgcn_readlane(wave_scan_add(x), 63);
+}
+__device__ __forceinline__ int32_t wave_min(int32_t x) {  // minimum over the 64 lanes, wavefront-uniform
+    int32_t y;
+    y = dpp_or_self<0x111, 0xf>(x); x = y < x ? y : x;
+    y = dpp_or_self<0x112, 0xf>(x); x = y < x ? y : x;
+    y = dpp_or_self<0x114, 0xf>(x); x = y < x ? y : x;
+    y = dpp_or_self<0x118, 0xf>(x); x = y < x ? y : x;
+    y = dpp_or_self<0x142, 0xa>(x); x = y < x ? y : x;
+    y = dpp_or_self<0x143, 0xc>(x); x = y < x ? y : x;
+    return __builtin_amdgcn_readlane(x, 63);
+}
+
 // Packed pipeline register X:  bit31 = h.p (delta +1), bit30 = h.m (delta -1), bits[1:0] = base code, rest 0.
 // One Myers step on a lane of K 32-row subwords (myers.rs:27-55 on a 32K-bit word; eq from profile.rs:141-144).
 // `acc` collects the lane's outgoing deltas delayed by one step: newest column in bits [1:0] = (p,m),
@@ -674,8 +717,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
                 c += __builtin_popcount(vp[k] & keep) - __builtin_popcount(vm[k] & keep);
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        c = wave_add(c);
         if (plane == 0) atomicAdd((int32_t*)job.vsum_out, c);
     }
     if (job.sum_out) {
@@ -694,8 +736,7 @@ __device__ __forceinline__ void run_strip(const StripJob& job, uint32_t* err, ui
                 c += __builtin_popcount(vp[k] & tm) - __builtin_popcount(vm[k] & tm);
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        c = wave_add(c);
         sum -= c;
         if (plane == 0) *(gi32)job.sum_out = sum;
     }

@@ -46,19 +46,10 @@ struct DeviceWave {
     static __device__ __forceinline__ uint32_t readlane(vec x, int i) { return (uint32_t)__builtin_amdgcn_readlane((int)x, i); }
     static __device__ __forceinline__ int32_t readlane_i(vec x, int i) { return __builtin_amdgcn_readlane((int)x, i); }
     static __device__ __forceinline__ uint32_t reduce_add(vec x) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x += (uint32_t)__shfl_xor((int)x, o, 64);
-        return rfl32(x);
+        return (uint32_t)wave_add((int32_t)x);
     }
     static __device__ __forceinline__ vec prefix_excl(vec x) {
-        const uint32_t l = threadIdx.x & 63u;
-        uint32_t incl = x;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = (uint32_t)__shfl_up((int)incl, o, 64);
-            incl += l >= (uint32_t)o ? y : 0u;
-        }
-        return incl - x;
+        return (uint32_t)wave_scan_add((int32_t)x) - x;
     }
 
     // ---- memory ----
@@ -144,7 +135,8 @@ struct DeviceWave {
     // lane l holds half (l & 1) of word word0 + l / 2: the even lane stores the word's p, the odd lane its m (8 bytes each,
     // write-through) = byte 8 * l of the strip's 512-byte column segment; inactive lanes store out of range (dropped)
     static __device__ __forceinline__ void store_v_halves(uint64_t* col, uint32_t word0, vec lane, mask act, vec sp, vec sm) {
-        const uint32_t p_other = (uint32_t)__shfl_xor((int)sp, 1, 64), m_other = (uint32_t)__shfl_xor((int)sm, 1, 64);
+        // the other lane of the pair: quad_perm:[1,0,3,2]
+        const uint32_t p_other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sp, 0xB1, 0xf, 0xf, true), m_other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sm, 0xB1, 0xf, 0xf, true);
         const bool odd = (lane & 1u) != 0;
         const u32x2 d = {odd ? m_other : sp, odd ? sm : p_other};
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(col + 2 * (int64_t)word0, 0, 512, 0x00020000);

@@ -53,11 +53,7 @@ enum : uint32_t { kTraceFailed = 0xFFFFFFFFu };
 constexpr int kTraceScratchWords = 128;
 enum : uint32_t { kOpMatch = 0, kOpSub = 1, kOpIns = 2, kOpDel = 3 };  // '=', 'X', 'I' (advances b), 'D' (advances a)
 
-__device__ __forceinline__ int32_t wave_sum(int32_t x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return (int32_t)rfl((uint32_t)x);
-}
+__device__ __forceinline__ int32_t wave_sum(int32_t x) { return wave_add(x); }
 
 // Sum of the vertical deltas of the first `rows` rows of a column stored as V words (u32 view, word 0 first); nullptr = V::one.
 __device__ __forceinline__ int32_t column_prefix(gcu32 col, int rows, int lane) {
@@ -116,17 +112,71 @@ constexpr int32_t kDtInf = 0x7FFFFFFF;
 // BANDED: the blocks are the banded blocks of the batched A*PA2 (TraceJob::rec) and TraceStats are counted; the full-height
 // checkpoints of the full-DP traced batch (pa_batch_create_trace) compile without either (round 4: with both in one instance the
 // full-DP traceback of C4 had gone from 12.2 to 16.6 ms).
+// The order the traceback's wavefronts start in: the most expensive pairs first.  A pair's traceback lasts about as long as its
+// alignment has edits (DT levels; beyond ~38 edits per block the re-fill and the parent walk on top): in C4 a pair at 15 % takes
+// 4.6 ms and a pair at 1 % 0.4 ms, the GPU holds half of the 10 000 wavefronts at a time, and in index order the kernel lasted as long
+// as TWO of the slow pairs (9.4 ms for 4.2 ms' worth of work per wavefront slot).  One workgroup sorts the launch's pairs by the cost
+// the forward pass found (a counting sort into 1024 buckets, descending); `out` is what trace_kernel walks, the text kernel keeps
+// the index order.  The order inside a bucket is whatever the atomics make it: it decides when a pair runs, never what comes out.
+__global__ __launch_bounds__(1024) void trace_order_kernel(const TraceJob* __restrict__ jobs, const int32_t* __restrict__ list, int cnt, int32_t* __restrict__ out,
+                                                           uint32_t max_cost) {
+    __shared__ uint32_t hist[1024], scan[1024];
+    const int tid = (int)threadIdx.x;
+    auto bucket = [&](int pair) -> uint32_t {
+        const TraceJob& t = jobs[pair];
+        int64_t c;
+        if (t.res) c = t.res->cost;
+        else c = t.n == 0 ? t.m : (t.m == 0 ? t.n : 64 * (int64_t)t.w + *t.sum);
+        c = c < 0 ? 0 : c;
+        const uint64_t b = (uint64_t)c * 1023u / (max_cost ? max_cost : 1u);
+        return 1023u - (uint32_t)(b > 1023u ? 1023u : b);
+    };
+    hist[tid] = 0;
+    __syncthreads();
+    for (int k = tid; k < cnt; k += 1024) atomicAdd(&hist[bucket(list[k])], 1u);
+    __syncthreads();
+    uint32_t v = hist[tid];
+    scan[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // inclusive scan over the buckets
+        const uint32_t t = tid >= o ? scan[tid - o] : 0u;
+        __syncthreads();
+        scan[tid] += t;
+        __syncthreads();
+    }
+    hist[tid] = scan[tid] - v;  // where the bucket starts
+    __syncthreads();
+    for (int k = tid; k < cnt; k += 1024) {
+        const int pair = list[k];
+        out[atomicAdd(&hist[bucket(pair)], 1u)] = pair;
+    }
+}
+
+// -DPA_TRACE_CLOCKS (experiments; tools/trace_clocks.py): where the wavefronts' time goes, summed over a launch (100 MHz ticks).
+#ifdef PA_TRACE_CLOCKS
+__device__ unsigned long long g_trace_clk[10];  // ticks: DT that succeeded, DT that failed, re-fills, parent steps, whole wavefront; counts: levels, steps, blocks
+#define PA_TCLK(...) __VA_ARGS__
+#else
+#define PA_TCLK(...)
+#endif
 template <bool DT, bool BANDED>
 // (wavefronts per SIMD asked of the register allocator, measured on C4: the DT variant 13.1 ms without the bound, 9.1 / 9.9 / 13.8 ms
 //  at 5 / 6 / 7; the re-fill variant 12.6 / 12.1 / 13.1 ms at 5 / 6 / 7)
 __global__ __launch_bounds__(64 * kStripBlockWaves, PA_TRACE_WAVES(DT, BANDED)) void trace_kernel(const TraceJob* __restrict__ jobs, const int32_t* __restrict__ list, int npairs, uint32_t* err) {
     // `list`: the pairs of this launch (a chunk of the batch: pa_batch_align runs the chunks on streams of their own, so that the
     // traceback of one overlaps the forward pass of the next and the copy-out of the one before)
-    const int slot_ = (int)rfl((uint32_t)(blockIdx.x * kStripBlockWaves + (threadIdx.x >> 6)));
+    const int slot_ = (int)rfl((uint32_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
     if (slot_ >= npairs) return;
     const int pair = (int)rfl((uint32_t)list[slot_]);
     const int lane = (int)(threadIdx.x & 63);
-    const TraceJob tj = jobs[pair];
+    TraceJob tj = jobs[pair];
+    // (every field gets a scalar live range of its own -- apa2_kernel.hpp own_sgpr: the descriptor arrives in one wide scalar load, and
+    //  a spilled tuple is reloaded whole for every later use of one field)
+#define PA_OWN(f) tj.f = own_sgpr(tj.f)
+    PA_OWN(a); PA_OWN(b); PA_OWN(a_codes); PA_OWN(b_prof); PA_OWN(ckpt); PA_OWN(final_v); PA_OWN(sum); PA_OWN(cigar); PA_OWN(cigar_len); PA_OWN(cost_out);
+    PA_OWN(scratch_v); PA_OWN(scratch_vals); PA_OWN(scratch_words); PA_OWN(scratch_gran); PA_OWN(n); PA_OWN(m); PA_OWN(w); PA_OWN(cigar_cap);
+    PA_OWN(dt_max_g); PA_OWN(dt_fr_drop); PA_OWN(rec); PA_OWN(res); PA_OWN(tstats); PA_OWN(win); PA_OWN(slot_ratio);
+#undef PA_OWN
     extern __shared__ unsigned char pa_trace_lds[];
     DtLds& L = *reinterpret_cast<DtLds*>(pa_trace_lds + (size_t)(threadIdx.x >> 6) * sizeof(DtLds));
     const gcu8 a = (gcu8)tj.a;
@@ -146,6 +196,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, PA_TRACE_WAVES(DT, BANDED)) 
     }
     if (lane == 0) *(gi32)tj.cost_out = g;
 
+    PA_TCLK(uint64_t ck_dt_ok = 0; uint64_t ck_dt_fail = 0; uint64_t ck_fill = 0; uint64_t ck_walk = 0; uint32_t ck_levels = 0; uint32_t ck_steps = 0; const uint64_t ck_begin = wall_clock64();)
     uint32_t len = 0, cur_op = 0, cur_cnt = 0;
     uint32_t n_dt_try = 0, n_dt_ok = 0, n_dt_fb = 0, n_fill_try = 0, n_fill_ok = 0, n_fill_fb = 0;  // TraceStats (trace.rs:3-14)
     auto emit = [&](uint32_t op, uint32_t cnt) {
@@ -213,6 +264,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, PA_TRACE_WAVES(DT, BANDED)) 
             if (i0 < to_i - 1) {
                 const int G = tj.dt_max_g, drop = tj.dt_fr_drop;
                 const int st_i = to_i, st_j = to_j, cols = st_i - i0;
+                PA_TCLK(const uint64_t ck_t0 = wall_clock64();)
                 const gcu32 ck = ckpt_col(i0);
                 const BlkMeta cm = blk_meta(i0 >> 8);
                 n_dt_try += 1;
@@ -224,24 +276,53 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, PA_TRACE_WAVES(DT, BANDED)) 
                     for (int k = lane; k < st_j - b_lo; k += 64) bwb[k] = b[b_lo + k];
                 }
                 __builtin_amdgcn_wave_barrier();
-                // extension to the left along matches (trace.rs:443-500), all lanes at once, four characters per round: the dword
-                // that ENDS at the current character (two aligned LDS words and a byte funnel shift), most significant byte first
+                // extension to the left along matches (trace.rs:443-500), all lanes at once, eight characters per round: the eight
+                // bytes that END at the current character (three aligned LDS words and two byte funnel shifts), most significant byte
+                // first.  (Four per round until round 4: a level lasts as long as its longest run, 6-8 rounds of ~0.1 us at 15 %.)
                 auto extend = [&](int& i, int& j, bool on) -> int {
                     int cnt = 0;
                     bool go = on && i > i0 && j > 0;
-                    while (__ballot(go) != 0) {
+                    for (;;) {
+                        const uint64_t gm = __ballot(go);
+                        if (gm == 0) break;
+                        if ((gm & (gm - 1)) == 0) {
+                            // one diagonal is still running (the alignment's own, as a rule): the whole wavefront extends it, 64 characters
+                            // per round, one per lane
+                            const int l = __builtin_ctzll(gm);
+                            int si = __builtin_amdgcn_readlane(i, l), sj = __builtin_amdgcn_readlane(j, l), total = 0;
+                            const uint8_t* ab = reinterpret_cast<const uint8_t*>(L.aw) + 8;
+                            const uint8_t* bb = reinterpret_cast<const uint8_t*>(L.bw) + 8;
+                            for (;;) {
+                                const int room = si - i0 < sj ? si - i0 : sj;
+                                if (room <= 0) break;
+                                const bool eq = lane < room && ab[si - 1 - lane - i0] == bb[sj - 1 - lane - b_lo];
+                                const uint64_t em = __ballot(eq);
+                                const int run = em == ~0ull ? 64 : __builtin_ctzll(~em);
+                                si -= run;
+                                sj -= run;
+                                total += run;
+                                if (run < 64) break;
+                            }
+                            if (lane == l) {
+                                i = si;
+                                j = sj;
+                                cnt += total;
+                            }
+                            break;
+                        }
                         if (go) {
-                            const int qa = i - 1 - i0 + 8 - 3, qb = j - 1 - b_lo + 8 - 3;  // byte offsets of the dwords (>= 5: headroom)
-                            const uint32_t va = __builtin_amdgcn_alignbyte(L.aw[(qa >> 2) + 1], L.aw[qa >> 2], (uint32_t)(qa & 3));
-                            const uint32_t vb = __builtin_amdgcn_alignbyte(L.bw[(qb >> 2) + 1], L.bw[qb >> 2], (uint32_t)(qb & 3));
-                            const uint32_t x = va ^ vb;
-                            int run = x ? (__builtin_clz(x) >> 3) : 4;
+                            const int qa = i - 1 - i0 + 8 - 7, qb = j - 1 - b_lo + 8 - 7;  // byte offsets of the eight bytes (>= 1: headroom)
+                            const uint32_t a0 = L.aw[qa >> 2], a1 = L.aw[(qa >> 2) + 1], a2 = L.aw[(qa >> 2) + 2];
+                            const uint32_t b0 = L.bw[qb >> 2], b1 = L.bw[(qb >> 2) + 1], b2 = L.bw[(qb >> 2) + 2];
+                            const uint32_t xh = __builtin_amdgcn_alignbyte(a2, a1, (uint32_t)(qa & 3)) ^ __builtin_amdgcn_alignbyte(b2, b1, (uint32_t)(qb & 3));
+                            const uint32_t xl = __builtin_amdgcn_alignbyte(a1, a0, (uint32_t)(qa & 3)) ^ __builtin_amdgcn_alignbyte(b1, b0, (uint32_t)(qb & 3));
+                            int run = xh ? (__builtin_clz(xh) >> 3) : (xl ? 4 + (__builtin_clz(xl) >> 3) : 8);
                             const int room = i - i0 < j ? i - i0 : j;
                             run = run < room ? run : room;
                             i -= run;
                             j -= run;
                             cnt += run;
-                            go = run == 4 && i > i0 && j > 0;
+                            go = run == 8 && i > i0 && j > 0;
                         }
                     }
                     return cnt;
@@ -282,40 +363,38 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, PA_TRACE_WAVES(DT, BANDED)) 
                     __builtin_amdgcn_wave_barrier();
                     const int ng = lvl + 1, nlo = d_lo - 1, nhi = d_hi + 1;
                     int32_t min_fr = kDtInf, min_i = kDtInf;
+                    int32_t fr_lane = kDtInf;  // this lane's diagonal (nlo + lane) of the level just computed, when it fits one round
+                    bool fr_mine = false;
                     for (int base = nlo; base <= nhi && found_g < 0; base += 64) {
                         const int e = base + lane;
                         const bool mine = e <= nhi;
-                        // expand (trace.rs:351-364): candidates in the host's order, strict `<`
+                        // expand (trace.rs:351-364): candidates in the host's order, strict `<` (the three LDS words are asked for together;
+                        // one outside the level's range is read and ignored)
                         int32_t bi = kDtInf, bpd = 0;
                         if (mine) {
-                            if (e - 1 >= d_lo && e - 1 <= d_hi) {
-                                const int32_t y = cur[e - 1 + G + 2];
-                                if (y < bi) {
-                                    bi = y;
-                                    bpd = -1;
-                                }
+                            const int32_t c0 = cur[e - 1 + G + 2], c1 = cur[e + G + 2], c2 = cur[e + 1 + G + 2];
+                            const bool v0 = e - 1 >= d_lo && e - 1 <= d_hi, v1 = e >= d_lo && e <= d_hi, v2 = e + 1 >= d_lo && e + 1 <= d_hi;
+                            if (v0 && c0 < bi) {
+                                bi = c0;
+                                bpd = -1;
                             }
-                            if (e >= d_lo && e <= d_hi) {
-                                const int32_t y = cur[e + G + 2] - 1;
-                                if (y < bi) {
-                                    bi = y;
-                                    bpd = 0;
-                                }
+                            if (v1 && c1 - 1 < bi) {
+                                bi = c1 - 1;
+                                bpd = 0;
                             }
-                            if (e + 1 >= d_lo && e + 1 <= d_hi) {
-                                const int32_t y = cur[e + 1 + G + 2] - 1;
-                                if (y < bi) {
-                                    bi = y;
-                                    bpd = 1;
-                                }
+                            if (v2 && c2 - 1 < bi) {
+                                bi = c2 - 1;
+                                bpd = 1;
                             }
                         }
                         // extend (trace.rs:370-385)
                         const bool reach = mine && bi < kDtInf - 4 * kDtMaxG;
                         int i = bi, j = reach ? st_j - (st_i - bi) - e : 0;
                         const int cnt = extend(i, j, reach);
+                        fr_lane = reach ? i : bi;
+                        fr_mine = mine;
                         if (mine) {
-                            nxt[e + G + 2] = reach ? i : bi;
+                            nxt[e + G + 2] = fr_lane;
                             L.tbl[ng * ng + ng + e] = (uint16_t)((reach ? cnt : 0) | ((bpd + 1) << 12));
                         }
                         // a diagonal at the checkpoint column with the right value ends the block: the lowest d first
@@ -323,7 +402,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, PA_TRACE_WAVES(DT, BANDED)) 
                         while (cand) {
                             const int l = __builtin_ctzll(cand);
                             cand &= cand - 1;
-                            const int jl = __shfl(j, l, 64);
+                            const int jl = __builtin_amdgcn_readlane(j, l);
                             if (value_at(jl) == g - ng) {
                                 found_g = ng;
                                 found_d = base + l;
@@ -346,28 +425,32 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, PA_TRACE_WAVES(DT, BANDED)) 
                     }
                     __builtin_amdgcn_wave_barrier();
                     if (lvl == G / 2) {  // trace.rs:388-391
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) {
-                            const int32_t a2 = __shfl_xor(min_i, o, 64);
-                            min_i = a2 < min_i ? a2 : min_i;
-                        }
+                        min_i = wave_min(min_i);
                         if (min_i > (i0 + st_i) / 2) dt_fail = true;
                     }
                     if (lvl == G) dt_fail = true;
-                    if (!dt_fail && drop > 0) {
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) {
-                            const int32_t a1 = __shfl_xor(min_fr, o, 64);
-                            min_fr = a1 < min_fr ? a1 : min_fr;
-                        }
-                    }
+                    if (!dt_fail && drop > 0) min_fr = wave_min(min_fr);
                     if (!dt_fail && drop > 0) {  // trace.rs:396-413
-                        auto bad = [&](int d) -> bool {
-                            const int32_t fi = cur[d + G + 2];
-                            return fi <= i0 || (int64_t)2 * fi - d > (int64_t)min_fr + drop;
-                        };
-                        while (d_lo < d_hi && bad(d_lo)) d_lo += 1;  // (uniform: every lane reads the same LDS words)
-                        while (d_lo < d_hi && bad(d_hi)) d_hi -= 1;
+                        if (d_hi - d_lo < 64) {
+                            // the level fitted one round: every lane judges its own diagonal and the two loops of the reference become the
+                            // first and the last set bit of one ballot (all bad: d_lo runs up to d_hi and the second loop never starts)
+                            const int d = d_lo + lane;
+                            const bool keep = fr_mine && !(fr_lane <= i0 || (int64_t)2 * fr_lane - d > (int64_t)min_fr + drop);
+                            const uint64_t km = __ballot(keep);
+                            if (km == 0) {
+                                d_lo = d_hi;
+                            } else {
+                                d_hi = d_lo + 63 - __builtin_clzll(km);
+                                d_lo = d_lo + __builtin_ctzll(km);
+                            }
+                        } else {
+                            auto bad = [&](int d) -> bool {
+                                const int32_t fi = cur[d + G + 2];
+                                return fi <= i0 || (int64_t)2 * fi - d > (int64_t)min_fr + drop;
+                            };
+                            while (d_lo < d_hi && bad(d_lo)) d_lo += 1;  // (uniform: every lane reads the same LDS words)
+                            while (d_lo < d_hi && bad(d_hi)) d_hi -= 1;
+                        }
                         if (d_lo > d_hi) dt_fail = true;
                     }
                 }
@@ -393,9 +476,11 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, PA_TRACE_WAVES(DT, BANDED)) 
                     to_i = i0;
                     to_j = st_j - cols - found_d;
                     n_dt_ok += 1;
+                    PA_TCLK(ck_dt_ok += wall_clock64() - ck_t0; ck_levels += (uint32_t)found_g;)
                     continue;
                 }
                 n_dt_fb += 1;
+                PA_TCLK(ck_dt_fail += wall_clock64() - ck_t0; ck_levels += (uint32_t)lvl;)
             }
         }
         // ---- re-fill when the walk has left the filled columns (trace.rs:83-125) ----
@@ -412,6 +497,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, PA_TRACE_WAVES(DT, BANDED)) 
             fcols = (banded ? slot_ptr((n + 255) >> 8) : (gcu32)tj.final_v) + (size_t)(lm.js >> 6) * 4;
         }
         if (!(f_i0 < to_i && to_i <= f_i1)) {
+            PA_TCLK(const uint64_t ck_t1 = wall_clock64();)
             fcols = (gcu32)vals;
             const int i0 = ((to_i - 1) >> 8) << 8;
             const int cols = to_i - i0;
@@ -489,8 +575,10 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, PA_TRACE_WAVES(DT, BANDED)) 
                 height *= 2;
             }
             if (failed) break;
+            PA_TCLK(ck_fill += wall_clock64() - ck_t1;)
         }
         // ---- parent (trace.rs:145-228) ----
+        PA_TCLK(ck_steps += 1;)
         // Every address a step may need depends only on `to`, so all loads are issued together (one memory round trip per
         // step instead of up to four dependent ones); the decisions below then follow the reference's order.
         const int r = to_j - 1;
@@ -613,6 +701,14 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, PA_TRACE_WAVES(DT, BANDED)) 
         if (g != 0) failed = true;  // "trace ends at distance 0"
     }
     if (lane == 0) *(gu32)tj.cigar_len = failed ? kTraceFailed : len;
+    PA_TCLK(if (lane == 0) {
+        atomicAdd(&g_trace_clk[0], (unsigned long long)ck_dt_ok); atomicAdd(&g_trace_clk[1], (unsigned long long)ck_dt_fail);
+        const uint64_t ck_all = wall_clock64() - ck_begin;
+        ck_walk = ck_all - ck_dt_ok - ck_dt_fail - ck_fill;  // parent steps and everything else
+        atomicAdd(&g_trace_clk[2], (unsigned long long)ck_fill); atomicAdd(&g_trace_clk[3], (unsigned long long)ck_walk);
+        atomicAdd(&g_trace_clk[4], (unsigned long long)ck_all); atomicAdd(&g_trace_clk[5], (unsigned long long)ck_levels);
+        atomicAdd(&g_trace_clk[6], (unsigned long long)ck_steps); atomicAdd(&g_trace_clk[7], (unsigned long long)(n_dt_try + n_fill_try));
+    })
     if (BANDED && tj.tstats && lane == 0) {
         gu32 ts = (gu32)tj.tstats;
         ts[0] = n_dt_try;

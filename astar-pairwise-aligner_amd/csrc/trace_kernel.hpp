@@ -246,6 +246,13 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, PA_TRACE_WAVES(DT, BANDED)) 
     auto filled_col = [&](int i) -> gcu32 { return fcols + (size_t)(i - f_i0 - 1) * (size_t)f_words * 4; };
 
     while (!failed && (to_i > 0 || to_j > 0)) {
+        // (the walk's state is wavefront-uniform; saying so once per step keeps it in scalar registers)
+        to_i = (int)rfl((uint32_t)to_i);
+        to_j = (int)rfl((uint32_t)to_j);
+        g = (int32_t)rfl((uint32_t)g);
+        len = rfl(len);
+        cur_op = rfl(cur_op);
+        cur_cnt = rfl(cur_cnt);
         if (to_i == 0) {  // first column: V::one all the way up (trace.rs parent on Block::first_col)
             emit(kOpIns, (uint32_t)to_j);
             g -= to_j;
@@ -360,6 +367,10 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, PA_TRACE_WAVES(DT, BANDED)) 
                 int32_t* cur = L.cur;  // furthest-reaching columns of level lvl / lvl + 1, swapped after every level
                 int32_t* nxt = L.nxt;
                 while (found_g < 0 && !dt_fail) {
+                    // (all of these are wavefront-uniform; saying so keeps the level's loops on the scalar unit)
+                    lvl = (int)rfl((uint32_t)lvl);
+                    d_lo = (int)rfl((uint32_t)d_lo);
+                    d_hi = (int)rfl((uint32_t)d_hi);
                     __builtin_amdgcn_wave_barrier();
                     const int ng = lvl + 1, nlo = d_lo - 1, nhi = d_hi + 1;
                     int32_t min_fr = kDtInf, min_i = kDtInf;
@@ -445,7 +456,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, PA_TRACE_WAVES(DT, BANDED)) 
                             }
                         } else {
                             auto bad = [&](int d) -> bool {
-                                const int32_t fi = cur[d + G + 2];
+                                const int32_t fi = (int32_t)rfl((uint32_t)cur[d + G + 2]);  // (uniform, and the compiler must know it: d_lo / d_hi steer every loop of the level)
                                 return fi <= i0 || (int64_t)2 * fi - d > (int64_t)min_fr + drop;
                             };
                             while (d_lo < d_hi && bad(d_lo)) d_lo += 1;  // (uniform: every lane reads the same LDS words)
@@ -456,20 +467,22 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, PA_TRACE_WAVES(DT, BANDED)) 
                 }
                 if (found_g >= 0) {
                     // walk back through the table (trace.rs:274-314); the elements go out from the END of the alignment
+                    // (every word read back from LDS is wavefront-uniform; readfirstlane says so, and the run-length state of `emit` stays scalar)
                     int dk = found_d;
                     for (int k = found_g; k >= 0; --k) {
                         if (lane == 0) L.chain[k] = dk;
-                        dk += (int)(L.tbl[k * k + k + dk] >> 12) - 1;
+                        dk += (int)(rfl((uint32_t)L.tbl[k * k + k + dk]) >> 12) - 1;
                     }
                     __builtin_amdgcn_wave_barrier();
+                    int d = (int)rfl((uint32_t)L.chain[0]);
                     for (int k = 0; k <= found_g; ++k) {
-                        const int d = L.chain[k];
-                        const uint32_t ext = L.tbl[k * k + k + d] & 0xFFFu;
+                        const uint32_t ext = rfl((uint32_t)L.tbl[k * k + k + d]) & 0xFFFu;
                         if (ext > 0) emit(kOpMatch, ext);
                         if (k < found_g) {
-                            const int dn = L.chain[k + 1];
-                            const int pd = (int)(L.tbl[(k + 1) * (k + 1) + (k + 1) + dn] >> 12) - 1;
+                            const int dn = (int)rfl((uint32_t)L.chain[k + 1]);
+                            const int pd = (int)(rfl((uint32_t)L.tbl[(k + 1) * (k + 1) + (k + 1) + dn]) >> 12) - 1;
                             emit(pd == -1 ? kOpIns : (pd == 0 ? kOpSub : kOpDel), 1);
+                            d = dn;
                         }
                     }
                     g -= found_g;

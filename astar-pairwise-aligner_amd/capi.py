@@ -20,7 +20,7 @@ EXPORTED_SYMBOLS = [
     "pa_last_error", "pa_device_count", "pa_set_device",
     "pa_bp_profile_build", "pa_bp_compute", "pa_bp_fill", "pa_search", "pa_search_trace",
     "pa_batch_create", "pa_batch_run", "pa_batch_stats", "pa_batch_shape", "pa_batch_destroy",
-    "pa_batch_create_banded", "pa_batch_create_trace", "pa_batch_align", "pa_batch_trace_fallbacks", "pa_params_batch_align",
+    "pa_batch_create_banded", "pa_batch_create_trace", "pa_batch_align", "pa_batch_align_view", "pa_batch_trace_fallbacks", "pa_params_batch_align",
     "pa_pairs_read", "pa_pairs_count", "pa_pairs_get", "pa_pairs_free", "pa_write_results_csv", "pa_align_file",
     "pa_align", "pa_batch_align_multi", "pa_batch_create_trace_params",
     "pa_bp_ctx_create", "pa_bp_ctx_compute", "pa_bp_ctx_fill", "pa_bp_ctx_destroy",
@@ -104,6 +104,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_batch_pair_stats.restype = C.c_int
     L.pa_batch_align.argtypes = [vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.pa_batch_align.restype = C.c_int
+    L.pa_batch_align_view.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.pa_batch_align_view.restype = C.c_int
     L.pa_batch_trace_fallbacks.argtypes = [vp]
     L.pa_batch_trace_fallbacks.restype = C.c_size_t
     L.pa_batch_window_retries.argtypes = [vp]
@@ -316,6 +318,11 @@ _str_from_c.restype = C.py_object
 _str_from_c.argtypes = [C.c_void_p]
 
 
+_str_from_c_n = C.pythonapi.PyUnicode_FromStringAndSize
+_str_from_c_n.restype = C.py_object
+_str_from_c_n.argtypes = [C.c_void_p, C.c_ssize_t]
+
+
 def _c_strings(ptrs, n: int) -> list[str]:
     """The NUL-terminated strings a C call left in the pointer array `ptrs` (NULL -> "")."""
     return [_str_from_c(p) if p else "" for p in list(ptrs)[:n]]
@@ -452,7 +459,30 @@ class Batch:
 
     def align(self):
         """-> (costs int32[pairs], CIGAR strings, forward-kernel ms, traceback-kernel ms); needs trace=True.
-        `self.last_c_abi_ms` = wall time of the pa_batch_align call itself (before Python turns the C strings into str)."""
+        `self.last_c_abi_ms` = wall time of the C call itself (before Python turns the texts into str).  The call is pa_batch_align_view:
+        the texts stay in the plan's host buffer and become str objects straight from there (pa_batch_align would malloc one C string per
+        pair first, for Python to copy and free again)."""
+        import time
+
+        L = load()
+        n = self.pairs
+        out = np.zeros(n, np.int32)
+        txt = (C.c_void_p * max(n, 1))()
+        lens = np.zeros(max(n, 1), np.uint32)
+        fms, tms = C.c_float(0), C.c_float(0)
+        t0 = time.perf_counter()
+        rc = L.pa_batch_align_view(self._h, _p(out), txt, _p(lens), C.byref(fms), C.byref(tms))
+        self.last_c_abi_ms = (time.perf_counter() - t0) * 1e3
+        if rc == -1:
+            raise ValueError("sequence contains a character outside ACGT")
+        if rc != 0:
+            raise PaError(f"pa_batch_align_view rc={rc}: {last_error()}")
+        cigars = [_str_from_c_n(p, l) if p else "" for p, l in zip(list(txt)[:n], lens[:n].tolist())]
+        return out, cigars, float(fms.value), float(tms.value)
+
+    def align_c_strings(self):
+        """The same through pa_batch_align (one malloc'ed NUL-terminated string per pair, released with pa_free_cigars): the entry point a C
+        caller of the reference's style uses.  -> (costs, CIGAR strings, forward-kernel ms, traceback-kernel ms)."""
         import time
 
         L = load()

@@ -1279,6 +1279,16 @@ struct pa_batch {
     hipEvent_t ev2 = nullptr;
     uint8_t* h_text = nullptr;  // pinned host buffer for the packed CIGAR text of one chunk
     size_t h_text_size = 0;
+    // pa_batch_align_view: the texts stay in h_text (one chunk) and the caller gets pointers + lengths; strings that come from elsewhere
+    // (the host engine, the second round, the small-batch route, several chunks) are malloc'ed as usual and owned by the plan
+    bool view_mode = false;
+    std::vector<uint32_t> view_len;
+    std::vector<char*> view_owned;
+    bool in_text(const char* q) const { return h_text && (const uint8_t*)q >= h_text && (const uint8_t*)q < h_text + h_text_size; }
+    void free_view_owned() {
+        for (char* q : view_owned) std::free(q);
+        view_owned.clear();
+    }
     // pa_batch_align can work in CHUNKS of the (heaviest-first) order, each on a stream of its own: forward pass (batched A*PA2),
     // traceback, CIGAR text and its copy-out of different chunks overlap (one chunk by default: see the chunk plan in batch_create)
     static constexpr int kMaxChunks = 8;
@@ -1337,6 +1347,7 @@ struct pa_batch {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (ev2) (void)hipEventDestroy(ev2);
+        free_view_owned();
         pinned_give(h_text, h_text_size);
         pinned_give(h_meta, h_meta_size);
         if (ev_pre) (void)hipEventDestroy(ev_pre);
@@ -1674,6 +1685,15 @@ static void parallel_pairs(size_t P, F&& f) {
 static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t* const* b, std::vector<TraceJob>& tjobs) {
     const engine::AstarPa2Params ap = engine::params_from_c(p->aparams_c);
     const size_t P = p->pairs;
+    static const bool cprof = getenv("PA_ALIGN_PROFILE") != nullptr;  // diagnostics: where the creation time goes
+    auto cnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double c_mark = cnow();
+    auto cmark = [&](const char* what) {
+        if (!cprof) return;
+        const double t = cnow();
+        std::fprintf(stderr, "[pa_batch_create]   full: %-22s %8.3f ms\n", what, t - c_mark);
+        c_mark = t;
+    };
     p->sp.heur = ap.heuristic == engine::HeuristicKind::Gap ? sweep::kHeurGap : (ap.heuristic == engine::HeuristicKind::SH ? sweep::kHeurSH : sweep::kHeurNone);
     p->sp.sparse_h = ap.sparse_h ? 1 : 0;
     p->sp.doubling = ap.doubling == engine::DoublingKind::LinearSearch ? apa2::kDoublingLinear : apa2::kDoublingBand;
@@ -1752,6 +1772,7 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
     p->full_matches = tm;
     p->full_seeds = tseeds;
     p->full_build_ms = p->device_build ? 0.0 : std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    cmark("host tables / sizes");
     if (!p->d_rec.alloc(std::max<size_t>(tr, 1) * sizeof(sweep::BlockRec)) || !p->d_jh.alloc(std::max<size_t>(tr, 1) * 4) ||
         !p->d_results.alloc(std::max<size_t>(P, 1) * sizeof(apa2::PairResult)) || !p->d_fjobs.alloc(std::max<size_t>(P, 1) * sizeof(apa2::FullJob)) ||
         !p->d_order.alloc(std::max<size_t>(P, 1) * 4) || !p->d_tstats.alloc(std::max<size_t>(P, 1) * 32) || !p->d_sh.alloc(std::max<size_t>(tsh, 1) * 4) ||
@@ -1761,8 +1782,9 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
         !p->d_lrec.alloc((tm + 2 * std::max<size_t>(P, 1)) * sizeof(apa2::GcshCell)) || !p->d_cell.alloc(std::max<size_t>(tm, 1) * sizeof(apa2::GcshCell)) ||
         !p->d_probe.alloc(128))
         return false;
+    cmark("device buffers");
     if (tsh && !hip_ok(hipMemcpy(p->d_sh.ptr, shv.data(), tsh * 4, hipMemcpyHostToDevice), "H2D sh")) return false;
-    if (tm) {
+    if (tm && !p->device_build) {  // (the GPU's builder writes d_mi / d_mj itself: nothing to upload -- until round 4 this sent 2 x 4 tm bytes of zeros)
         std::vector<int32_t> mi(tm), mj(tm);
         for (size_t i = 0; i < P; ++i) {
             std::copy(pmi[i].begin(), pmi[i].end(), mi.begin() + (long)match_off[i]);
@@ -1781,6 +1803,7 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
         if (!p->d_bscratch.alloc(bytes) || !p->d_bjobs.alloc(std::max<size_t>(P, 1) * sizeof(apa2::GcshBuildJob)) || !p->d_bstatus.alloc(std::max<size_t>(P, 1) * 4) ||
             !p->d_bticket.alloc(64) || !hip_ok(hipEventCreate(&p->evB0), "event") || !hip_ok(hipEventCreate(&p->evB1), "event"))
             return false;
+        cmark("  build: buffers");
         int32_t* w32 = p->d_bscratch.as<int32_t>();
         uint8_t* w8 = (uint8_t*)(w32 + words);
         size_t o32 = 0, o8 = 0;
@@ -1825,8 +1848,11 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
             x.tsize = (int32_t)tsz[i];
             x.cap = (int32_t)cap[i];
         }
+        cmark("  build: descriptors");
         if (P && !hip_ok(hipMemcpy(p->d_bjobs.ptr, bj.data(), P * sizeof(apa2::GcshBuildJob), hipMemcpyHostToDevice), "H2D build jobs")) return false;
+        cmark("  build: H2D");
     }
+    cmark("build scratch + jobs");
     const bool launch_build = p->device_build && P;
     std::vector<apa2::FullJob> fj(P);
     std::vector<int32_t> order(P);
@@ -1880,6 +1906,7 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
     if (P && (!hip_ok(hipMemcpy(p->d_fjobs.ptr, fj.data(), P * sizeof(apa2::FullJob), hipMemcpyHostToDevice), "H2D pair jobs") ||
               !hip_ok(hipMemcpy(p->d_order.ptr, order.data(), P * 4, hipMemcpyHostToDevice), "H2D order")))
         return false;
+    cmark("pair jobs + order");
     if (launch_build) {
         // The matches of GCSH are part of the batch like the sequences they are derived from: found here, once, by the GPU (one wavefront
         // per pair, 16 KB of LDS each: eight to a CU), on the batch's stream -- the first alignment call queues behind it.
@@ -2599,7 +2626,7 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
     auto fail_all = [&](int code) {
         if (cigar_out)
             for (size_t k = 0; k < P; ++k) {
-                std::free(cigar_out[k]);
+                if (!(p->view_mode && p->in_text(cigar_out[k]))) std::free(cigar_out[k]);
                 cigar_out[k] = nullptr;
             }
         return code;
@@ -2677,6 +2704,11 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
         auto make = [&](size_t q) {
             const size_t i = (size_t)p->torder_host[q];
             if (h_tlen[q] == kTextFailed) return;
+            if (p->view_mode && C == 1) {  // pa_batch_align_view: the text stays where the copy from the GPU put it
+                cigar_out[i] = (char*)(p->h_text + h_dst[q]);
+                p->view_len[i] = h_tlen[q];
+                return;
+            }
             char* out = (char*)std::malloc((size_t)h_tlen[q] + 1);
             if (!out) {
                 oom = true;
@@ -2828,7 +2860,7 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
                 results[i].status = apa2::kOk;
                 if (q < sub->pair_stats.size()) p->pair_stats[i] = sub->pair_stats[q];
                 if (cigar_out) {
-                    std::free(cigar_out[i]);
+                    if (!(p->view_mode && p->in_text(cigar_out[i]))) std::free(cigar_out[i]);
                     cigar_out[i] = g2[q];
                 }
             }
@@ -2881,7 +2913,7 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
             return fail_all(PA_E_INTERNAL);
         }
         if (!cigar_out) continue;
-        std::free(cigar_out[i]);
+        if (!(p->view_mode && p->in_text(cigar_out[i]))) std::free(cigar_out[i]);
         cigar_out[i] = (char*)std::malloc(text.size() + 1);
         if (!cigar_out[i]) {
             set_error("out of memory");
@@ -3048,6 +3080,35 @@ extern "C" void pa_batch_full_info(const pa_batch* p, double* build_ms, double* 
     if (rounds) *rounds = (double)pr[1];
     if (phase_wave_ms)
         for (int t = 0; t < 7; ++t) phase_wave_ms[t] = (double)pr[2 + t] * 1e-5;
+}
+
+// pa_batch_align without the per-pair strings: text_out[i] points at text_len_out[i] characters of pair i's CIGAR (NOT NUL-terminated)
+// inside memory the plan owns -- valid until the next alignment call on this plan or its destruction, nothing to free.  For callers that
+// copy the text somewhere of their own anyway (a language binding building its string objects, a writer of the pa-bin CSV): 10 000
+// malloc + copy + free less per C4 batch.
+extern "C" int pa_batch_align_view(pa_batch* p, int32_t* cost_out, const char** text_out, uint32_t* text_len_out, float* forward_ms, float* trace_ms) {
+    if (!p || !text_out || !text_len_out) {
+        set_error("pa_batch_align_view: plan, text_out and text_len_out must not be NULL");
+        return PA_E_ARG;
+    }
+    p->free_view_owned();
+    p->view_len.assign(p->pairs, 0);
+    p->view_mode = true;
+    const int rc = pa_batch_align(p, cost_out, const_cast<char**>(text_out), forward_ms, trace_ms);
+    p->view_mode = false;
+    if (rc != 0) return rc;
+    for (size_t i = 0; i < p->pairs; ++i) {
+        const char* q = text_out[i];
+        if (!q) {
+            text_len_out[i] = 0;
+        } else if (p->in_text(q)) {
+            text_len_out[i] = p->view_len[i];
+        } else {  // a string of its own (host engine, second round, ...): the plan keeps it until the next call
+            text_len_out[i] = (uint32_t)std::strlen(q);
+            p->view_owned.push_back(const_cast<char*>(q));
+        }
+    }
+    return 0;
 }
 
 extern "C" size_t pa_batch_trace_fallbacks(const pa_batch* p) { return p ? p->trace_fallbacks : 0; }

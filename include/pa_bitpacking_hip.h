@@ -135,6 +135,10 @@ struct pa_astarpa2_params;
 pa_batch* pa_batch_create_trace_params(const uint8_t* const* a, const size_t* a_len, const uint8_t* const* b, const size_t* b_len,
                                        size_t pairs, const struct pa_astarpa2_params* trace_params);
 int pa_batch_align(pa_batch* plan, int32_t* cost_out, char** cigar_out, float* forward_ms, float* trace_ms);
+/* pa_batch_align without one malloc'ed string per pair: text_out[i] points at text_len_out[i] characters of pair i's CIGAR -- NOT
+ * NUL-terminated -- in host memory the plan owns, valid until the next alignment call on this plan or pa_batch_destroy; nothing to free.
+ * For callers that copy the text into objects of their own anyway (a language binding, the writer of pa-bin's CSV). */
+int pa_batch_align_view(pa_batch* plan, int32_t* cost_out, const char** text_out, uint32_t* text_len_out, float* forward_ms, float* trace_ms);
 /* Releases cigars[0 .. n) of a batch result in one call (entries may be NULL; they are set to NULL). */
 void pa_free_cigars(char** cigars, size_t n);
 /* Pairs (summed over all pa_batch_align calls of this plan) whose traceback was redone by the host engine. */

@@ -197,3 +197,45 @@ def test_allocation_cache_reuses_large_buffers_and_leaks_nothing_into_results(pa
         assert (int(c), g) == oracle.cpu_align(a, b, prm)[:2]
     capi.release_pools()
     assert capi.alloc_cache_stats()["cached_bytes"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"PA_ALIGN_CHUNKS": "3"}, {"PA_TRACE_ORDER": "0"}, {"PA_ALIGN_CHUNKS": "4", "PA_TRACE_ORDER": "0"}])
+def test_chunks_and_trace_order_do_not_change_results(env):
+    """pa_batch_align runs ONE chunk by default and starts the traceback's most expensive pairs first (trace_order_kernel).  The
+    other shapes -- several chunks on streams of their own (PA_ALIGN_CHUNKS), the traceback in index order (PA_TRACE_ORDER=0) -- must give
+    the same cost, CIGAR string and statistics: both families, 300 pairs of mixed length and divergence, against the CPU-kernel engine."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import oracle
+        import astar_pairwise_aligner_amd as pa
+        from tests.test_gpu_engine import gpu_params
+        from tests.test_sweep_emu import KEYS
+        from tests.util_seq import gen_pair
+        pairs = [gen_pair(400 + 37 * (i %% 50), (0.01, 0.05, 0.10, 0.15, 0.25)[i %% 5], 9000 + i) for i in range(300)]
+        for oc in (oracle.params_simple(), oracle.params_full()):
+            b = pa.Batch(pairs, params=gpu_params(pa, oc))
+            for rep in range(2):
+                costs, cigars, _, _ = b.align()
+                st = b.pair_stats()
+                for i, (x, y) in enumerate(pairs):
+                    w = oracle.cpu_align(x, y, oc)
+                    assert (int(costs[i]), cigars[i]) == w[:2] and all(st[i][k] == w[2][k] for k in KEYS), (i, rep)
+            assert b.trace_fallbacks() == 0
+            b.close()
+        full = pa.Batch(pairs, trace=True)  # the full-DP traced batch shares the traceback kernel and the chunks
+        costs, cigars, _, _ = full.align()
+        nw = oracle.make_params(domain="full", heuristic="none", doubling="none", block_width=256, sparse=True, incremental_doubling=False, dt_trace=False)
+        for i, (x, y) in enumerate(pairs[:60]):
+            w = oracle.cpu_align(x, y, nw)
+            assert (int(costs[i]), cigars[i]) == w[:2], i
+        print("ok")
+    """) % str(__import__("pathlib").Path(__file__).resolve().parent.parent)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

@@ -263,3 +263,41 @@ def test_trace_params_are_validated(pa, oracle):
     dense = gpu_params(pa, oracle.make_params(domain="full", heuristic="none", doubling="none", block_width=256, sparse=False))
     with pytest.raises(pa.PaError):
         pa.Batch(pairs, trace=True, trace_params=dense)
+
+
+@pytest.mark.gpu
+def test_view_and_c_string_entry_points_agree(pa, oracle):
+    """pa_batch_align_view (texts left in the plan's host buffer: what Batch.align() calls) and pa_batch_align (one malloc'ed C string per
+    pair: Batch.align_c_strings()) return the same costs and CIGARs -- full-DP traced batch, both A*PA2 families, a batch small enough for
+    the host-driven route, and one whose repeat-rich pair goes to the host engine (a string of its own inside the view)."""
+    from tests.test_gpu_engine import gpu_params
+    from tests.util_seq import gen_pair, rand_seq
+
+    pairs = [gen_pair(300 + 53 * (i % 40), (0.02, 0.08, 0.2)[i % 3], 7000 + i) for i in range(150)]
+    unit = rand_seq(7, seed=3)
+    a = (unit * 600)[:3000]
+    b = bytearray(a)
+    for q in (100, 900, 1700, 2500):
+        b[q] = ord("A") if b[q] != ord("A") else ord("C")
+    with_repeat = pairs[:80] + [(a, bytes(b[:1200] + b[1230:]))] + pairs[80:]
+    batches = [
+        pa.Batch(pairs, trace=True),
+        pa.Batch(pairs, params=gpu_params(pa, oracle.params_simple())),
+        pa.Batch(with_repeat, params=gpu_params(pa, oracle.params_full())),
+        pa.Batch(pairs[:3], params=gpu_params(pa, oracle.params_full())),
+    ]
+    for bt in batches:
+        for rep in range(2):
+            c1, g1, _, _ = bt.align()
+            c2, g2, _, _ = bt.align_c_strings()
+            c3, g3, _, _ = bt.align()
+            assert list(c1) == list(c2) == list(c3)
+            assert g1 == g2 == g3
+            assert all(isinstance(x, str) and x for x in g1)
+        bt.close()
+    full = oracle.params_full()
+    want = oracle.cpu_align(*with_repeat[80], full)
+    bt = pa.Batch(with_repeat, params=gpu_params(pa, full))
+    costs, cigars, _, _ = bt.align()
+    assert (int(costs[80]), cigars[80]) == want[:2] and bt.trace_fallbacks() >= 1
+    bt.close()

@@ -468,10 +468,14 @@ def main():
                 dt = time.perf_counter() - t
                 if dt < best[0]:
                     best = (dt, f_ms, t_ms, ba.last_c_abi_ms)
-            t = time.perf_counter()
-            cs2, gs2, _, _ = ba.align_c_strings()  # the reference-style entry point: one malloc'ed C string per pair (pa_batch_align)
-            t_strings = (time.perf_counter() - t, ba.last_c_abi_ms)
-            assert list(cs2) == list(cs) and gs2 == gs
+            t_strings = (1e9, 1e9)
+            for _ in range(2):  # the reference-style entry point: one malloc'ed C string per pair (pa_batch_align)
+                t = time.perf_counter()
+                cs2, gs2, _, _ = ba.align_c_strings()
+                dt = time.perf_counter() - t
+                if ba.last_c_abi_ms < t_strings[1]:
+                    t_strings = (dt, ba.last_c_abi_ms)
+                assert list(cs2) == list(cs) and gs2 == gs
             sts = ba.pair_stats()
             for i in sample:  # plumbing check on a sample (the parity tests compare every pair)
                 wc, wg, ws = _orc.cpu_align(*ps[i], oprm)
@@ -483,7 +487,7 @@ def main():
                 "ms": round(best[0] * 1e3, 3),
                 "c_abi_ms": round(best[3], 3),                 # pa_batch_align_view: texts left in the plan's host buffer (what the Python layer calls)
                 "c_abi_pairs_per_sec": round(len(ps) / (best[3] * 1e-3), 1),
-                "c_abi_strings_ms": round(t_strings[1], 3),     # pa_batch_align: one malloc'ed NUL-terminated string per pair (one call, not best of 3)
+                "c_abi_strings_ms": round(t_strings[1], 3),     # pa_batch_align: one malloc'ed NUL-terminated string per pair (best of 2)
                 "c_abi_strings_pairs_per_sec": round(len(ps) / (t_strings[1] * 1e-3), 1),
                 "forward_kernel_ms": round(best[1], 3),
                 "trace_kernel_ms": round(best[2], 3),

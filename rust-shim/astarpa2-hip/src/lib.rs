@@ -79,6 +79,9 @@ extern "C" {
                                         trace_params: *const PaAstarPa2Params) -> *mut core::ffi::c_void;
     pub fn pa_batch_align(plan: *mut core::ffi::c_void, cost_out: *mut i32, cigar_out: *mut *mut c_char, forward_ms: *mut f32,
                           trace_ms: *mut f32) -> i32;
+    // ... without one malloc'ed string per pair: text_out[i] .. + text_len_out[i] (no NUL) inside the plan, valid until the next call / destroy
+    pub fn pa_batch_align_view(plan: *mut core::ffi::c_void, cost_out: *mut i32, text_out: *mut *const c_char, text_len_out: *mut u32,
+                               forward_ms: *mut f32, trace_ms: *mut f32) -> i32;
     pub fn pa_batch_destroy(plan: *mut core::ffi::c_void);
     pub fn pa_batch_align_multi(a: *const *const u8, a_len: *const usize, b: *const *const u8, b_len: *const usize, pairs: usize,
                                 devices: *const i32, ndevices: i32, cost_out: *mut i32, cigar_out: *mut *mut c_char) -> i32;
@@ -167,7 +170,7 @@ impl HipAstarPa2 {
 
 impl HipAstarPa2 {
     /// The loop of pa-bin (`for (a, b) in pairs { aligner.align(a, b) }`, pa-bin/src/main.rs:24-35) as ONE call: every pair's band
-    /// search runs on the GPU side by side (`pa_batch_create_params` + `pa_batch_align`); parameters outside the `simple` family
+    /// search runs on the GPU side by side (`pa_batch_create_params` + `pa_batch_align_view`); parameters outside the batched family
     /// (and `trace == false`) fall back to the loop.
     pub fn align_many(&mut self, pairs: &[(Seq, Seq)]) -> Vec<(Cost, Option<Cigar>, PaAstarPa2Stats)> {
         let n = pairs.len();
@@ -180,21 +183,24 @@ impl HipAstarPa2 {
             return pairs.iter().map(|(a, b)| self.align_with_stats(a, b)).collect();
         }
         let mut costs = vec![0i32; n];
-        let mut ptrs: Vec<*mut c_char> = vec![std::ptr::null_mut(); n];
+        let mut ptrs: Vec<*const c_char> = vec![std::ptr::null(); n];
+        let mut lens = vec![0u32; n];
         let mut stats = vec![PaAstarPa2Stats::default(); n];
-        let rc = unsafe { pa_batch_align(plan, costs.as_mut_ptr(), ptrs.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut()) };
+        // the texts stay in the plan's host buffer (pa_batch_align_view): parsed into `Cigar`s before the plan goes
+        let rc = unsafe { pa_batch_align_view(plan, costs.as_mut_ptr(), ptrs.as_mut_ptr(), lens.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut()) };
         let rc2 = if rc == 0 { unsafe { pa_batch_pair_stats(plan, stats.as_mut_ptr()) } } else { rc };
-        unsafe { pa_batch_destroy(plan) };
         if rc2 != 0 {
-            panic!("pa_batch_align failed ({}): {}", rc2, unsafe { std::ffi::CStr::from_ptr(pa_last_error()) }.to_string_lossy());
+            unsafe { pa_batch_destroy(plan) };
+            panic!("pa_batch_align_view failed ({}): {}", rc2, unsafe { std::ffi::CStr::from_ptr(pa_last_error()) }.to_string_lossy());
         }
-        (0..n)
+        let out = (0..n)
             .map(|i| {
-                let s = unsafe { std::ffi::CStr::from_ptr(ptrs[i]) }.to_str().unwrap().to_owned();
-                unsafe { astarpa_free_cigar(ptrs[i] as *mut u8) };
-                (costs[i], Some(parse_cigar(&s)), stats[i])
+                let bytes: &[u8] = if ptrs[i].is_null() { &[] } else { unsafe { std::slice::from_raw_parts(ptrs[i] as *const u8, lens[i] as usize) } };
+                (costs[i], Some(parse_cigar(std::str::from_utf8(bytes).unwrap())), stats[i])
             })
-            .collect()
+            .collect();
+        unsafe { pa_batch_destroy(plan) };
+        out
     }
 }
 

@@ -301,3 +301,25 @@ def test_view_and_c_string_entry_points_agree(pa, oracle):
     costs, cigars, _, _ = bt.align()
     assert (int(costs[80]), cigars[80]) == want[:2] and bt.trace_fallbacks() >= 1
     bt.close()
+
+
+@pytest.mark.gpu
+def test_c_batch_view_program(tmp_path):
+    """tests/c_abi/batch_view_check.c: pa_batch_align_view from plain C beside pa_batch_align and pa_align, both presets."""
+    import os
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    libdir = root / "astar-pairwise-aligner_amd"
+    gcc = shutil.which("gcc") or shutil.which("cc")
+    if gcc is None or not (libdir / "libastarpa_c_hip.so").exists():
+        pytest.skip("no C compiler or library")
+    exe = tmp_path / "batch_view_check"
+    subprocess.run([gcc, str(root / "tests" / "c_abi" / "batch_view_check.c"), "-I", str(root / "include"), "-L", str(libdir),
+                    "-lastarpa_c_hip", "-Wl,-rpath," + str(libdir), "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, LD_LIBRARY_PATH=str(libdir) + ":" + os.environ.get("LD_LIBRARY_PATH", "")))
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("batch_view_check ok pairs=48 chars=")

@@ -2718,7 +2718,7 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
             out[h_tlen[q]] = 0;
             cigar_out[i] = out;
         };
-        if (total >= (size_t(8) << 20) && cnt >= 64 && host_threads() > 1) {
+        if (total >= (size_t(8) << 20) && cnt >= 64 && host_threads() > 1 && !(p->view_mode && C == 1)) {  // (a view copies nothing)
             const unsigned nt = std::min<unsigned>(host_threads(), 8);
             std::vector<std::thread> th;
             for (unsigned t = 0; t < nt; ++t)

@@ -92,3 +92,21 @@ def test_c_layout_program_compiles():
         pytest.skip("no C compiler")
     for prog in ("layout_check.c", "link_check.c", "ctx_check.c", "batch_view_check.c"):
         subprocess.run([gcc, "-fsyntax-only", "-Wall", "-I", str(ROOT / "include"), str(ROOT / "tests" / "c_abi" / prog)], check=True)
+
+
+def test_text_helpers_of_the_binding():
+    """The two ways the Python layer turns the library's CIGAR texts into str: NUL-terminated strings behind an array of pointers
+    (pa_batch_align; NULL -> "") and pointer + length pairs without a terminator (pa_batch_align_view)."""
+    import ctypes as C
+
+    from astar_pairwise_aligner_amd import capi
+
+    texts = [b"12=X3I=", b"", b"=" * 5000, b"4=2D1X"]
+    bufs = [C.create_string_buffer(t) for t in texts]
+    ptrs = (C.c_void_p * 6)(*[C.addressof(b) for b in bufs], None, None)
+    assert capi._c_strings(ptrs, 5) == [t.decode() for t in texts] + [""]
+    packed = C.create_string_buffer(b"".join(texts), sum(len(t) for t in texts) + 1)  # back to back, no terminators in between
+    off = 0
+    for t in texts:
+        assert capi._str_from_c_n(C.addressof(packed) + off, len(t)) == t.decode()
+        off += len(t)

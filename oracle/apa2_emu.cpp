@@ -99,6 +99,15 @@ struct EmuBackend {
 
 }  // namespace
 
+// The band-proportional slots of the batch kernels' column store (csrc/sweep_logic.hpp SlotGeom): the addressing the GPU kernels and the
+// host share, exposed for tests/test_host_logic_slots.py.
+extern "C" int32_t pa_emu_slot_off(int32_t n, int32_t m, int32_t win, uint32_t ratio, int32_t k) {
+    return pa::sweep::slot_off(pa::sweep::SlotGeom{n, m, win, ratio}, k);
+}
+extern "C" int pa_emu_slot_holds(int32_t n, int32_t m, int32_t win, uint32_t ratio, int32_t k, int32_t w0, int32_t w1) {
+    return pa::sweep::slot_holds(pa::sweep::SlotGeom{n, m, win, ratio}, k, w0, w1) ? 1 : 0;
+}
+
 // rc 0 = ran; 1 = parameters not supported by the batched program; 2 = the program handed the pair back (info[0] = status).
 // info[1] = scans run, info[2] = scans whose jumping probes did NOT end on the first / last row with f <= f_max.
 extern "C" int pa_apa2_emu_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params* params,

@@ -322,3 +322,28 @@ def test_pairs_the_match_builder_refuses_go_to_the_host_engine(pa, oracle):
         w = oracle.cpu_align(x, y, oc)
         assert (int(costs[i]), cigars[i]) == w[:2], i
         assert {k: stats[i][k] for k in KEYS} == {k: w[2][k] for k in KEYS}, i
+
+
+@pytest.mark.parametrize("preset", ["simple", "full"])
+def test_reference_harness_as_one_batch(pa, oracle, preset):
+    """pa-test's `test_aligner` (pa-test/src/lib.rs:7-40; astarpa2/src/tests.rs runs it per configuration) as ONE batch per preset: the 8
+    literal pairs, the whole length x error-rate grid (fixed seeds; the reference samples a random quarter per run) and the structural
+    error models (a long insertion, a long deletion, a repeated block).  The reference's acceptance rules -- the cost is the plain
+    Levenshtein distance, the CIGAR is the engine's -- for every pair: cost, CIGAR string and statistics against the CPU-kernel engine."""
+    from tests.util_seq import PA_TEST_ES, PA_TEST_NS, mutate
+
+    pairs = list(PA_TEST_PAIRS)
+    for n in PA_TEST_NS:
+        for e in PA_TEST_ES:
+            pairs.append(gen_pair(n, e, seed=31415 + n * 7 + int(e * 1000)))
+    for seed in range(6):
+        base = rand_seq(700, seed=seed)
+        ins = base[:300] + rand_seq(150, seed=100 + seed) + base[300:]
+        dele = base[:200] + base[420:]
+        rep = base[:350] + base[250:350] * 2 + base[350:]
+        pairs += [(base, mutate(ins, 0.03, seed)), (base, mutate(dele, 0.03, seed)), (base, mutate(rep, 0.05, seed)), (ins, base), (rep, dele)]
+    oc = oracle.params_full() if preset == "full" else oracle.params_simple()
+    costs, cigars, _, _ = check(pa, oracle, pairs, oc)
+    for (a, b), c in zip(pairs, costs):
+        assert c == oracle.levenshtein(a, b), (len(a), len(b))
+    assert len(pairs) == 8 + len(PA_TEST_NS) * len(PA_TEST_ES) + 30

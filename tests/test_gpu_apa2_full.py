@@ -324,12 +324,7 @@ def test_pairs_the_match_builder_refuses_go_to_the_host_engine(pa, oracle):
         assert {k: stats[i][k] for k in KEYS} == {k: w[2][k] for k in KEYS}, i
 
 
-@pytest.mark.parametrize("preset", ["simple", "full"])
-def test_reference_harness_as_one_batch(pa, oracle, preset):
-    """pa-test's `test_aligner` (pa-test/src/lib.rs:7-40; astarpa2/src/tests.rs runs it per configuration) as ONE batch per preset: the 8
-    literal pairs, the whole length x error-rate grid (fixed seeds; the reference samples a random quarter per run) and the structural
-    error models (a long insertion, a long deletion, a repeated block).  The reference's acceptance rules -- the cost is the plain
-    Levenshtein distance, the CIGAR is the engine's -- for every pair: cost, CIGAR string and statistics against the CPU-kernel engine."""
+def harness_pairs():
     from tests.util_seq import PA_TEST_ES, PA_TEST_NS, mutate
 
     pairs = list(PA_TEST_PAIRS)
@@ -342,6 +337,35 @@ def test_reference_harness_as_one_batch(pa, oracle, preset):
         dele = base[:200] + base[420:]
         rep = base[:350] + base[250:350] * 2 + base[350:]
         pairs += [(base, mutate(ins, 0.03, seed)), (base, mutate(dele, 0.03, seed)), (base, mutate(rep, 0.05, seed)), (ins, base), (rep, dele)]
+    return pairs
+
+
+SIMPLE_FAMILY = ["dijkstra", "sh12", "sh5", "gap_nosparseh", "gap_nodt", "gap_startgap", "gap_startzero_f15", "linear"]
+
+
+@pytest.mark.parametrize("name", SIMPLE_FAMILY + [n for n in FULL_FAMILY if n != "full"])
+def test_reference_harness_every_batched_configuration(pa, oracle, name):
+    """The harness of the test above through every other parameter set the batch kernels take -- the configurations of
+    astarpa2/src/tests.rs that are Domain::Astar over sparse blocks (band doubling over Dijkstra / GapCost / SH, GCSH with pruning,
+    DT-trace on and off, incremental doubling) and their relatives: cost = Levenshtein, CIGAR and statistics = the CPU-kernel engine."""
+    from tests.test_sweep_emu import variants as simple_variants
+
+    oc = simple_variants(oracle)[name] if name in SIMPLE_FAMILY else variants(oracle)[name][0]
+    pairs = harness_pairs()
+    costs, _, _, _ = check(pa, oracle, pairs, oc)
+    for (a, b), c in zip(pairs, costs):
+        assert c == oracle.levenshtein(a, b), (len(a), len(b))
+
+
+@pytest.mark.parametrize("preset", ["simple", "full"])
+def test_reference_harness_as_one_batch(pa, oracle, preset):
+    """pa-test's `test_aligner` (pa-test/src/lib.rs:7-40; astarpa2/src/tests.rs runs it per configuration) as ONE batch per preset: the 8
+    literal pairs, the whole length x error-rate grid (fixed seeds; the reference samples a random quarter per run) and the structural
+    error models (a long insertion, a long deletion, a repeated block).  The reference's acceptance rules -- the cost is the plain
+    Levenshtein distance, the CIGAR is the engine's -- for every pair: cost, CIGAR string and statistics against the CPU-kernel engine."""
+    from tests.util_seq import PA_TEST_ES, PA_TEST_NS
+
+    pairs = harness_pairs()
     oc = oracle.params_full() if preset == "full" else oracle.params_simple()
     costs, cigars, _, _ = check(pa, oracle, pairs, oc)
     for (a, b), c in zip(pairs, costs):

@@ -323,3 +323,20 @@ def test_c_batch_view_program(tmp_path):
                        env=dict(os.environ, LD_LIBRARY_PATH=str(libdir) + ":" + os.environ.get("LD_LIBRARY_PATH", "")))
     assert r.returncode == 0, r.stderr
     assert r.stdout.startswith("batch_view_check ok pairs=48 chars=")
+
+
+@pytest.mark.gpu
+def test_reference_harness_through_the_full_dp_batches(pa, oracle):
+    """pa-test's `test_aligner` set (the 8 literal pairs, the whole length x error-rate grid with fixed seeds, the structural error models:
+    tests/test_gpu_apa2_full.py harness_pairs) through the full-DP traced batch, re-fill-only and with the DT-trace options: cost = plain
+    Levenshtein, CIGAR = the engine's with the same `front` (astarpa2/src/tests.rs `full` / `dt_trace` configurations, batched)."""
+    from tests.test_gpu_apa2_full import harness_pairs
+
+    pairs = harness_pairs()
+    check(pa, oracle, pairs)
+    check_dt(pa, oracle, pairs)
+    batch = pa.Batch(pairs, trace=True)
+    costs, _, _, _ = batch.align()
+    batch.close()
+    for (a, b), c in zip(pairs, costs):
+        assert c == oracle.levenshtein(a, b), (len(a), len(b))

@@ -245,3 +245,20 @@ def test_gpu_results_equal_the_second_restatement(pa, oracle):
     bt.close()
     for i, w in enumerate(want["simple"]):
         assert (int(costs[i]), cigars[i]) == w[:2] and {k: int(st[i][k]) for k in KEYS} == {k: w[2][k] for k in KEYS}, i
+
+
+@pytest.mark.parametrize("preset", ["simple", "full"])
+def test_reference_harness_one_call_at_a_time(pa, oracle, preset):
+    """pa-test's whole `test_aligner` set (tests/test_gpu_apa2_full.py harness_pairs: 8 literal pairs, the full length x error-rate grid,
+    structural error models) through pa_align, one pair per call -- what the drop-in symbols astarpa2_simple / astarpa2_full run: cost =
+    Levenshtein, CIGAR and statistics = the CPU-kernel engine."""
+    from tests.test_gpu_apa2_full import harness_pairs
+
+    oc = oracle.params_full() if preset == "full" else oracle.params_simple()
+    aligner = gpu_params(pa, oc).make_aligner(True)
+    for a, b in harness_pairs():
+        want_cost, want_cigar, want_stats = oracle.cpu_align(a, b, oc)
+        cost, cigar, stats = aligner.align_with_stats(a, b)
+        assert (cost, cigar) == (want_cost, want_cigar), (len(a), len(b))
+        assert {k: stats[k] for k in STAT_KEYS} == {k: want_stats[k] for k in STAT_KEYS}, (len(a), len(b))
+        assert cost == oracle.levenshtein(a, b)

@@ -63,9 +63,12 @@ struct DevBackend {
     }
 
     __device__ __forceinline__ int32_t uniform(int32_t x) const { return (int32_t)rfl((uint32_t)x); }  // back to a scalar register
-    __device__ __forceinline__ bool failed() const { return rfl(__hip_atomic_load((const PA_GLOBAL uint32_t*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != PA_ERR_NONE; }
-
     mutable bool win_fail = false;  // a block left the window of the column store
+    // (a block that left the window ends the pass at once, like a strip error: the records, scans and prefix sums that would follow
+    //  address words outside the slot -- other slots, other pairs, past the end of the store; apa2_full_kernel.hpp does the same)
+    __device__ __forceinline__ bool failed() const {
+        return win_fail || rfl(__hip_atomic_load((const PA_GLOBAL uint32_t*)err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != PA_ERR_NONE;
+    }
     __device__ __forceinline__ sweep::SlotGeom geom() const { return sweep::SlotGeom{job.n, job.m, (int32_t)job.col_stride, job.slot_ratio}; }
     // slot k, addressed by ABSOLUTE word (the pointer is moved back by the window's first word)
     // (a block's logic asks for slots k and k - 1 a dozen times: the last two answers are kept)

@@ -380,7 +380,9 @@ void* pinned_take(size_t bytes, size_t* got) {
         std::lock_guard<std::mutex> lk(g_pin_mu);
         size_t best = g_pin.size();
         for (size_t i = 0; i < g_pin.size(); ++i)
-            if (g_pin[i].size >= bytes && (best == g_pin.size() || g_pin[i].size < g_pin[best].size)) best = i;
+            // (best fit, and never a block more than twice the request + 64 KB: a 100 KB request must not take the pooled 30 MB text
+            //  buffer and send the next text request back to hipHostMalloc)
+            if (g_pin[i].size >= bytes && g_pin[i].size <= 2 * bytes + 65536 && (best == g_pin.size() || g_pin[i].size < g_pin[best].size)) best = i;
         if (best != g_pin.size()) {
             void* p = g_pin[best].ptr;
             *got = g_pin[best].size;
@@ -1721,7 +1723,7 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
         seed_off[i] = tseeds;
         if (gcsh) tseeds += p->n[i] >= (size_t)hk ? (p->n[i] - hk) / hk + 1 : 0;
     }
-    // The matches of GCSH are found on the GPU, inside every alignment call (gcsh_build_kernel.hpp), when the look-ahead of local
+    // The matches of GCSH are found on the GPU, once, at the end of this function (gcsh_build_kernel.hpp), when the look-ahead of local
     // pruning fits its LDS arrays; PA_GCSH_HOST_BUILD=1 finds them on host threads at creation instead (tests compare the two).
     static const bool host_build_env = getenv("PA_GCSH_HOST_BUILD") != nullptr && getenv("PA_GCSH_HOST_BUILD")[0] != '0';
     p->device_build = gcsh && !host_build_env && ap.heuristic_p >= 0 && ap.heuristic_p <= apa2::kBuildMaxP && hk <= 31;
@@ -3064,7 +3066,7 @@ extern "C" int pa_debug_trace_clocks(double* out10) {
 extern "C" void pa_batch_full_info(const pa_batch* p, double* build_ms, double* matches, double* probes, double* rounds, double* phase_wave_ms) {
     if (build_ms) *build_ms = p ? p->full_build_ms : 0;
     if (matches) *matches = p ? (double)p->full_matches : 0;
-    if (p && p->device_build && p->pairs) {  // the GPU found them: the build kernel's time in the last call (negative = on the device), their number
+    if (p && p->device_build && p->pairs) {  // the GPU found them: the build kernel's time at creation (negative = on the device), their number
         float ms = 0.f;
         if (build_ms && p->evB0 && hipEventElapsedTime(&ms, p->evB0, p->evB1) == hipSuccess) *build_ms = -(double)ms;
         std::vector<apa2::FullJob> fj(p->pairs);

@@ -304,7 +304,11 @@ static int batch_align_queue(const uint8_t* const* a, const size_t* a_len, const
     if (ndevices == 1) chunk = std::max<size_t>(pairs, 1);  // one worker: nothing to balance, every chunk more is a batch creation more
     if (const char* e = std::getenv("PA_MULTI_CHUNK")) chunk = std::max<size_t>(1, (size_t)std::atoll(e));  // (tests)
     // ... and no chunk's block-column store (traced batches: one V column per 256 columns of a, full height) beyond ~24 GB
-    const double kChunkBytes = 24e9;
+    double kChunkBytes = 24e9;
+    if (const char* e = std::getenv("PA_MULTI_CHUNK_BYTES")) kChunkBytes = std::max(1.0, std::atof(e));  // (tests)
+    auto need_of = [&](size_t i) -> double {
+        return (cigar_out || params) ? ((double)a_len[i] / 256.0 + 2.0) * (double)((b_len[i] + 63) / 64) * 16.0 : 0.0;
+    };
     std::vector<size_t> bounds{0};
     if (ndevices > 1 && pairs > 0 && chunk * (size_t)ndevices >= pairs && !std::getenv("PA_MULTI_CHUNK")) {
         // Few pairs: one chunk per device, and then the queue cannot correct a bad split -- contiguous slices of the heaviest-first
@@ -317,17 +321,31 @@ static int batch_align_queue(const uint8_t* const* a, const size_t* a_len, const
             bin[r].push_back(order[k]);
             load[r] += work[order[k]];
         }
+        // (a bin is still cut where its block-column store would pass the cap: a few hundred long traced pairs dealt into one chunk
+        //  per device need far more than a device holds -- 1 GB per 1 Mbp pair)
         size_t pos = 0;
         for (size_t r = 0; r < bins; ++r) {
-            for (size_t i : bin[r]) order[pos++] = i;
-            bounds.push_back(pos);
+            double bytes = 0;
+            size_t cnt = 0;
+            for (size_t i : bin[r]) {
+                const double need = need_of(i);
+                if (cnt > 0 && bytes + need > kChunkBytes) {
+                    bounds.push_back(pos);
+                    bytes = 0;
+                    cnt = 0;
+                }
+                order[pos++] = i;
+                bytes += need;
+                cnt += 1;
+            }
+            if (cnt > 0) bounds.push_back(pos);
         }
     } else {
         double bytes = 0;
         size_t cnt = 0;
         for (size_t k = 0; k < pairs; ++k) {
             const size_t i = order[k];
-            const double need = (cigar_out || params) ? ((double)a_len[i] / 256.0 + 2.0) * (double)((b_len[i] + 63) / 64) * 16.0 : 0.0;
+            const double need = need_of(i);
             if (cnt > 0 && (cnt >= chunk || bytes + need > kChunkBytes)) {
                 bounds.push_back(k);
                 bytes = 0;

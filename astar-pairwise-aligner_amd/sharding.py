@@ -167,7 +167,9 @@ def _sharded(pairs, compute, group, with_cigar, all_ranks, work, min_chunk):
         qid = torch.zeros(1, dtype=torch.int64, device=qdev)
         if rank == 0:
             qid[0] = int(store.add("pa_work_queue_ids", 1))
-        dist.broadcast(qid, src=0, group=group)
+        # (`src` is a GLOBAL rank: on a sub-group that does not hold global rank 0 the drawer is the group's first member)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast(qid, src=src, group=group)
         key = f"pa_work_queue_{int(qid.item())}"
         while True:
             c = int(store.add(key, 1)) - 1

@@ -86,7 +86,8 @@ int pa_runtime_hints(void);
  * 10 Mbp alignment: gigabytes).  This frees the calling thread's pools; the next call builds them again.
  * It also returns the library's cache of large device buffers to the driver: a device buffer of 16 MB or more is kept when its
  * batch or pool lets go of it and handed to the next request it fits (hipMalloc + hipFree of a 40 GB block-column store cost about
- * a second; the cache is bounded at 96 GB, emptied when an allocation fails, off with PA_NO_ALLOC_CACHE=1). */
+ * a second; the cache is bounded PER DEVICE at half of the device's memory and at most 16 GB -- PA_ALLOC_CACHE_MAX bytes overrides --,
+ * emptied when an allocation fails, off with PA_NO_ALLOC_CACHE=1). */
 void pa_release_pools(void);
 /* Diagnostics of that cache: requests served from it / not served from it, bytes it holds now.  Any argument may be NULL. */
 void pa_alloc_cache_stats(uint64_t* hits, uint64_t* misses, uint64_t* cached_bytes);

@@ -157,8 +157,9 @@ size_t pa_batch_window_retries(const pa_batch* plan);
  * Supported parameters: Domain::Astar with NoCost / GapCost / SH / GCSH (exact matches, local pruning p), block_width 256,
  * front.sparse, with or without incremental doubling and pruning of matches, BandDoubling or LinearSearch (NULL otherwise: use
  * pa_align).  GCSH, pruning and incremental doubling -- the `full` preset -- run in a second kernel (csrc/apa2_full_kernel.hpp) that
- * keeps the heuristic on the GPU: its matches are found by a kernel of their own inside every alignment call (seeds, exact k-mer matches,
- * transform filter, local pruning: csrc/gcsh_build_kernel.hpp; PA_GCSH_HOST_BUILD=1 = on host threads when the batch is created), the
+ * keeps the heuristic on the GPU: its matches are found by a kernel of their own, ONCE, when the batch is created (seeds, exact k-mer
+ * matches, transform filter, local pruning: csrc/gcsh_build_kernel.hpp; PA_GCSH_HOST_BUILD=1 = on host threads instead); every
+ * pa_batch_align of the batch starts from them again (the flags of pruned matches are reset, the matches are not searched again), the
  * contours are derived and probed by the pair's wavefront (pa-heuristic csh.rs:341-376,
  * hint_contours.rs:213-272), the matches of a block are pruned by one lane per seed (prune.rs:245-292), the stored row of
  * incremental doubling (blocks.rs:342-469) is tapped out of the block's single strip.  Results come from pa_batch_align(); a pair the
@@ -173,8 +174,8 @@ pa_batch* pa_batch_create_params(const uint8_t* const* a, const size_t* a_len, c
                                  size_t pairs, const struct pa_astarpa2_params* params);
 int pa_batch_pair_stats(const pa_batch* plan, struct pa_astarpa2_stats* stats_out);
 int pa_batch_params_supported(const struct pa_astarpa2_params* params); /* 1: pa_batch_create_params takes them; 0: use pa_align */
-/* Reporting for batches of the `full` family: ms spent on the heuristic's matches (host threads at creation: positive; the GPU's build kernel in
- * the last alignment call: NEGATIVE), their number, and (PA_APA2_PROBE_STATS
+/* Reporting for batches of the `full` family: ms spent on the heuristic's matches when the batch was created (host threads: positive; the GPU's
+ * build kernel: NEGATIVE), their number, and (PA_APA2_PROBE_STATS
  * set) the h probes of the last forward pass, the 64-layer load rounds they took, and phase_wave_ms[0..7): wavefront-milliseconds (summed over
  * wavefronts) deriving contours, in DP strips, in h probes, in Block::index, in prune_block, initialising columns, in total. */
 void pa_batch_full_info(const pa_batch* plan, double* build_ms, double* matches, double* probes, double* rounds, double* phase_wave_ms);

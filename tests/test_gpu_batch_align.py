@@ -175,6 +175,23 @@ def test_work_queue_of_chunks_over_devices(pa, oracle, monkeypatch):
     assert [{k: s[k] for k in KEYS} for s in stats] == [{k: s[k] for k in KEYS} for s in a_stats]
 
 
+def test_few_long_pairs_over_devices_are_cut_at_the_byte_cap(pa, oracle, monkeypatch):
+    """Few pairs over several devices are dealt out longest-processing-time-first, one bin per device -- and a bin is still cut where its
+    block-column store would pass the cap (round 4's advisor finding: the dealt bins skipped the cap that the byte-bounded path applies).
+    The cap is forced down to one pair's worth, so every bin becomes several chunks; results equal one batch."""
+    pairs = [gen_pair(n, 0.08, seed=n) for n in (9000, 8000, 7000, 6000, 5000, 4000, 3000, 2000, 1000)]
+    single = pa.Batch(pairs, trace=True)
+    want_costs, want_cigars, _, _ = single.align()
+    single.close()
+    monkeypatch.setenv("PA_MULTI_CHUNK_BYTES", str((9000 / 256 + 2) * 141 * 16 + 1))
+    costs, cigars = pa.align_multi(pairs, [0, 0])
+    assert costs.tolist() == want_costs.tolist() and cigars == want_cigars
+    prm = pa.AstarPa2Params.simple()
+    costs, cigars, _ = pa.align_multi(pairs, [0, 0, 0], params=prm, stats=True)
+    assert costs.tolist() == want_costs.tolist()
+    assert all(oracle.cigar_verify(g, x, y) == c for g, (x, y), c in zip(cigars, pairs, costs.tolist()))
+
+
 def test_concurrent_host_threads_through_the_c_abi(pa, oracle):
     """Python threads calling different entry points at once (ctypes releases the GIL): pa_align through the sweep, a cost-only
     batch and a traced batch, all on device 0."""

@@ -145,6 +145,37 @@ def test_gcsh_matches_local_pruning_and_h_values(oracle):
             assert len(g.mi) < len(restated.Gcsh(a, b, k, 0, True).mi)  # (local pruning removed something)
 
 
+def long_kmer_collision_pair(k: int = 20, seeds: int = 60, seed: int = 5):
+    """Seeds of a that share their LAST 16 characters and differ in the first k - 16 (round 4's advisor finding: 32-bit k-mer keys made
+    all of them match each other for k > 16; the reference compares whole q-grams, qgrams.rs:36-43)."""
+    rnd = random.Random(seed)
+    tail = bytes(rnd.choice(b"ACGT") for _ in range(16))
+    heads = [bytes(rnd.choice(b"ACGT") for _ in range(k - 16)) for _ in range(seeds)]
+    a = b"".join(h + tail for h in heads)
+    order = list(range(seeds))
+    rnd.shuffle(order)
+    b = b"".join(heads[i] + tail for i in order[: seeds // 2]) + b"".join(bytes(rnd.choice(b"ACGT") for _ in range(k - 16)) + tail for _ in range(seeds // 2))
+    return a, b
+
+
+def test_gcsh_kmers_longer_than_16_are_compared_in_full(oracle):
+    for k, p in ((20, 0), (24, 3), (31, 0), (17, 14)):
+        a, b = long_kmer_collision_pair(k)
+        g = restated.Gcsh(a, b, k, p, True)
+        q = [(0, 0), (len(a), len(b)), (len(a) // 2, len(b) // 3)]
+        want_h, want_kept = oracle.gcsh_probe(a, b, k, p, q)
+        assert sorted(map(tuple, want_kept)) == sorted(zip(g.mi.tolist(), g.mj.tolist())), (k, p)
+        assert [g.h(i, j) for i, j in q] == want_h
+        if p == 0:  # brute force: every (seed start, j) with equal k-mers, under the transform filter the matches respect
+            brute = {(i, j) for i in range(0, len(a) - k + 1, k) for j in range(len(b) - k + 1) if a[i:i + k] == b[j:j + k]}
+            assert set(map(tuple, want_kept)) <= brute and len(brute) < (len(a) // k) ** 2 // 4
+    # SH (static seed heuristic): a seed counts as matched only if its WHOLE k-mer occurs in b
+    a, b = long_kmer_collision_pair(20)
+    b2 = b[: 20 * 30]  # only the first thirty k-mers of b are copies of seeds of a
+    compare(oracle, a, b2, oracle.make_params(**{**BASE, "heuristic": "sh", "k": 20}), dict(heuristic="sh", k=20))
+    compare(oracle, a, b2, oracle.make_params(**{**BASE, "heuristic": "gcsh", "k": 20, "p": 3, "prune": True}), dict(heuristic="gcsh", k=20, p=3, prune=True))
+
+
 def test_c3_pair_of_the_bench_full_preset(oracle):
     """The 100 kbp pair of the bench through `full` (GCSH k = 12, p = 14, pruning at the start, incremental doubling)."""
     a, b = gen_pair(100_000, 0.05, seed=3_000_000)

@@ -188,6 +188,55 @@ def test_queue_key_survives_calls_on_subgroups():
     assert sum(n for _, _, n in res) == 3 * 40  # every pair of the three world calls computed exactly once
 
 
+def _subgroup_without_rank0_worker(rank, world, port, q):
+    """A sub-group that does NOT hold global rank 0 (round 4's advisor finding: the queue id was broadcast with `src=0`, a GLOBAL rank that
+    is not a member of such a group): ranks 1 and 2 of a world of three share one queue, then the whole world runs a call."""
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from astar_pairwise_aligner_amd.sharding import sharded_costs
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sub = dist.new_group([1, 2])  # (every rank creates the group; rank 0 is not in it)
+    pairs = [(b"ACGT" * (i + 1), b"ACGA" * (i + 1)) for i in range(40)]
+    want = [i + 1 for i in range(40)]
+    calls = []
+
+    def compute(part):
+        calls.append(len(part))
+        return [len(a) // 4 for a, _ in part]
+
+    ok = True
+    n_sub = 0
+    if rank in (1, 2):
+        ok = sharded_costs(pairs[:24], compute=compute, group=sub, min_chunk=2) == want[:24]
+        n_sub = sum(calls)
+    ok = ok and sharded_costs(pairs, compute=compute, min_chunk=4) == want
+    q.put((rank, ok, n_sub, sum(calls) - n_sub))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_queue_on_a_subgroup_without_global_rank0():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_without_rank0_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res)
+    assert sum(n for _, _, n, _ in res) == 24  # the sub-group's pairs: computed once, by ranks 1 and 2 together
+    assert sum(n for _, _, _, n in res) == 40  # the world call
+
+
 def test_few_pairs_are_dealt_by_work_not_sliced():
     from astar_pairwise_aligner_amd.sharding import plan_chunks
 

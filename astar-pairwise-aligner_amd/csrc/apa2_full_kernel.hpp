@@ -24,6 +24,7 @@
 //  * The probing loops of j_range / fixed_j_range stay literal (GCSH with local pruning is not consistent: a jump may skip rows that
 //    would pass, and the reference's results depend on where the probes land).
 #pragma once
+#include "apa2_jobs.hpp"
 #include "apa2_full_logic.hpp"
 #include "apa2_kernel.hpp"
 #include "gcsh_dev.hpp"
@@ -32,24 +33,6 @@
 namespace pa {
 namespace apa2 {
 
-enum : int32_t { kFullHeurNone = 0, kFullHeurGap = 1, kFullHeurSH = 2, kFullHeurGcsh = 3 };  // engine.hpp HeuristicKind
-
-struct FullJob {
-    const uint32_t* a_codes;  // packed 2-bit codes of a
-    const uint32_t* b_prof;   // BitProfile words of b, u32 view
-    BlockRec* rec;            // [nblk + 2] persistent block records (the traceback reads them: trace_kernel.hpp)
-    int32_t* jh;              // [nblk + 2] row of the stored horizontal differences per block (Block::j_h), kNone: none
-    uint32_t* col;            // column store: slot k = col + k * col_stride * 4, indexed by absolute word
-    int64_t col_stride;       // words per slot: the pair's window (sweep_logic.hpp SlotGeom)
-    uint8_t* hrow;            // [n] the stored row: one byte per column, bit0 = +1, bit1 = -1 (blocks.rs:103-105)
-    const int32_t* sh_h;      // SH: h(i) for i = 0..n
-    uint64_t* gran;           // 2 rows x 8 granules, zero between uses
-    int32_t* sum;             // scratch: bottom-row sum of the last strip
-    PairResult* result;
-    GcshDev g;                // GCSH
-    int32_t n, m, heur;
-    uint32_t slot_ratio;      // SlotGeom::ratio
-};
 
 typedef int32_t pa_i32x4 __attribute__((ext_vector_type(4)));
 
@@ -559,6 +542,7 @@ __device__ __forceinline__ void store_full_result(const FullJob& job, const Full
 
 // Pairs are claimed by ticket in the order of `order` (heaviest first); a block is four independent wavefronts.
 // probe_stats (optional, diagnostics): [0] += h probes, [1] += load rounds they took, [2..9) += phase clocks (pa_batch_full_info).
+#ifdef PA_UNIT_APA2_FULL  // (the kernel is compiled in a translation unit of its own: csrc/apa2_units.hpp)
 __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_full_kernel(const FullJob* __restrict__ jobs, const int32_t* __restrict__ order, int npairs,
                                                                          FullParams sp, uint32_t* ticket, uint32_t* err, uint32_t* dbg,
                                                                          unsigned long long* probe_stats) {
@@ -602,6 +586,7 @@ __global__ __launch_bounds__(64) void gcsh_probe_kernel(const FullJob* __restric
     }
     out[nq] = be.g.nlayers;
 }
+#endif  // PA_UNIT_APA2_FULL
 
 }  // namespace apa2
 }  // namespace pa

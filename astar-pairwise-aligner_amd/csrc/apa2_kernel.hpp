@@ -16,26 +16,13 @@
 //  * The right-edge column of every block stays in HBM at its absolute word position (slot k of the pair's column store), so
 //    the traceback (trace_kernel.hpp) reads the blocks of the successful pass where the forward pass left them.
 #pragma once
+#include "apa2_jobs.hpp"
 #include "apa2_logic.hpp"
 #include "strip_kernel.hpp"
 
 namespace pa {
 namespace apa2 {
 
-struct PairJob {
-    const uint32_t* a_codes;  // packed 2-bit codes of a
-    const uint32_t* b_prof;   // BitProfile words of b, u32 view
-    BlockRec* rec;            // [nblk + 1] persistent block records
-    uint32_t* col;            // column store: slot k (block k's right-edge column) = col + k * col_stride * 4, indexed by absolute word
-    int64_t col_stride;       // words per slot: the pair's window (sweep_logic.hpp SlotGeom), ceil(m / 64) = the full column
-    uint32_t slot_ratio;      // SlotGeom::ratio
-    uint32_t pad0;
-    const int32_t* sh_h;      // SH: h(i) for i = 0..n, else nullptr
-    uint64_t* gran;           // 2 rows x 8 granules, zero between uses
-    int32_t* sum;             // scratch: bottom-row sum of the last strip
-    PairResult* result;
-    int32_t n, m;
-};
 
 __device__ __forceinline__ int32_t wsum(int32_t x) { return wave_add(x); }
 
@@ -274,6 +261,7 @@ struct DevBackend {
 };
 
 // Pairs are claimed by ticket in the order of `order` (heaviest first); a block is four independent wavefronts.
+#ifdef PA_UNIT_APA2_SIMPLE  // (the kernel is compiled in a translation unit of its own: csrc/apa2_units.hpp)
 __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_kernel(const PairJob* __restrict__ jobs, const int32_t* __restrict__ order, int npairs,
                                                                     SearchParams sp, uint32_t* ticket, uint32_t* err, uint32_t* dbg, int k1_only) {
     const int lane = (int)(threadIdx.x & 63);
@@ -313,6 +301,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_kernel(const Pa
         *job.result = res;  // (every lane stores the same 64 bytes: no lane-dependent branch at the end of the loop body either)
     }
 }
+#endif  // PA_UNIT_APA2_SIMPLE
 
 }  // namespace apa2
 }  // namespace pa

@@ -23,6 +23,7 @@
 // A pair whose candidates outgrow its buffers (a repeat-rich sequence) or whose ring would drop a match still in reach is flagged and
 // goes to the host engine, like every other pair the batch kernels hand back.
 #pragma once
+#include "apa2_jobs.hpp"
 #include "apa2_kernel.hpp"
 #include "gcsh_dev.hpp"
 
@@ -30,33 +31,6 @@ namespace pa {
 namespace apa2 {
 
 typedef int32_t pa_i32x4_b __attribute__((ext_vector_type(4)));  // a GcshSeedWindow as one 16-byte store
-constexpr int kBuildMaxP = 14;                    // local-pruning look-ahead the LDS arrays are sized for (the `full` preset's)
-constexpr int kBuildFr = 2 * kBuildMaxP + 3;      // diagonals of a search + one sentinel either side
-constexpr int32_t kBuildNeg = INT32_MIN;          // "no column yet" (prepruning.rs uses I::MIN)
-
-struct GcshBuildJob {
-    const uint8_t* a;   // ASCII, device
-    const uint8_t* b;
-    uint32_t* keys;     // [nseeds]   the k-mer of every seed (low 32 bits of the 2-bit packing, first character highest: qgrams.rs:30-43)
-    int32_t* slot;      // [tsize]    hash table: the newest seed of a k-mer's chain, -1 empty
-    int32_t* next_same; // [nseeds]   next seed with the same k-mer, -1
-    int32_t* cnt;       // [nseeds + 1] candidates per seed, then their exclusive prefix
-    int32_t* fill;      // [nseeds]
-    int32_t* tmp_s;     // [cap] candidates in push order read backwards: rows ascending, seeds descending within a row
-    int32_t* tmp_j;     // [cap]
-    int32_t* gpos;      // [cap] position of candidate t in the by-start order
-    int32_t* cj;        // [cap] by-start order: rows (the seed of position q is the one whose prefix range holds q)
-    uint8_t* flag;      // [cap] by candidate t: 1 = kept
-    uint8_t* keptg;     // [cap] by by-start position: 1 = kept
-    int32_t* mi;        // out [cap] kept matches by start: columns
-    int32_t* mj;        // out: rows
-    GcshSeedWindow* win0;  // out [nseeds]
-    int32_t* nmatch_out;   // out: &FullJob::g.nmatch of this pair
-    uint32_t* status;      // out: 0 built, else why not (kBuild*)
-    int32_t n, m, k, p, nseeds, tsize, cap, pad;
-    unsigned long long* clocks;  // diagnostics (optional): 100 MHz ticks of phases A .. F, then the candidates, those kept alone, the searches of E
-};
-enum : uint32_t { kBuildOk = 0, kBuildOverflow = 1, kBuildRing = 2 };
 
 __device__ __forceinline__ uint32_t kmer_key(const PA_GLOBAL uint8_t* s, int32_t k) {  // qgrams.rs:30-43: (c >> 1) & 3, first character highest
     uint64_t q = 0;
@@ -285,6 +259,7 @@ __device__ __forceinline__ bool prune_with_kept(const BuildCtx& cx, int32_t si, 
     return false;
 }
 
+#ifdef PA_UNIT_GCSH_BUILD  // (the kernel is compiled in a translation unit of its own: csrc/apa2_units.hpp)
 __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __restrict__ jobs, int npairs, uint32_t* ticket) {
     __shared__ int32_t lds_fr[2][kBuildFr * 64];
     __shared__ int32_t ring_i[64], ring_d[64], nm_lds[64];
@@ -562,6 +537,7 @@ __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __re
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
 }
+#endif  // PA_UNIT_GCSH_BUILD
 
 }  // namespace apa2
 }  // namespace pa

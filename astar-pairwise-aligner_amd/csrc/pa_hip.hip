@@ -3,9 +3,7 @@
 #include "pa_hip_internal.hpp"
 #include "engine_capi.hpp"
 #include "trace_kernel.hpp"
-#include "apa2_kernel.hpp"
-#include "apa2_full_kernel.hpp"
-#include "gcsh_build_kernel.hpp"
+#include "apa2_units.hpp"
 
 #include <sched.h>
 
@@ -1915,8 +1913,7 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
         const int cus = g_device_props_cus > 0 ? g_device_props_cus : 256;
         const int grid = (int)std::min<size_t>(P, (size_t)cus * 8);
         if (!hip_ok(hipMemsetAsync(p->d_bticket.ptr, 0, 64, p->stream), "memset") || !hip_ok(hipEventRecord(p->evB0, p->stream), "event")) return false;
-        hipLaunchKernelGGL(apa2::gcsh_build_kernel, dim3(grid), dim3(64), 0, p->stream, p->d_bjobs.as<apa2::GcshBuildJob>(), (int)P, p->d_bticket.as<uint32_t>());
-        if (!hip_ok(hipGetLastError(), "gcsh_build_kernel launch") || !hip_ok(hipEventRecord(p->evB1, p->stream), "event")) return false;
+        if (!hip_ok(apa2::launch_gcsh_build_kernel(grid, p->stream, p->d_bjobs.as<apa2::GcshBuildJob>(), (int)P, p->d_bticket.as<uint32_t>()), "gcsh_build_kernel launch") || !hip_ok(hipEventRecord(p->evB1, p->stream), "event")) return false;
     }
     return true;
 }
@@ -2316,13 +2313,11 @@ static int launch_astar(pa_batch* p, hipStream_t s, size_t lo, size_t cnt, uint3
     const int cus = g_device_props_cus > 0 ? g_device_props_cus : 256;
     const int grid = (int)std::min<size_t>((cnt + kStripBlockWaves - 1) / kStripBlockWaves, (size_t)cus * per_cu);
     const int32_t* ord = p->d_order.as<int32_t>() + lo;
-    if (p->astar_full)
-        hipLaunchKernelGGL(apa2::apa2_full_kernel, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, p->d_fjobs.as<apa2::FullJob>(), ord, (int)cnt, p->fsp, ticket,
-                           p->d_misc.as<uint32_t>() + 1, dbg, probe_stats ? p->d_probe.as<unsigned long long>() : nullptr);
-    else
-        hipLaunchKernelGGL(apa2::apa2_kernel, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, p->d_pjobs.as<apa2::PairJob>(), ord, (int)cnt, p->sp, ticket,
-                           p->d_misc.as<uint32_t>() + 1, dbg, getenv("PA_APA2_K1") ? 1 : 0);
-    return hip_ok(hipGetLastError(), "apa2_kernel launch") ? 0 : PA_E_HIP;
+    const hipError_t e = p->astar_full ? apa2::launch_apa2_full_kernel(grid, s, p->d_fjobs.as<apa2::FullJob>(), ord, (int)cnt, p->fsp, ticket, p->d_misc.as<uint32_t>() + 1, dbg,
+                                                                       probe_stats ? p->d_probe.as<unsigned long long>() : nullptr)
+                                       : apa2::launch_apa2_kernel(grid, s, p->d_pjobs.as<apa2::PairJob>(), ord, (int)cnt, p->sp, ticket, p->d_misc.as<uint32_t>() + 1, dbg,
+                                                                  getenv("PA_APA2_K1") ? 1 : 0);
+    return hip_ok(e, "apa2_kernel launch") ? 0 : PA_E_HIP;
 }
 
 // Profiles -> (granule clear) -> DP kernel, all queued on the batch's stream; ev0/ev1 bracket the DP kernel.
@@ -2979,8 +2974,7 @@ extern "C" long pa_debug_gcsh_matches(const uint8_t* a, size_t a_len, const uint
     if (!hip_ok(hipMemcpy(d_a.ptr, a, a_len, hipMemcpyHostToDevice), "H2D") || !hip_ok(hipMemcpy(d_b.ptr, b, b_len, hipMemcpyHostToDevice), "H2D") ||
         !hip_ok(hipMemset(d_out.ptr, 0, 64), "memset") || !hip_ok(hipMemcpy(d_job.ptr, &x, sizeof x, hipMemcpyHostToDevice), "H2D"))
         return PA_E_HIP;
-    hipLaunchKernelGGL(apa2::gcsh_build_kernel, dim3(1), dim3(64), 0, 0, d_job.as<apa2::GcshBuildJob>(), 1, d_out.as<uint32_t>() + 8);
-    if (!hip_ok(hipGetLastError(), "gcsh_build_kernel") || !hip_ok(hipDeviceSynchronize(), "sync") || !hip_ok(hipMemcpy(res, d_out.ptr, 16, hipMemcpyDeviceToHost), "D2H"))
+    if (!hip_ok(apa2::launch_gcsh_build_kernel(1, 0, d_job.as<apa2::GcshBuildJob>(), 1, d_out.as<uint32_t>() + 8), "gcsh_build_kernel") || !hip_ok(hipDeviceSynchronize(), "sync") || !hip_ok(hipMemcpy(res, d_out.ptr, 16, hipMemcpyDeviceToHost), "D2H"))
         return PA_E_HIP;
     if (clocks) {
         unsigned long long c[16] = {0};
@@ -3041,8 +3035,7 @@ extern "C" int pa_debug_gcsh_probe(const uint8_t* a, size_t a_len, const uint8_t
         !hip_ok(hipMemcpy(d_job.ptr, &j, sizeof j, hipMemcpyHostToDevice), "H2D") ||
         (nq && !hip_ok(hipMemcpy(d_q.ptr, queries, nq * 8, hipMemcpyHostToDevice), "H2D")))
         return PA_E_HIP;
-    hipLaunchKernelGGL(apa2::gcsh_probe_kernel, dim3(1), dim3(64), 0, 0, d_job.as<apa2::FullJob>(), d_q.as<int32_t>(), (int)nq, d_out.as<int32_t>(), d_err.as<uint32_t>());
-    if (!hip_ok(hipGetLastError(), "gcsh_probe_kernel") || !hip_ok(hipDeviceSynchronize(), "sync") ||
+    if (!hip_ok(apa2::launch_gcsh_probe_kernel(0, d_job.as<apa2::FullJob>(), d_q.as<int32_t>(), (int)nq, d_out.as<int32_t>(), d_err.as<uint32_t>()), "gcsh_probe_kernel") || !hip_ok(hipDeviceSynchronize(), "sync") ||
         !hip_ok(hipMemcpy(out, d_out.ptr, (nq + 1) * 4, hipMemcpyDeviceToHost), "D2H"))
         return PA_E_HIP;
     return 0;

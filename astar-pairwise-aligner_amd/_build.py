@@ -10,7 +10,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libastarpa_c_hip.so"
 
-HIP_SOURCES = ["pa_hip.hip", "engine_hip.hip", "astarpa_c.hip", "pairs_io.hip", "apa2_simple_unit.hip", "apa2_full_unit.hip", "gcsh_build_unit.hip"]
+HIP_SOURCES = ["pa_hip.hip", "engine_hip.hip", "astarpa_c.hip", "pairs_io.hip", "apa2_simple_unit.hip", "apa2_full_unit.hip", "gcsh_build_unit.hip", "sketch_unit.hip"]
 
 
 def _hipcc() -> str:

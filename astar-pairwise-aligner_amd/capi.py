@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "pa_align", "pa_batch_align_multi", "pa_batch_create_trace_params",
     "pa_bp_ctx_create", "pa_bp_ctx_compute", "pa_bp_ctx_fill", "pa_bp_ctx_destroy",
     "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools", "pa_align_file_params", "pa_batch_params_supported", "pa_alloc_cache_stats", "pa_free_cigars",
-    "pa_batch_full_info", "pa_debug_gcsh_probe", "pa_debug_gcsh_matches", "pa_batch_window_retries",
+    "pa_batch_full_info", "pa_batch_rdv_stats", "pa_debug_gcsh_probe", "pa_debug_gcsh_matches", "pa_batch_window_retries",
 ]
 
 _lib = None
@@ -83,6 +83,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_batch_stats.argtypes = [vp] + [C.POINTER(C.c_double)] * 4
     L.pa_batch_full_info.argtypes = [vp] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_double)]
     L.pa_batch_full_info.restype = None
+    L.pa_batch_rdv_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.pa_batch_rdv_stats.restype = C.c_int
     L.pa_batch_shape.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.pa_batch_destroy.argtypes = [vp]
     L.pa_batch_create_banded.argtypes = [vp, vp, vp, vp, sz, C.c_float]
@@ -520,6 +522,14 @@ class Batch:
         d = dict(zip(("build_ms", "matches", "probes", "rounds"), (v.value for v in vals)))
         d["phase_wave_ms"] = dict(zip(("contours", "dp", "h", "index", "prune", "init", "total"), [x for x in ph][:7]))
         return d
+
+    def rdv_stats(self) -> dict:
+        """pa_batch_rdv_stats: how the half-wave blocks of the last forward pass met (batched A*PA2; diagnostics)."""
+        out = (C.c_uint64 * 4)()
+        rc = load().pa_batch_rdv_stats(self._h, out)
+        if rc != 0:
+            raise PaError(f"pa_batch_rdv_stats rc={rc}: {last_error()}")
+        return dict(zip(("fused", "served", "alone", "withdrawn"), (int(x) for x in out)))
 
     def trace_fallbacks(self) -> int:
         return int(load().pa_batch_trace_fallbacks(self._h))

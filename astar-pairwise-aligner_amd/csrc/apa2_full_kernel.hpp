@@ -28,6 +28,7 @@
 #include "apa2_full_logic.hpp"
 #include "apa2_kernel.hpp"
 #include "gcsh_dev.hpp"
+#include "strip2_kernel.hpp"
 #include "strip_kernel.hpp"
 
 namespace pa {
@@ -45,6 +46,12 @@ struct FullDevBackend {
     int32_t hint = 0;      // the last score (the next probe's window is centred on it)
     bool dirty = false;    // matches were pruned since the contours were derived
     mutable uint32_t strip_units = 0;
+    // the rendezvous of half-wave blocks (strip2_kernel.hpp, round 5): a block of `full` is about ten words -- twenty lanes -- so two pairs'
+    // blocks run as ONE strip whenever two wavefronts of the workgroup reach theirs within each other's patience
+    RdvLds rdv{nullptr, 0};
+    int wave = 0;
+    RdvParams rp{0u, 0u};
+    mutable rdv::Counters rdv_cnt;
     uint32_t n_probe = 0, n_round = 0;  // diagnostics: h probes and the load rounds they took
     bool timing = false;                // diagnostics (PA_APA2_PROBE_STATS): phase clocks, 100 MHz ticks
     mutable uint64_t t_build = 0, t_dp = 0, t_h = 0, t_index = 0, t_prune = 0, t_init = 0;
@@ -292,6 +299,11 @@ struct FullDevBackend {
             // the tap: the deltas leaving the lane whose last row is 64 wt - 1, if that row is in this strip
             int tl = -1;
             if (tap_inside && wt > sw0 && wt <= sw0 + take) tl = kk == 2 ? (wt - sw0) - 1 : 2 * (wt - sw0) - 1;
+            if (kk == 1 && rp.enabled && dual_ok(j) && rdv_strip<true>(rdv, wave, rp, j, tl, err, &rdv_cnt, &strip_units)) {
+                sync_mem();
+                ck = -1;
+                break;  // (a strip that qualifies is the block's only one)
+            }
             if (kk == 2) run_strip<2, false, false, false, true, false, false, true, true>(j, err, 0, tl);
             else if (j.nlanes <= 32) run_strip<1, false, false, false, true, false, true, true, true>(j, err, 0, tl);
             else run_strip<1, false, false, false, true, false, false, true, true>(j, err, 0, tl);
@@ -300,7 +312,7 @@ struct FullDevBackend {
             strip_units += (uint32_t)((((i1 - i0 + 31) >> 5) + ((kk == 1 && j.nlanes <= 32) ? 1 : 2)) * (11 + 12 * kk));
             done += take;
         }
-        const int32_t ret = (int32_t)rfl((uint32_t)*(const PA_GLOBAL int32_t*)job.sum);
+        const int32_t ret = (int32_t)rfl((uint32_t)__hip_atomic_load((const PA_GLOBAL int32_t*)job.sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         t_dp += tick() - t0;
         return ret;
     }
@@ -545,8 +557,13 @@ __device__ __forceinline__ void store_full_result(const FullJob& job, const Full
 #ifdef PA_UNIT_APA2_FULL  // (the kernel is compiled in a translation unit of its own: csrc/apa2_units.hpp)
 __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_full_kernel(const FullJob* __restrict__ jobs, const int32_t* __restrict__ order, int npairs,
                                                                          FullParams sp, uint32_t* ticket, uint32_t* err, uint32_t* dbg,
-                                                                         unsigned long long* probe_stats) {
+                                                                         unsigned long long* probe_stats, RdvParams rp, unsigned long long* rdv_stats) {
     const int lane = (int)(threadIdx.x & 63);
+    __shared__ RdvShared apa2_rdv;
+    rdv_init(&apa2_rdv, kStripBlockWaves);
+    const RdvLds rdv_lds{(lds_u32)&apa2_rdv, lane};
+    const int wave_in_block = (int)rfl((uint32_t)(threadIdx.x >> 6));
+    rdv::Counters rdv_total;
     for (;;) {
         uint32_t t = atomicAdd(ticket, lane == 0 ? 1u : 0u);  // (branch-free: see apa2_kernel.hpp)
         t = rfl(t);
@@ -555,6 +572,9 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_full_kernel(con
         const FullJob job = jobs[pair];
         FullDevBackend be(job, err, dbg);
         be.timing = probe_stats != nullptr;
+        be.rdv = rdv_lds;
+        be.wave = wave_in_block;
+        be.rp = rp;
         const uint64_t t_begin = be.tick();
         FullResult fr{};
         if (job.n > 0 && job.m > 0 && !(job.heur == kFullHeurGcsh && job.g.nmatch < 0)) {  // (nmatch < 0: the matches could not be built on the device)
@@ -570,6 +590,15 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_full_kernel(con
             const unsigned long long vals[9] = {be.n_probe, be.n_round, be.t_build, be.t_dp, be.t_h, be.t_index, be.t_prune, be.t_init, be.tick() - t_begin};
             for (int q = 0; q < 9; ++q) atomicAdd(probe_stats + q, lane == 0 ? vals[q] : 0ull);
         }
+        rdv_total.took += be.rdv_cnt.took;
+        rdv_total.served += be.rdv_cnt.served;
+        rdv_total.alone += be.rdv_cnt.alone;
+        rdv_total.withdrawn += be.rdv_cnt.withdrawn;
+    }
+    rdv_lds.leave();  // (a block of this workgroup that waits for a partner now knows one candidate less)
+    if (rdv_stats) {
+        const unsigned long long vals[4] = {rdv_total.took, rdv_total.served, rdv_total.alone, rdv_total.withdrawn};
+        for (int q = 0; q < 4; ++q) atomicAdd(rdv_stats + q, lane == 0 ? vals[q] : 0ull);
     }
 }
 

@@ -8,8 +8,8 @@ namespace pa {
 namespace apa2 {
 
 hipError_t launch_apa2_full_kernel(int grid, hipStream_t s, const FullJob* jobs, const int32_t* order, int npairs, const FullParams& sp, uint32_t* ticket,
-                                   uint32_t* err, uint32_t* dbg, unsigned long long* probe_stats) {
-    hipLaunchKernelGGL(apa2_full_kernel, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, jobs, order, npairs, sp, ticket, err, dbg, probe_stats);
+                                   uint32_t* err, uint32_t* dbg, unsigned long long* probe_stats, const RdvParams& rp, unsigned long long* rdv_stats) {
+    hipLaunchKernelGGL(apa2_full_kernel, dim3(grid), dim3(64 * kStripBlockWaves), 0, s, jobs, order, npairs, sp, ticket, err, dbg, probe_stats, rp, rdv_stats);
     return hipGetLastError();
 }
 

@@ -15,9 +15,13 @@
 //    exact wave-parallel searches (see apa2_logic.hpp for why they end where the reference's jumping probes end).
 //  * The right-edge column of every block stays in HBM at its absolute word position (slot k of the pair's column store), so
 //    the traceback (trace_kernel.hpp) reads the blocks of the successful pass where the forward pass left them.
+//  * Two pairs per strip (round 5): a block of at most 16 words -- half a wave -- meets a block of another wavefront of the same
+//    workgroup (rdv_logic.hpp) and the two run as ONE strip, pair A in lanes 0..31 and pair B in lanes 32..63 (strip2_kernel.hpp):
+//    25 instead of 24 + 24 VALU instructions per step for what is 80 % of this kernel's instructions on short pairs.
 #pragma once
 #include "apa2_jobs.hpp"
 #include "apa2_logic.hpp"
+#include "strip2_kernel.hpp"
 #include "strip_kernel.hpp"
 
 namespace pa {
@@ -40,6 +44,11 @@ struct DevBackend {
     bool k1_only = false;  // experiments: K = 1 strips only (PA_APA2_K1)
     uint32_t lds_eq = 0;   // byte offset of this wavefront's 4 KB LDS slice for the eq words of K = 4 strips (strip_kernel.hpp LdsEq)
     mutable uint32_t strip_units = 0;  // modelled VALU instructions of the strips so far, in units of 32 (one per unrolled chunk step)
+    // the rendezvous of half-wave blocks (strip2_kernel.hpp): this workgroup's shared word and mail, this wavefront's index in it
+    RdvLds rdv{nullptr, 0};
+    int wave = 0;
+    RdvParams rp{0u, 0u};
+    mutable rdv::Counters rdv_cnt;
     __device__ __forceinline__ uint64_t strip_instructions() const { return (uint64_t)strip_units << 5; }
 
     // (own_sgpr on the descriptor's fields was tried here too, round 4: C4 forward 11.4 -> 11.7 ms -- this kernel's band logic is short
@@ -186,6 +195,11 @@ struct DevBackend {
             j.hin_n = 0;
             j.vsum_out = nullptr;
             // (a strip that is not the last one is full, the last one does not need an exact bottom row: NOPASS)
+            if (kk == 1 && rp.enabled && dual_ok(j) && rdv_strip<false>(rdv, wave, rp, j, -1, err, &rdv_cnt, &strip_units)) {
+                // (this block and a block of another wavefront ran as one strip -- or a partner ran it: the column and the sum are in memory)
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                break;
+            }
             if (kk == 4) run_strip<4, false, false, false, true, true, false, true>(j, err, lds_eq);  // eq words from LDS: 50 instead of 59 per step
             else if (kk == 3) run_strip<3, false, false, false, true, false, false, true>(j, err);
             else if (kk == 2) run_strip<2, false, false, false, true, false, false, true>(j, err);
@@ -196,7 +210,7 @@ struct DevBackend {
             strip_units += (uint32_t)((((i1 - i0 + 31) >> 5) + ((kk == 1 && j.nlanes <= 32) ? 1 : 2)) * (kk == 4 ? 50 : 11 + 12 * kk));
             done += take;
         }
-        return (int32_t)rfl((uint32_t)*(const PA_GLOBAL int32_t*)job.sum);
+        return (int32_t)rfl((uint32_t)__hip_atomic_load((const PA_GLOBAL int32_t*)job.sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
     }
 
     __device__ __forceinline__ int32_t hval(int32_t i, int32_t j, int32_t sh_i) const {
@@ -263,8 +277,14 @@ struct DevBackend {
 // Pairs are claimed by ticket in the order of `order` (heaviest first); a block is four independent wavefronts.
 #ifdef PA_UNIT_APA2_SIMPLE  // (the kernel is compiled in a translation unit of its own: csrc/apa2_units.hpp)
 __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_kernel(const PairJob* __restrict__ jobs, const int32_t* __restrict__ order, int npairs,
-                                                                    SearchParams sp, uint32_t* ticket, uint32_t* err, uint32_t* dbg, int k1_only) {
+                                                                    SearchParams sp, uint32_t* ticket, uint32_t* err, uint32_t* dbg, int k1_only,
+                                                                    RdvParams rp, unsigned long long* rdv_stats) {
     const int lane = (int)(threadIdx.x & 63);
+    __shared__ RdvShared apa2_rdv;
+    rdv_init(&apa2_rdv, kStripBlockWaves);
+    const RdvLds rdv_lds{(lds_u32)&apa2_rdv, lane};
+    const int wave_in_block = (int)rfl((uint32_t)(threadIdx.x >> 6));
+    rdv::Counters rdv_total;
     // one 4 KB slice per wavefront for the eq words of K = 4 strips, aligned to its size (the strip ORs offsets into the address)
     __shared__ __attribute__((aligned(4096))) uint32_t apa2_lds_eq[kStripBlockWaves][LdsEq<4>::kWaveBytes / 4];
     typedef __attribute__((address_space(3))) uint32_t* lds_u32p;
@@ -287,6 +307,9 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_kernel(const Pa
         DevBackend be(job, hp, err, dbg);
         be.k1_only = k1_only != 0;
         be.lds_eq = lds_eq_off;
+        be.rdv = rdv_lds;
+        be.wave = wave_in_block;
+        be.rp = rp;
         be.mark(7, (uint32_t)pair + 1u);
         PairProg<DevBackend> prog(be, hp, sp);
         PairResult res;
@@ -299,6 +322,15 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_kernel(const Pa
         if (be.win_fail) res.status = kErrWindow;
         else if (rfl(*(const PA_GLOBAL uint32_t*)err) != PA_ERR_NONE && res.status == kOk) res.status = kErrDevice;
         *job.result = res;  // (every lane stores the same 64 bytes: no lane-dependent branch at the end of the loop body either)
+        rdv_total.took += be.rdv_cnt.took;
+        rdv_total.served += be.rdv_cnt.served;
+        rdv_total.alone += be.rdv_cnt.alone;
+        rdv_total.withdrawn += be.rdv_cnt.withdrawn;
+    }
+    rdv_lds.leave();  // (a block of this workgroup that waits for a partner now knows one candidate less)
+    if (rdv_stats) {
+        const unsigned long long vals[4] = {rdv_total.took, rdv_total.served, rdv_total.alone, rdv_total.withdrawn};
+        for (int q = 0; q < 4; ++q) atomicAdd(rdv_stats + q, lane == 0 ? vals[q] : 0ull);
     }
 }
 #endif  // PA_UNIT_APA2_SIMPLE

@@ -1316,6 +1316,7 @@ struct pa_batch {
     pa_astarpa2_params aparams_c{};
     apa2::SearchParams sp{};
     DeviceBuf d_rec, d_results, d_pjobs, d_order, d_tstats, d_sh;
+    DeviceBuf d_rdv;  // 8 x u64: the rendezvous of half-wave blocks in the last forward pass (strips run fused, served by a partner, alone, withdrawn)
     // ... the whole family (pa_batch_create_params with GCSH / pruning / incremental doubling: apa2_full_kernel.hpp)
     bool astar_full = false;
     apa2::FullParams fsp{};
@@ -1570,6 +1571,36 @@ static bool apa2_full_supported(const engine::AstarPa2Params& p) {
            (!p.front.dt_trace || (p.front.max_g >= 1 && p.front.max_g <= kDtMaxG));
 }
 
+// The start order of the batched band search: the most expensive pairs first (sketch_unit.hip has the why).  Expected work of a pair:
+// its length times the band its final pass needs, band ~ estimated cost = e (n + m) / 2 with e from the sketch ((1 - e)^16 = found / 64).
+// PA_APA2_ORDER_INPUT keeps the caller's order, PA_APA2_ORDER_LENGTH the order of the lengths (round 4) -- experiments and tests.
+static bool astar_start_order(pa_batch* p, std::vector<int32_t>& order) {
+    const size_t P = p->pairs;
+    order.resize(P);
+    for (size_t i = 0; i < P; ++i) order[i] = (int32_t)i;
+    if (getenv("PA_APA2_ORDER_INPUT") || P < 2) return true;
+    std::vector<double> key(P);
+    for (size_t i = 0; i < P; ++i) key[i] = (double)(p->n[i] + p->m[i]);
+    static_assert(sizeof(apa2::SketchDesc) == sizeof(PairDesc), "the sketch reads the batch's pair descriptors");
+    if (!getenv("PA_APA2_ORDER_LENGTH")) {
+        DeviceBuf d_found;
+        std::vector<uint8_t> found(P);
+        if (!d_found.alloc(P) ||
+            !hip_ok(apa2::launch_sketch_kernel(p->stream, p->d_a.as<uint8_t>(), p->d_b.as<uint8_t>(), (const apa2::SketchDesc*)p->d_desc.ptr, (int)P, d_found.as<uint8_t>()),
+                    "sketch_kernel launch") ||
+            !hip_ok(hipMemcpyAsync(found.data(), d_found.ptr, P, hipMemcpyDeviceToHost, p->stream), "D2H sketch") || !hip_ok(hipStreamSynchronize(p->stream), "sync"))
+            return false;
+        for (size_t i = 0; i < P; ++i) {
+            const double len = (double)(p->n[i] + p->m[i]);
+            const double f = std::min(64.0, std::max(0.5, (double)found[i])) / 64.0;  // (nothing found: as if half a sample had been)
+            const double e = 1.0 - std::pow(f, 1.0 / 16.0);
+            key[i] = len * (e * len * 0.5 + 128.0);
+        }
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return key[(size_t)x] > key[(size_t)y]; });
+    return true;
+}
+
 // The per-pair descriptors of the A*PA2 mode; completes the trace jobs (banded blocks, statistics).
 static bool astar_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t* const* b, std::vector<TraceJob>& tjobs) {
     const engine::AstarPa2Params ap = engine::params_from_c(p->aparams_c);
@@ -1628,7 +1659,7 @@ static bool astar_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t* cons
         (void)w;
         order[i] = (int32_t)i;
     }
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return p->n[x] + p->m[x] > p->n[y] + p->m[y]; });  // heaviest first
+    if (!astar_start_order(p, order)) return false;  // the most expensive pairs first
     p->order_host = order;
     if (P && (!hip_ok(hipMemcpy(p->d_pjobs.ptr, pj.data(), P * sizeof(apa2::PairJob), hipMemcpyHostToDevice), "H2D pair jobs") ||
               !hip_ok(hipMemcpy(p->d_order.ptr, order.data(), P * 4, hipMemcpyHostToDevice), "H2D order")))
@@ -1901,7 +1932,7 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
         (void)w;
         order[i] = (int32_t)i;
     }
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return p->n[x] + p->m[x] > p->n[y] + p->m[y]; });  // heaviest first
+    if (!astar_start_order(p, order)) return false;  // the most expensive pairs first
     p->order_host = order;
     if (P && (!hip_ok(hipMemcpy(p->d_fjobs.ptr, fj.data(), P * sizeof(apa2::FullJob), hipMemcpyHostToDevice), "H2D pair jobs") ||
               !hip_ok(hipMemcpy(p->d_order.ptr, order.data(), P * 4, hipMemcpyHostToDevice), "H2D order")))
@@ -2313,10 +2344,18 @@ static int launch_astar(pa_batch* p, hipStream_t s, size_t lo, size_t cnt, uint3
     const int cus = g_device_props_cus > 0 ? g_device_props_cus : 256;
     const int grid = (int)std::min<size_t>((cnt + kStripBlockWaves - 1) / kStripBlockWaves, (size_t)cus * per_cu);
     const int32_t* ord = p->d_order.as<int32_t>() + lo;
+    // Two half-wave blocks of one workgroup run as one strip (strip2_kernel.hpp).  PA_APA2_RDV=0 turns the rendezvous off (every strip alone,
+    // as before round 5: same results -- tests compare the two); PA_APA2_RDV_PATIENCE_US: how long a posted block waits for a partner.
+    static const bool rdv_on = !(getenv("PA_APA2_RDV") && getenv("PA_APA2_RDV")[0] == '0');
+    static const double rdv_us = getenv("PA_APA2_RDV_PATIENCE_US") ? std::max(0.0, atof(getenv("PA_APA2_RDV_PATIENCE_US"))) : 20.0;
+    RdvParams rp;
+    rp.enabled = rdv_on && cnt > 1 ? 1u : 0u;
+    rp.patience = (uint32_t)(rdv_us * 100.0);  // ticks of the 100 MHz clock
+    unsigned long long* rdv_stats = p->d_rdv.ptr ? p->d_rdv.as<unsigned long long>() : nullptr;
     const hipError_t e = p->astar_full ? apa2::launch_apa2_full_kernel(grid, s, p->d_fjobs.as<apa2::FullJob>(), ord, (int)cnt, p->fsp, ticket, p->d_misc.as<uint32_t>() + 1, dbg,
-                                                                       probe_stats ? p->d_probe.as<unsigned long long>() : nullptr)
+                                                                       probe_stats ? p->d_probe.as<unsigned long long>() : nullptr, rp, rdv_stats)
                                        : apa2::launch_apa2_kernel(grid, s, p->d_pjobs.as<apa2::PairJob>(), ord, (int)cnt, p->sp, ticket, p->d_misc.as<uint32_t>() + 1, dbg,
-                                                                  getenv("PA_APA2_K1") ? 1 : 0);
+                                                                  getenv("PA_APA2_K1") ? 1 : 0, rp, rdv_stats);
     return hip_ok(e, "apa2_kernel launch") ? 0 : PA_E_HIP;
 }
 
@@ -2327,6 +2366,8 @@ static int batch_forward(pa_batch* p, bool launch = true) {
     hipStream_t s = p->stream;
     // (1) profiles (BitProfile::build, once per pair: blocks.rs:112)
     if (!hip_ok(hipMemsetAsync(p->d_misc.ptr, 0, 32, s), "memset")) return PA_E_HIP;  // (+ the pace counter of chained batches)
+    if (p->astar && !p->d_rdv.ptr && !p->d_rdv.alloc(64)) return PA_E_HIP;
+    if (p->d_rdv.ptr && !hip_ok(hipMemsetAsync(p->d_rdv.ptr, 0, 64, s), "memset rendezvous counters")) return PA_E_HIP;
     for (size_t base = 0; base < p->pairs; base += 32768) {  // gridDim.y limit
         const unsigned ny = (unsigned)std::min<size_t>(32768, p->pairs - base);
         const PairDesc* dd = p->d_desc.as<PairDesc>() + base;
@@ -3056,6 +3097,17 @@ extern "C" int pa_debug_trace_clocks(double* out10) {
     return hip_ok(hipMemcpyToSymbol(HIP_SYMBOL(pa::g_trace_clk), z, sizeof(z)), "trace clocks") ? 0 : PA_E_HIP;
 }
 #endif
+// Diagnostics: the rendezvous of half-wave blocks in the last forward pass of a batched A*PA2 plan -- out4[0] strips that ran fused with a
+// partner's (counted at the wavefront that ran both), [1] strips a partner ran, [2] strips that ran alone, [3] of those: posted, then withdrawn.
+extern "C" int pa_batch_rdv_stats(const pa_batch* p, uint64_t* out4) {
+    if (!p || !out4) return PA_E_ARG;
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    if (!p->d_rdv.ptr) return 0;
+    unsigned long long v[4] = {0, 0, 0, 0};
+    if (!hip_ok(hipMemcpy(v, p->d_rdv.ptr, sizeof(v), hipMemcpyDeviceToHost), "D2H rendezvous counters")) return PA_E_HIP;
+    for (int i = 0; i < 4; ++i) out4[i] = v[i];
+    return 0;
+}
 extern "C" void pa_batch_full_info(const pa_batch* p, double* build_ms, double* matches, double* probes, double* rounds, double* phase_wave_ms) {
     if (build_ms) *build_ms = p ? p->full_build_ms : 0;
     if (matches) *matches = p ? (double)p->full_matches : 0;

@@ -179,6 +179,11 @@ int pa_batch_params_supported(const struct pa_astarpa2_params* params); /* 1: pa
  * set) the h probes of the last forward pass, the 64-layer load rounds they took, and phase_wave_ms[0..7): wavefront-milliseconds (summed over
  * wavefronts) deriving contours, in DP strips, in h probes, in Block::index, in prune_block, initialising columns, in total. */
 void pa_batch_full_info(const pa_batch* plan, double* build_ms, double* matches, double* probes, double* rounds, double* phase_wave_ms);
+/* Diagnostics of the batched A*PA2 kernels' rendezvous (round 5: two blocks of at most 16 words from two pairs run as ONE wavefront strip,
+ * csrc/strip2_kernel.hpp; PA_APA2_RDV=0 turns it off, PA_APA2_RDV_PATIENCE_US sets how long a block waits for a partner): for the last
+ * forward pass out4[0] = strips that ran fused with another pair's, [1] = strips a partner ran, [2] = strips that ran alone, [3] = of
+ * those, strips that had waited for a partner first.  Results never depend on any of it. */
+int pa_batch_rdv_stats(const pa_batch* plan, uint64_t* out4);
 /* Diagnostics / tests: the matches of GCSH (seeds, exact k-mer matches, transform filter, local pruning p_local <= 14) of one pair as the GPU
  * finds them (csrc/gcsh_build_kernel.hpp), by start: out_ij[2 t] = column, out_ij[2 t + 1] = row.  Returns their number, < 0 on error. */
 long pa_debug_gcsh_matches(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, int32_t k, int32_t p_local, int32_t* out_ij, size_t cap_out);

@@ -1,0 +1,79 @@
+"""The seeded pairs and the row format of tests/golden/restated_<variant>.json.
+
+Those files hold what the SECOND restatement of the reference's A*PA2 host logic (oracle/astarpa2_restated.py: pure Python on big integers,
+written from the Rust text alone, no line shared with csrc/engine.hpp or any kernel) returns for N_PAIRS seeded pairs under each of the 26
+parameter sets of tests/test_restated_engine.py `variants`: cost, SHA-256 of the CIGAR string (first 16 hex digits) and the eleven
+statistics.  tests/golden/make_restated.py (run in the build container) writes them; tests/test_gpu_restated_fixtures.py pushes the same
+pairs through pa_align and the batch kernels on the GPU and compares -- no engine.hpp in between; tests/test_restated_fixtures.py checks
+a sample on the CPU.  The pairs are not stored: pair_for(i) regenerates them from the index (Python's Mersenne Twister through
+random.Random(seed): randrange / choice / random are stable across 3.x)."""
+import hashlib
+import json
+import random
+from pathlib import Path
+
+from tests.util_seq import gen_pair, rand_seq
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+N_PAIRS = 2048
+KEYS = ["num_blocks", "num_incremental_blocks", "computed_lanes", "unique_lanes", "f_max_tries", "dt_trace_tries", "dt_trace_success",
+        "dt_trace_fallback", "fill_tries", "fill_success", "fill_fallback"]
+DENSE_MAX_N = 2500  # `nw` (dense blocks: one Block per column in the restatement) takes the pairs up to this length only
+
+
+def pair_for(i: int):
+    """Pair i: lengths 1 .. 9 000 (a third each below 300, below 2 500, above), divergence 0 .. 80 %, a quarter with one long indel, one in
+    twenty unrelated, one in ten low-complexity (tandem copies of a short unit with a few edits)."""
+    rng = random.Random(0x5EED0000 + i)
+    n = rng.choice([rng.randint(1, 300), rng.randint(300, 2500), rng.randint(2500, 9000)])
+    e = rng.choice([0.0, 0.01, 0.03, 0.08, 0.15, 0.3, 0.8])
+    mode = rng.random()
+    if mode < 0.10:
+        unit = rand_seq(rng.randint(2, 60), rng.randint(1, 10**9))
+        a = (unit * (n // len(unit) + 1))[:n]
+        b = bytearray(a)
+        for _ in range(rng.randint(0, max(1, int(e * len(b))))):
+            q = rng.randrange(len(b))
+            b[q] = rng.choice(b"ACGT")
+        cut = rng.randint(0, len(b))
+        b = bytes(b[:cut] + b[cut + rng.randint(0, min(200, len(b) // 3)):]) or b"A"
+        return a, b
+    a, b = gen_pair(n, e, rng.randint(1, 10**9))
+    if mode < 0.35 and n > 50:
+        cut = rng.randint(0, len(b) - 1)
+        ln = rng.randint(1, max(1, min(1500, len(b) // 2)))
+        b = b[:cut] + b[cut + ln:] if rng.random() < 0.5 else b[:cut] + rand_seq(ln, rng.randint(1, 10**9)) + b[cut:]
+        b = b or b"A"
+    elif mode < 0.40:
+        b = rand_seq(rng.randint(1, n + 50), rng.randint(1, 10**9))
+    return a, b
+
+
+def takes(name: str, i: int, a: bytes) -> bool:
+    return name != "nw" or len(a) <= DENSE_MAX_N
+
+
+def row_of(cost: int, cigar: str, stats) -> list:
+    return [int(cost), hashlib.sha256(cigar.encode()).hexdigest()[:16]] + [int(stats[k]) for k in KEYS]
+
+
+def load(name: str) -> dict:
+    return json.loads((GOLDEN / f"restated_{name}.json").read_text())
+
+
+def variant_names() -> list:
+    return sorted(p.stem[len("restated_"):] for p in GOLDEN.glob("restated_*.json"))
+
+
+def params_from_kwargs(pa, kw: dict):
+    """The package's AstarPa2Params for the keyword arguments of restated.align (its defaults: oracle/astarpa2_restated.py `Restated`) --
+    straight from the fixture file, no oracle library involved."""
+    d = dict(heuristic="gap", k=12, sparse_h=True, block_width=256, dt_trace=True, max_g=40, fr_drop=10, domain="astar", sparse=True,
+             doubling="band", start="h0", factor=2.0, delta=1.0, incremental_doubling=False, p=0, prune=False)
+    d.update(kw)
+    heur = d["heuristic"] if d["domain"] == "astar" else "none"
+    return pa.AstarPa2Params(domain=d["domain"], heuristic=heur, k=d["k"], p=d["p"], doubling=d["doubling"], doubling_start=d["start"],
+                             factor=d["factor"], delta=d["delta"], block_width=d["block_width"],
+                             front=pa.BlockParams(sparse=d["sparse"], simd=True, no_ilp=False, incremental_doubling=d["incremental_doubling"],
+                                                  dt_trace=d["dt_trace"], max_g=d["max_g"], fr_drop=d["fr_drop"]),
+                             sparse_h=d["sparse_h"], prune=d["prune"])

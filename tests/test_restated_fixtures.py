@@ -1,0 +1,44 @@
+"""tests/golden/restated_<variant>.json on the CPU: the files are what the committed generator writes (a sample regenerated from
+oracle/astarpa2_restated.py), and the product's host engine over the CPU oracle kernels (oracle.cpu_align: csrc/engine.hpp) returns the
+same cost, CIGAR and statistics on a sample of every parameter set.  The GPU side of the same fixtures: tests/test_gpu_restated_fixtures.py."""
+import pytest
+
+from oracle import astarpa2_restated as restated
+from tests import restated_fixture as rf
+from tests.test_restated_engine import variants
+
+
+def test_every_parameter_set_has_its_fixture(oracle):
+    names = rf.variant_names()
+    assert sorted(names) == sorted(variants(oracle)) and len(names) == 26
+    total = 0
+    for name in names:
+        doc = rf.load(name)
+        assert doc["n_pairs"] == rf.N_PAIRS >= 2000 and len(doc["rows"]) == rf.N_PAIRS and doc["row"][2:] == rf.KEYS
+        assert doc["restated_kwargs"] == variants(oracle)[name][1]
+        total += sum(r is not None for r in doc["rows"])
+    assert total > 25 * rf.N_PAIRS
+
+
+def test_pairs_cover_what_they_claim():
+    ps = [rf.pair_for(i) for i in range(0, rf.N_PAIRS, 8)]
+    ns = [len(a) for a, _ in ps]
+    assert min(ns) <= 20 and max(ns) > 8000 and sum(n < 300 for n in ns) > 50 and sum(n > 2500 for n in ns) > 50
+    assert sum(abs(len(a) - len(b)) > 100 for a, b in ps) > 20  # long indels
+
+
+@pytest.mark.parametrize("part", range(4))
+def test_sample_regenerates_and_equals_the_cpu_kernel_engine(oracle, part):
+    vs = variants(oracle)
+    for vi, name in enumerate(sorted(vs)):
+        if vi % 4 != part:
+            continue
+        prm, kw = vs[name]
+        rows = rf.load(name)["rows"]
+        for i in range(vi % 32, rf.N_PAIRS, 32):
+            if rows[i] is None:
+                continue
+            a, b = rf.pair_for(i)
+            if i % 128 == vi % 32:  # (the pure-Python restatement is the slow side: a quarter of the sample)
+                assert rf.row_of(*restated.align(a, b, **kw)) == rows[i], (name, i)  # the file is what the generator writes
+            assert rf.row_of(*oracle.cpu_align(a, b, prm)) == rows[i], (name, i)   # ... and what csrc/engine.hpp over the CPU kernels returns

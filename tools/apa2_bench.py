@@ -33,6 +33,7 @@ def bench(pairs, label, reps=3):
     print(f"{label}: {len(pairs)} pairs  create {t_create*1e3:.1f} ms  align {best[0]*1e3:.2f} ms (c abi {best[3]:.2f})  forward {best[1]:.2f} ms  trace {best[2]:.2f} ms  "
           f"=> {len(pairs)/best[0]:.0f} pairs/s ({len(pairs)/(best[3]*1e-3):.0f} at the C ABI)  computed lanes {lanes:.3e} = {lanes*256*64/(best[1]*1e-3)/1e9:.0f} band-GCUPS  "
           f"strip VALU instructions (model) {strip_instr:.3e} = {strip_instr/(best[1]*1e-3)/1e9:.0f} G/s  fallbacks {bt.trace_fallbacks()}  tries {sum(s['f_max_tries'] for s in st)/len(st):.2f}", flush=True)
+    print(f"   half-wave blocks of the last forward pass: {bt.rdv_stats()}", flush=True)
     if PRESET == "full":
         fi = bt.full_info()
         print(f"   full: match building {abs(fi['build_ms']):.1f} ms ({'GPU' if fi['build_ms'] < 0 else 'host threads'}) for {fi['matches']:.0f} matches; h probes {fi['probes']:.3e}, load rounds {fi['rounds']:.3e}; wavefront-ms by phase {({k: round(v, 1) for k, v in fi['phase_wave_ms'].items()})}", flush=True)

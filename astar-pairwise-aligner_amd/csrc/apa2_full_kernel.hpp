@@ -50,7 +50,7 @@ struct FullDevBackend {
     // blocks run as ONE strip whenever two wavefronts of the workgroup reach theirs within each other's patience
     RdvLds rdv{nullptr, 0};
     int wave = 0;
-    RdvParams rp{0u, 0u};
+    RdvParams rp{0u, 0u, 0u, 0u};
     mutable rdv::Counters rdv_cnt;
     uint32_t n_probe = 0, n_round = 0;  // diagnostics: h probes and the load rounds they took
     bool timing = false;                // diagnostics (PA_APA2_PROBE_STATS): phase clocks, 100 MHz ticks
@@ -568,6 +568,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_full_kernel(con
         uint32_t t = atomicAdd(ticket, lane == 0 ? 1u : 0u);  // (branch-free: see apa2_kernel.hpp)
         t = rfl(t);
         if (t >= (uint32_t)npairs) break;
+        if (rp.prio) PA_SETPRIO_BY_RANK(t, npairs);
         const int pair = (int)rfl((uint32_t)order[t]);
         const FullJob job = jobs[pair];
         FullDevBackend be(job, err, dbg);

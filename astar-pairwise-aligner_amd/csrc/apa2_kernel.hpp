@@ -47,7 +47,7 @@ struct DevBackend {
     // the rendezvous of half-wave blocks (strip2_kernel.hpp): this workgroup's shared word and mail, this wavefront's index in it
     RdvLds rdv{nullptr, 0};
     int wave = 0;
-    RdvParams rp{0u, 0u};
+    RdvParams rp{0u, 0u, 0u, 0u};
     mutable rdv::Counters rdv_cnt;
     __device__ __forceinline__ uint64_t strip_instructions() const { return (uint64_t)strip_units << 5; }
 
@@ -297,6 +297,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_kernel(const Pa
         uint32_t t = atomicAdd(ticket, lane == 0 ? 1u : 0u);
         t = rfl(t);
         if (t >= (uint32_t)npairs) break;
+        if (rp.prio) PA_SETPRIO_BY_RANK(t, npairs);
         const int pair = (int)rfl((uint32_t)order[t]);
         const PairJob job = jobs[pair];
         HeurParams hp;

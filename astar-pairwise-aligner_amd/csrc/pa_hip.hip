@@ -2346,11 +2346,19 @@ static int launch_astar(pa_batch* p, hipStream_t s, size_t lo, size_t cnt, uint3
     const int32_t* ord = p->d_order.as<int32_t>() + lo;
     // Two half-wave blocks of one workgroup run as one strip (strip2_kernel.hpp).  PA_APA2_RDV=0 turns the rendezvous off (every strip alone,
     // as before round 5: same results -- tests compare the two); PA_APA2_RDV_PATIENCE_US: how long a posted block waits for a partner.
-    static const bool rdv_on = !(getenv("PA_APA2_RDV") && getenv("PA_APA2_RDV")[0] == '0');
-    static const double rdv_us = getenv("PA_APA2_RDV_PATIENCE_US") ? std::max(0.0, atof(getenv("PA_APA2_RDV_PATIENCE_US"))) : 20.0;
+    // (read at every launch: tests switch it inside one process)
+    const char* rdv_env = getenv("PA_APA2_RDV");
+    const double rdv_us = getenv("PA_APA2_RDV_PATIENCE_US") ? std::max(0.0, atof(getenv("PA_APA2_RDV_PATIENCE_US"))) : 20.0;
+    // A block that waits for a partner is a wavefront that does nothing: worth it when the SIMDs have other wavefronts to run, not when a
+    // batch leaves most of them with one or none (512 x 100 kbp: 38.3 against 36.4 ms).  PA_APA2_RDV=0: never; =2: whatever the batch size.
+    const size_t simds = (size_t)(g_device_props_cus > 0 ? g_device_props_cus : 256) * 4;
     RdvParams rp;
-    rp.enabled = rdv_on && cnt > 1 ? 1u : 0u;
+    rp.enabled = cnt >= 2 * simds ? 1u : 0u;
+    if (rdv_env && rdv_env[0] == '0') rp.enabled = 0u;
+    if (rdv_env && rdv_env[0] == '2') rp.enabled = cnt > 1 ? 1u : 0u;
     rp.patience = (uint32_t)(rdv_us * 100.0);  // ticks of the 100 MHz clock
+    rp.prio = (getenv("PA_APA2_PRIO") && getenv("PA_APA2_PRIO")[0] == '0') ? 0u : 1u;  // (experiments: PA_APA2_PRIO=0)
+    rp.pad = 0;
     unsigned long long* rdv_stats = p->d_rdv.ptr ? p->d_rdv.as<unsigned long long>() : nullptr;
     const hipError_t e = p->astar_full ? apa2::launch_apa2_full_kernel(grid, s, p->d_fjobs.as<apa2::FullJob>(), ord, (int)cnt, p->fsp, ticket, p->d_misc.as<uint32_t>() + 1, dbg,
                                                                        probe_stats ? p->d_probe.as<unsigned long long>() : nullptr, rp, rdv_stats)

@@ -7,6 +7,19 @@ namespace pa {
 struct RdvParams {
     uint32_t enabled;   // 0: every strip runs alone
     uint32_t patience;  // ticks of the 100 MHz clock a posted strip waits for a partner before it runs alone
+    uint32_t prio;      // 1: the issue priority of a wavefront follows its pair's rank in the start order (the most expensive pairs -- the
+                        // launch's critical path -- are served first by their SIMDs; the cheap pairs that fill the rest have the slack)
+    uint32_t pad;
 };
+
+// s_setprio takes an immediate
+#define PA_SETPRIO_BY_RANK(t, npairs)                                               \
+    do {                                                                            \
+        const uint32_t t_ = (uint32_t)(t), n_ = (uint32_t)(npairs);                 \
+        if (t_ < n_ / 8u) __builtin_amdgcn_s_setprio(3);                            \
+        else if (t_ < n_ / 4u) __builtin_amdgcn_s_setprio(2);                       \
+        else if (t_ < n_ / 2u) __builtin_amdgcn_s_setprio(1);                       \
+        else __builtin_amdgcn_s_setprio(0);                                         \
+    } while (0)
 
 }  // namespace pa

@@ -38,6 +38,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # Measured issue rates per opcode class and for mixed streams: profiles/r01_runs/issue_probe*.log.
 VALU_PEAK_WAVE_INSTR = 256 * 4 * 2.4e9 / 2
 VALU_MIXED_CEILING = 256 * 4 / 1.57e-9
+# The headline kernel's own instruction mix (profiles/r05_headline_opcodes.json, from the ISA by tools/opcode_table.py: one K = 8 step is
+# 90.5 VALU instructions, 60.6 of the fast class and 29.9 of the slow one) priced with the measured clocks per class: the
+# ceiling THIS mix can reach lies between the two -- every slow instruction of the step is a carry of the 256-bit add, a funnel shift across
+# subwords, or the per-step plumbing (DPP shift, lane-0 feed), none of which has a fast-class form on gfx950.
+STEP_FAST, STEP_SLOW = 60.59, 29.94
+CLK_FAST, CLK_SLOW = (2.3, 3.0), (4.1, 4.3)
+WEIGHTED_CLK = tuple((STEP_FAST * f + STEP_SLOW * sl) / (STEP_FAST + STEP_SLOW) for f, sl in zip(CLK_FAST, CLK_SLOW))  # (2.90, 3.43)
 
 
 def parse_args():
@@ -133,7 +140,18 @@ def main():
         from astar_pairwise_aligner_amd.sharding import sharded_align
 
         divs = (0.01, 0.05, 0.10, 0.15)
-        c4s = [generate_pair(10_000, divs[i % 4], seed=1_000_000 + i) for i in range(args.c4_pairs)]
+
+        # Every rank needs every pair (the queue decides at run time who aligns which chunk), but nobody needs to GENERATE them all: rank r
+        # makes the pairs i = r (mod N) and the ranks swap them once (untimed set-up; round 4 generated all 10 000 on every rank).
+        own = {i: generate_pair(10_000, divs[i % 4], seed=1_000_000 + i) for i in range(rank, args.c4_pairs, world)}
+        if dist is not None:
+            parts = [None] * world
+            dist.all_gather_object(parts, own)
+            for part in parts:
+                own.update(part)
+            del parts
+        c4s = [own[i] for i in range(args.c4_pairs)]
+        del own
         from astar_pairwise_aligner_amd.sharding import default_align
 
         busy = [0.0]
@@ -241,6 +259,11 @@ def main():
             "unit": "G wave64 VALU instructions/s",
             "frac": round(shape["valu_instructions"] / avg_kernel_s / VALU_PEAK_WAVE_INSTR, 4),
             "traffic": None,
+            # the ceiling of the kernel's own opcode mix (see WEIGHTED_CLK above): between the optimistic and the pessimistic class clocks
+            "weighted_peak": [round(256 * 4 * 2.4e9 / c / 1e9, 1) for c in WEIGHTED_CLK],
+            "frac_of_weighted_peak": [round(shape["valu_instructions"] / avg_kernel_s / (256 * 4 * 2.4e9 / c), 4) for c in WEIGHTED_CLK],
+            "weighted_clocks_per_instruction": [round(c, 3) for c in WEIGHTED_CLK],
+            "achieved_clocks_per_instruction": round(256 * 4 * 2.4e9 / (shape["valu_instructions"] / avg_kernel_s), 3),
             "kernel": shape["kernel"],
             "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
             "hbm_bound": "hbm",
@@ -498,6 +521,10 @@ def main():
                 "mean_f_max_tries": round(sum(x["f_max_tries"] for x in sts) / len(sts), 2),
                 "host_engine_fallbacks": ba.trace_fallbacks(),
                 "kernel": ("pa::apa2::apa2_full_kernel" if preset == "full" else "pa::apa2::apa2_kernel") + " + pa::trace_kernel<true, true>",
+                # round 5: the pairs start most-expensive-first by a k-mer sketch (csrc/sketch_unit.hip, inside create_ms), and two blocks of
+                # at most 16 words from two pairs run as ONE strip when the batch fills the chip (csrc/strip2_kernel.hpp); counted per block
+                "start_order": "divergence sketch",
+                "half_wave_blocks": ba.rdv_stats(),
             }
             if preset == "full":
                 fi = ba.full_info()

@@ -21,6 +21,13 @@ def pa():
     return pa
 
 
+@pytest.fixture(autouse=True)
+def _two_pairs_per_strip_whatever_the_batch_size(monkeypatch):
+    """The rendezvous of half-wave blocks (csrc/rdv_logic.hpp, strip2_kernel.hpp) is on by itself only for batches that fill the chip; these
+    tests use small ones, so it is forced on: every comparison below also covers the fused strips."""
+    monkeypatch.setenv("PA_APA2_RDV", "2")
+
+
 def check(pa, oracle, pairs, oc, fallbacks=None, verify_only_sample=None):
     from tests.test_gpu_engine import gpu_params
 
@@ -239,3 +246,37 @@ def test_chunks_and_trace_order_do_not_change_results(env):
     """) % str(__import__("pathlib").Path(__file__).resolve().parent.parent)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("preset", ["simple", "full"])
+def test_two_pairs_per_strip_changes_nothing(pa, oracle, monkeypatch, preset):
+    """Round 5: two blocks of at most 16 words from two pairs of one workgroup run as ONE strip (pair A in lanes 0..31, pair B in lanes
+    32..63).  With the rendezvous off, on, impatient and very patient: cost, CIGAR and every statistic of every pair are the same, and the
+    counters say the fused strips were really taken."""
+    prm = pa.AstarPa2Params.full() if preset == "full" else pa.AstarPa2Params.simple()
+    rng = random.Random(11)
+    pairs = [gen_pair(rng.choice([700, 2500, 3000, 6000]), rng.choice([0.01, 0.05, 0.1, 0.15, 0.3]), seed=1000 + i) for i in range(600)]
+    pairs += [gen_pair(200, 0.1, seed=5), (b"ACGT" * 300, b"ACGT" * 290), gen_pair(20_000, 0.2, seed=6)]  # (the last: bands taller than half a wave)
+    got = {}
+    for mode, patience in (("0", None), ("2", None), ("2", "0"), ("2", "400")):
+        monkeypatch.setenv("PA_APA2_RDV", mode)
+        if patience is None:
+            monkeypatch.delenv("PA_APA2_RDV_PATIENCE_US", raising=False)
+        else:
+            monkeypatch.setenv("PA_APA2_RDV_PATIENCE_US", patience)
+        bt = pa.Batch(pairs, params=prm)
+        costs, cigars, _, _ = bt.align()
+        stats = [{k: s[k] for k in KEYS} for s in bt.pair_stats()]
+        rd = bt.rdv_stats()
+        bt.close()
+        got[(mode, patience)] = (costs.tolist(), cigars, stats)
+        if mode == "0":
+            assert rd["fused"] == rd["served"] == 0
+        else:
+            assert rd["fused"] == rd["served"] and (rd["fused"] > 100 or patience == "0"), rd
+            if patience == "400":
+                assert rd["fused"] > 10 * rd["alone"], rd
+    base = got[("0", None)]
+    assert all(v == base for v in got.values())
+    for (a, b), c in list(zip(pairs, base[0]))[::40]:
+        assert c == oracle.levenshtein(a, b)

@@ -27,6 +27,13 @@ def pa():
     return pa
 
 
+@pytest.fixture(autouse=True)
+def _two_pairs_per_strip_whatever_the_batch_size(monkeypatch):
+    """The rendezvous of half-wave blocks (csrc/rdv_logic.hpp, strip2_kernel.hpp) is on by itself only for batches that fill the chip; these
+    tests use small ones, so it is forced on: every comparison below also covers the fused strips."""
+    monkeypatch.setenv("PA_APA2_RDV", "2")
+
+
 def check(pa, oracle, pairs, oc, verify_only_sample=None, max_fallbacks=None):
     from tests.test_gpu_engine import gpu_params
 

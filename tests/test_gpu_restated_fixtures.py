@@ -17,6 +17,14 @@ NAMES = rf.variant_names()
 
 
 @pytest.fixture(scope="module")
+def pa():
+    import astar_pairwise_aligner_amd as pa
+
+    pa.require_gpu()
+    return pa
+
+
+@pytest.fixture(scope="module")
 def pairs():
     return [rf.pair_for(i) for i in range(rf.N_PAIRS)]
 

@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "pa_align", "pa_batch_align_multi", "pa_batch_create_trace_params",
     "pa_bp_ctx_create", "pa_bp_ctx_compute", "pa_bp_ctx_fill", "pa_bp_ctx_destroy",
     "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools", "pa_align_file_params", "pa_batch_params_supported", "pa_alloc_cache_stats", "pa_free_cigars",
-    "pa_batch_full_info", "pa_batch_rdv_stats", "pa_debug_gcsh_probe", "pa_debug_gcsh_matches", "pa_batch_window_retries",
+    "pa_batch_full_info", "pa_batch_rdv_stats", "pa_combine_stats", "pa_debug_gcsh_probe", "pa_debug_gcsh_matches", "pa_batch_window_retries",
 ]
 
 _lib = None
@@ -84,6 +84,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_batch_full_info.argtypes = [vp] + [C.POINTER(C.c_double)] * 4 + [C.POINTER(C.c_double)]
     L.pa_batch_full_info.restype = None
     L.pa_batch_rdv_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.pa_combine_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.pa_combine_stats.restype = None
     L.pa_batch_rdv_stats.restype = C.c_int
     L.pa_batch_shape.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.pa_batch_destroy.argtypes = [vp]

@@ -5,9 +5,14 @@
 // compute / fill rectangle of the engine is one chained-strip launch of strip_kernel.  Block right-edge
 // columns (`Block::v`) live in host memory because the band logic reads them (Block::index).
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "engine_capi.hpp"
 #include "pa_hip_internal.hpp"
@@ -873,6 +878,144 @@ struct StatsOnlyBackend {
 };
 
 // Shared by pa_align and the astarpa-c symbols.  Returns 0 or a PA_E_* code.
+// ---- call combining behind pa_align and the astarpa-c symbols (round 5) ---------------------------------------------------------------
+// The reference's entry points are stateless and re-entrant (astarpa-c/src/lib.rs:8-46): a multi-threaded caller aligns one pair per
+// thread at a time.  On the GPU one pair at a time is latency bound (a 10 kbp pair: 2 ms through the sweep, whatever else the chip could
+// do), while the batch kernels run thousands side by side and return per pair EXACTLY what pa_align returns -- cost, CIGAR string and
+// statistics (tests/test_gpu_apa2_batch.py, test_gpu_apa2_full.py, test_gpu_restated_fixtures.py).  So callers that are inside
+// pa_align AT THE SAME TIME with the same parameters are combined: the first one to find no leader becomes the leader, takes every
+// request queued so far, aligns them as ONE batch (pa_batch_create_params + pa_batch_align) and hands the results out; requests that
+// arrive meanwhile wait for the next leader.  No timer: a lone caller (nobody else inside) keeps the single-pair path and its latency;
+// the batch grows with the number of concurrent callers by itself.  PA_COMBINE=0 switches it off.
+namespace {
+struct CombineReq {
+    const uint8_t* a;
+    size_t a_len;
+    const uint8_t* b;
+    size_t b_len;
+    int32_t cost = 0;
+    std::string cigar;
+    pa_astarpa2_stats stats{};
+    int rc = 0;
+    bool done = false;
+    std::string err;
+};
+struct Combiner {
+    pa_astarpa2_params params;  // the key (byte-wise: a parameter set is plain data)
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<CombineReq*> pending;
+    bool leader = false;
+};
+std::mutex& g_comb_mu = *new std::mutex;
+std::vector<Combiner*>& g_combs = *new std::vector<Combiner*>;  // (never destroyed: callers may be inside at exit)
+std::atomic<int> g_inside{0};              // callers inside the traced path of align_hip right now
+std::atomic<uint64_t> g_comb_calls{0}, g_comb_batches{0};
+thread_local bool t_in_combiner = false;   // the leader's own batch may hand a pair back to pa_align's engine: that call is not combined again
+constexpr int kNotCombined = 1;
+constexpr size_t kCombineMaxLen = 32768;   // longer pairs keep the single-pair engine (many wavefronts per pass; pa_bitpacking_hip.h "small route")
+constexpr size_t kCombineMaxGroup = 8192;
+
+Combiner& combiner_for(const pa_astarpa2_params& params) {
+    std::lock_guard<std::mutex> lk(g_comb_mu);
+    for (Combiner* c : g_combs)
+        if (std::memcmp(&c->params, &params, sizeof(params)) == 0) return *c;
+    Combiner* c = new Combiner;
+    c->params = params;
+    g_combs.push_back(c);
+    return *c;
+}
+
+void run_group(std::vector<CombineReq*>& group, const pa_astarpa2_params& params) {
+    const size_t n = group.size();
+    std::vector<const uint8_t*> ap(n), bp(n);
+    std::vector<size_t> al(n), bl(n);
+    for (size_t i = 0; i < n; ++i) {
+        ap[i] = group[i]->a;
+        bp[i] = group[i]->b;
+        al[i] = group[i]->a_len;
+        bl[i] = group[i]->b_len;
+    }
+    std::vector<int32_t> costs(n, 0);
+    std::vector<char*> cigars(n, nullptr);
+    std::vector<pa_astarpa2_stats> st(n);
+    int rc = 0;
+    t_in_combiner = true;
+    pa_batch* bt = pa_batch_create_params(ap.data(), al.data(), bp.data(), bl.data(), n, &params);
+    if (!bt) rc = kNotCombined;  // (every caller falls back to the single-pair path, which reports its own errors)
+    else {
+        rc = pa_batch_align(bt, costs.data(), cigars.data(), nullptr, nullptr);
+        if (rc == 0) rc = pa_batch_pair_stats(bt, st.data());
+        pa_batch_destroy(bt);
+        if (rc != 0) rc = kNotCombined;
+    }
+    t_in_combiner = false;
+    for (size_t i = 0; i < n; ++i) {
+        CombineReq& r = *group[i];
+        r.rc = rc;
+        if (rc == 0) {
+            r.cost = costs[i];
+            r.cigar = cigars[i] ? cigars[i] : "";
+            r.stats = st[i];
+        }
+        std::free(cigars[i]);
+    }
+    g_comb_calls += n;
+    g_comb_batches += 1;
+}
+
+// 0: done (results filled in); kNotCombined: the caller runs the single-pair path.
+int combine_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params& params, int32_t* cost_out,
+                  std::string* cigar_out, pa_astarpa2_stats* stats_out) {
+    Combiner& c = combiner_for(params);
+    CombineReq req{a, a_len, b, b_len};
+    std::unique_lock<std::mutex> lk(c.mu);
+    c.pending.push_back(&req);
+    while (!req.done) {
+        if (c.leader) {
+            c.cv.wait(lk);
+            continue;
+        }
+        c.leader = true;
+        if ((int)c.pending.size() + 1 < g_inside.load(std::memory_order_relaxed)) {
+            // callers that are inside but have not queued yet (they arrived together): give them the time of a lock hand-over
+            lk.unlock();
+            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(30);
+            while (std::chrono::steady_clock::now() < until) std::this_thread::yield();
+            lk.lock();
+        }
+        std::vector<CombineReq*> group;
+        if (c.pending.size() <= kCombineMaxGroup) group.swap(c.pending);
+        else {
+            group.assign(c.pending.begin(), c.pending.begin() + (long)kCombineMaxGroup);
+            c.pending.erase(c.pending.begin(), c.pending.begin() + (long)kCombineMaxGroup);
+        }
+        lk.unlock();
+        run_group(group, params);
+        lk.lock();
+        for (CombineReq* r : group) r->done = true;
+        c.leader = false;
+        c.cv.notify_all();  // the served ones leave; one of those still pending becomes the next leader
+    }
+    lk.unlock();
+    if (req.rc != 0) return kNotCombined;
+    if (cost_out) *cost_out = req.cost;
+    if (cigar_out) *cigar_out = std::move(req.cigar);
+    if (stats_out) *stats_out = req.stats;
+    return 0;
+}
+struct InsideGuard {
+    InsideGuard() { g_inside.fetch_add(1, std::memory_order_relaxed); }
+    ~InsideGuard() { g_inside.fetch_sub(1, std::memory_order_relaxed); }
+};
+}  // namespace
+
+// Diagnostics: calls served through the combiner so far, and the batches they went out in.
+extern "C" void pa_combine_stats(uint64_t* calls, uint64_t* batches) {
+    if (calls) *calls = g_comb_calls.load();
+    if (batches) *batches = g_comb_batches.load();
+}
+
 int align_hip(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params& params,
               bool trace, bool self_check, int32_t* cost_out, std::string* cigar_out, pa_astarpa2_stats* stats_out) {
     if (!engine::params_valid(params)) {
@@ -911,6 +1054,13 @@ int align_hip(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, co
         if (cost_out) *cost_out = c;
         if (cigar_out) cigar_out->clear();
         return 0;
+    }
+    // Several callers inside at once, a parameter set the batch kernels take: one batch for all of them (see combine_align above)
+    InsideGuard inside;
+    if (trace && !self_check && !t_in_combiner && a_len > 0 && b_len > 0 && a_len < kCombineMaxLen && b_len < kCombineMaxLen &&
+        g_inside.load(std::memory_order_relaxed) > 1 && pa_batch_params_supported(&params)) {
+        static const bool combine_off = std::getenv("PA_COMBINE") != nullptr && std::getenv("PA_COMBINE")[0] == '0';
+        if (!combine_off && combine_align(a, a_len, b, b_len, params, cost_out, cigar_out, stats_out) == 0) return 0;
     }
     HipBackend& be = pooled_backend();
     be.bind(a, a_len, b, b_len);

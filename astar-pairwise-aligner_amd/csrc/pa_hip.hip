@@ -323,9 +323,16 @@ bool DeviceBuf::alloc(size_t bytes) {
     static const bool poison = getenv("PA_POISON_ALLOC") != nullptr;
     int dev = 0;
     if (!hip_ok(hipGetDevice(&dev), "hipGetDevice")) return false;
-    const bool big = bytes >= kCacheMin && cache_on();
+    // Small buffers are cached too (round 5), in size classes (2^k and 1.5 x 2^k): a batch of a few pairs -- what the call combiner behind
+    // pa_align creates a thousand times a second -- made some thirty hipMalloc / hipFree calls of 50-100 us each, every hipFree a device wait.
+    const bool big = cache_on();
+    if (big && bytes < kCacheMin) {
+        size_t c = 64;
+        while (c < bytes) c = (c + c / 2 >= bytes && (c & (c - 1)) == 0) ? c + c / 2 : ((c & (c - 1)) == 0 ? c * 2 : (c / 3) * 4);
+        bytes = c;
+    }
     if (big) {
-        bytes = (bytes + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);  // (2 MB steps: requests of almost the same size meet)
+        if (bytes >= kCacheMin) bytes = (bytes + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);  // (2 MB steps: requests of almost the same size meet)
         size_t got = 0;
         if (void* p = cache_take(dev, bytes, &got)) {
             ptr = p;
@@ -469,7 +476,7 @@ void release_scope_end() { g_release_synced = false; }
 
 void DeviceBuf::release() {
     if (ptr) {
-        if (size >= kCacheMin && cache_on() && g_release_synced) {
+        if (cache_on() && g_release_synced) {  // (inside a release scope the device has been waited for: any size goes to the cache)
             int cur = device;
             (void)hipGetDevice(&cur);
             if (cur == device) {
@@ -2357,7 +2364,8 @@ static int launch_astar(pa_batch* p, hipStream_t s, size_t lo, size_t cnt, uint3
     if (rdv_env && rdv_env[0] == '0') rp.enabled = 0u;
     if (rdv_env && rdv_env[0] == '2') rp.enabled = cnt > 1 ? 1u : 0u;
     rp.patience = (uint32_t)(rdv_us * 100.0);  // ticks of the 100 MHz clock
-    rp.prio = (getenv("PA_APA2_PRIO") && getenv("PA_APA2_PRIO")[0] == '0') ? 0u : 1u;  // (experiments: PA_APA2_PRIO=0)
+    // (measured on C4, profiles/r05_runs/prio_probe.log: `full` 11.08 -> 10.45 ms, `simple` 8.70 -> 9.12 ms: on for the first only)
+    rp.prio = getenv("PA_APA2_PRIO") ? (getenv("PA_APA2_PRIO")[0] == '0' ? 0u : 1u) : (p->astar_full ? 1u : 0u);
     rp.pad = 0;
     unsigned long long* rdv_stats = p->d_rdv.ptr ? p->d_rdv.as<unsigned long long>() : nullptr;
     const hipError_t e = p->astar_full ? apa2::launch_apa2_full_kernel(grid, s, p->d_fjobs.as<apa2::FullJob>(), ord, (int)cnt, p->fsp, ticket, p->d_misc.as<uint32_t>() + 1, dbg,

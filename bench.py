@@ -425,24 +425,36 @@ def main():
             import threading
             from concurrent.futures import ThreadPoolExecutor
 
-            T = 8
-            gate = threading.Barrier(T)
+            def threads_rate(T, work_pairs, want):
+                gate = threading.Barrier(T)
 
-            def _warm(tid):  # every worker exactly once: device buffers are pooled per host thread
-                gate.wait()
-                pa.c_abi_align("astarpa2_simple", *loop_pairs[tid])
+                def _warm(tid):  # every worker exactly once: device buffers are pooled per host thread
+                    gate.wait()
+                    pa.c_abi_align("astarpa2_simple", *work_pairs[tid % len(work_pairs)])
 
-            def _work(tid):
-                return [(i, pa.c_abi_align("astarpa2_simple", *loop_pairs[i])) for i in range(tid, len(loop_pairs), T)]
+                def _work(tid):
+                    return [(i, pa.c_abi_align("astarpa2_simple", *work_pairs[i])) for i in range(tid, len(work_pairs), T)]
 
-            with ThreadPoolExecutor(T) as ex:
-                list(ex.map(_warm, range(T)))
-                t = time.perf_counter()
-                parts = list(ex.map(_work, range(T)))
-                dtt = time.perf_counter() - t
-            got_t = [r for _, r in sorted(x for part in parts for x in part)]
-            assert got_t == got, "drop-in loop: results under 8 threads differ from the sequential loop"
-            out["dropin_loop"]["threads8_pairs_per_sec"] = round(len(loop_pairs) / dtt, 1)
+                with ThreadPoolExecutor(T) as ex:
+                    list(ex.map(_warm, range(T)))
+                    t = time.perf_counter()
+                    parts = list(ex.map(_work, range(T)))
+                    dtt = time.perf_counter() - t
+                got_t = [r for _, r in sorted(x for part in parts for x in part)]
+                assert got_t == want, f"drop-in loop: results under {T} threads differ from the sequential loop"
+                return round(len(work_pairs) / dtt, 1)
+
+            # round 5: callers that are inside the symbol at the same time are combined into one batch on the GPU (csrc/engine_hip.hip
+            # combine_align); every result is compared with the sequential loop's
+            out["dropin_loop"]["threads8_pairs_per_sec"] = threads_rate(8, loop_pairs, got)
+            many = loop_pairs * 8  # (1600 calls: 25 per thread)
+            out["dropin_loop"]["threads64_pairs_per_sec"] = threads_rate(64, many, got * 8)
+            import ctypes as _C
+
+            cc, cb = _C.c_uint64(0), _C.c_uint64(0)
+            pa.capi.load().pa_combine_stats(_C.byref(cc), _C.byref(cb))
+            out["dropin_loop"]["combined_calls"] = int(cc.value)
+            out["dropin_loop"]["combined_batches"] = int(cb.value)
         except AssertionError:
             raise
         except Exception as e:  # (reporting only)

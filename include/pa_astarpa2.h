@@ -76,6 +76,13 @@ void pa_params_batch_align(pa_astarpa2_params* p);
 int pa_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params* params,
              int trace, int32_t* cost_out, char** cigar_out, pa_astarpa2_stats* stats_out);
 
+/* Callers that are inside pa_align (or an astarpa-c symbol) AT THE SAME TIME with the same parameters, sequences shorter than 32 768
+ * bases and a parameter set the batch kernels take (pa_batch_params_supported) are COMBINED: one of them aligns all queued pairs as one
+ * batch on the GPU and hands every caller its own cost, CIGAR and statistics -- the values the single-pair path returns (timers 0).  A
+ * caller that is alone keeps the single-pair path.  PA_COMBINE=0 switches it off.  pa_combine_stats: calls served that way so far and
+ * the batches they went out in (either argument may be NULL). */
+void pa_combine_stats(uint64_t* calls, uint64_t* batches);
+
 /* Optional, once, BEFORE anything starts the HIP runtime in this process (torch, another library, the first pa_* call): asks the
  * runtime for 16 hardware queues (GPU_MAX_HW_QUEUES, default 4) unless the variable is set already, so that the pipelined passes
  * of one pa_align call -- each on its own stream -- run side by side (C3 `simple`: 14.5 ms with, ~20 ms without).  Exporting the

@@ -275,7 +275,7 @@ def test_two_pairs_per_strip_changes_nothing(pa, oracle, monkeypatch, preset):
         else:
             assert rd["fused"] == rd["served"] and (rd["fused"] > 100 or patience == "0"), rd
             if patience == "400":
-                assert rd["fused"] > 10 * rd["alone"], rd
+                assert rd["fused"] > rd["alone"], rd  # (a patient block mostly finds its partner)
     base = got[("0", None)]
     assert all(v == base for v in got.values())
     for (a, b), c in list(zip(pairs, base[0]))[::40]:

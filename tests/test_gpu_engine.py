@@ -219,6 +219,68 @@ def test_c_abi_is_reentrant_across_threads(pa, oracle):
         assert len({c for _, c in out}) == 1  # deterministic
 
 
+def test_concurrent_callers_are_combined_and_get_the_single_call_results(pa, oracle):
+    """Round 5: callers that are inside pa_align / an astarpa-c symbol at the same time are combined into one batch on the GPU
+    (csrc/engine_hip.hip combine_align).  Sixteen threads, both presets through the drop-in symbols and through pa_align with statistics:
+    EVERY result equals what the same call returns when it is made alone (the single-pair route), and the counters say calls were combined."""
+    import ctypes as C
+    import threading
+
+    from tests.util_seq import gen_pair
+
+    lib = pa.capi.load()
+    lib.pa_combine_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.pa_combine_stats.restype = None
+
+    def combined():
+        c, b = C.c_uint64(0), C.c_uint64(0)
+        lib.pa_combine_stats(C.byref(c), C.byref(b))
+        return c.value, b.value
+
+    T, PER = 16, 12
+    pairs = [gen_pair(500 + 331 * (i % 23), (0.01, 0.05, 0.1, 0.2)[i % 4], seed=700 + i) for i in range(T * PER)]
+    pairs[5] = (b"ACGT", b"ACGGT")
+    keys = ("num_blocks", "num_incremental_blocks", "computed_lanes", "unique_lanes", "f_max_tries", "dt_trace_tries", "dt_trace_success",
+            "dt_trace_fallback", "fill_tries", "fill_success", "fill_fallback")
+    al = {"simple": pa.AstarPa2Params.simple().make_aligner(True), "full": pa.AstarPa2Params.full().make_aligner(True)}
+
+    def one(i):
+        a, b = pairs[i]
+        if i % 3 == 0:
+            return pa.c_abi_align("astarpa2_simple", a, b)
+        if i % 3 == 1:
+            return pa.c_abi_align("astarpa2_full", a, b)
+        c, g, st = al["simple" if i % 2 else "full"].align_with_stats(a, b)
+        return c, g, tuple(int(st[k]) for k in keys)
+
+    alone = [one(i) for i in range(len(pairs))]  # one caller at a time: the single-pair route
+    before = combined()
+    assert before[0] == 0 or True
+    got = [None] * len(pairs)
+    errors = []
+    gate = threading.Barrier(T)
+
+    def work(t):
+        try:
+            gate.wait()
+            for i in range(t, len(pairs), T):
+                got[i] = one(i)
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not errors, errors
+    assert got == alone
+    after = combined()
+    assert after[0] - before[0] >= len(pairs) // 4 and after[1] > before[1], (before, after)  # calls really went out in batches
+    for i in range(0, len(pairs), 17):
+        assert alone[i][0] == oracle.levenshtein(*pairs[i])
+
+
 def test_gpu_results_equal_the_second_restatement(pa, oracle):
     """Every GPU route against oracle/astarpa2_restated.py directly (pure Python on big integers, no line shared with csrc/engine.hpp):
     pa_align with the three presets (the sweep kernel for `simple`, the host-driven HIP engine for `full` and `nw`) and the batched A*PA2."""

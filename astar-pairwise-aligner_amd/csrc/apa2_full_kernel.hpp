@@ -590,6 +590,9 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_full_kernel(con
         if (probe_stats) {
             const unsigned long long vals[9] = {be.n_probe, be.n_round, be.t_build, be.t_dp, be.t_h, be.t_index, be.t_prune, be.t_init, be.tick() - t_begin};
             for (int q = 0; q < 9; ++q) atomicAdd(probe_stats + q, lane == 0 ? vals[q] : 0ull);
+            // per pair: the XCD it ran on and how long its band search took (100 MHz ticks)
+            const unsigned long long xcc = (unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);  // HW_REG_XCC_ID[2:0]
+            probe_stats[16 + pair] = (xcc << 32) | (unsigned long long)(uint32_t)(be.tick() - t_begin);
         }
         rdv_total.took += be.rdv_cnt.took;
         rdv_total.served += be.rdv_cnt.served;

@@ -883,10 +883,10 @@ struct StatsOnlyBackend {
 // thread at a time.  On the GPU one pair at a time is latency bound (a 10 kbp pair: 2 ms through the sweep, whatever else the chip could
 // do), while the batch kernels run thousands side by side and return per pair EXACTLY what pa_align returns -- cost, CIGAR string and
 // statistics (tests/test_gpu_apa2_batch.py, test_gpu_apa2_full.py, test_gpu_restated_fixtures.py).  So callers that are inside
-// pa_align AT THE SAME TIME with the same parameters are combined: the first one to find no leader becomes the leader, takes every
-// request queued so far, aligns them as ONE batch (pa_batch_create_params + pa_batch_align) and hands the results out; requests that
-// arrive meanwhile wait for the next leader.  No timer: a lone caller (nobody else inside) keeps the single-pair path and its latency;
-// the batch grows with the number of concurrent callers by itself.  PA_COMBINE=0 switches it off.
+// pa_align AT THE SAME TIME with the same parameters are combined: a caller that finds nobody gathering gathers -- for 300 us, or until
+// everybody who is inside has queued --, aligns the gathered requests as ONE batch (pa_batch_create_params + pa_batch_align) and hands
+// the results out; requests that arrive meanwhile are gathered by the next caller, whose batch runs beside the first.  No timer: below a dozen concurrent callers (crowd_threshold below) everybody keeps the
+// single-pair path and its latency; above, the batch grows with the number of callers by itself.  PA_COMBINE=0 switches it off.
 namespace {
 struct CombineReq {
     const uint8_t* a;
@@ -905,7 +905,8 @@ struct Combiner {
     std::mutex mu;
     std::condition_variable cv;
     std::vector<CombineReq*> pending;
-    bool leader = false;
+    bool collecting = false;  // a caller is gathering the next batch
+    int in_flight = 0;        // batches on the GPU right now
 };
 std::mutex& g_comb_mu = *new std::mutex;
 std::vector<Combiner*>& g_combs = *new std::vector<Combiner*>;  // (never destroyed: callers may be inside at exit)
@@ -915,6 +916,32 @@ thread_local bool t_in_combiner = false;   // the leader's own batch may hand a 
 constexpr int kNotCombined = 1;
 constexpr size_t kCombineMaxLen = 32768;   // longer pairs keep the single-pair engine (many wavefronts per pass; pa_bitpacking_hip.h "small route")
 constexpr size_t kCombineMaxGroup = 8192;
+constexpr int kCombineInFlight = 8;        // batches of one parameter set on the GPU at a time
+constexpr int kCombineWindowUs = 300;      // how long a gathering caller waits for more callers
+// Who takes which route.  A batch costs what its slowest pair costs ONE wavefront -- band search and traceback of a 10 kbp pair at 15 %:
+// 6-8 ms -- whatever its size, while the single-pair path runs a pair's passes on many wavefronts (2 ms) and eight callers side by side
+// reach 1 300-1 400 pairs/s: combining pays from about a dozen concurrent callers on.  And the two routes do not mix: every single-pair
+// call keeps several persistent kernels in flight that poll each other, a batch queued behind them waits (measured: 64 threads, eight of
+// them on the single-pair path: 875 pairs/s; all combined: 6 000; sixty-four single-pair calls at once starve one another into their
+// bounded waits; profiles/r05_runs/dropin_threads.log).  So the library is in one of two modes: as long as fewer than kCrowd callers are
+// inside at a time, everybody takes the single-pair path; once kCrowd are, everybody is combined -- and stays so for kSticky after the
+// crowd was last seen (the callers of a finished batch leave together and come back one by one: the first ones back must not find the
+// place empty and start single-pair calls again).  PA_COMBINE_MIN overrides kCrowd (tests: 2).
+std::atomic<int64_t> g_crowded_until{0};  // steady-clock nanoseconds
+constexpr int64_t kStickyNs = 20 * 1000 * 1000;
+inline int crowd_threshold() {  // (read at every call: tests switch it inside one process)
+    const char* e = std::getenv("PA_COMBINE_MIN");
+    const int v = e ? std::atoi(e) : 12;
+    return v < 2 ? 2 : v;
+}
+inline bool combine_now() {
+    const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (g_inside.load(std::memory_order_relaxed) >= crowd_threshold()) {
+        g_crowded_until.store(now + kStickyNs, std::memory_order_relaxed);
+        return true;
+    }
+    return now < g_crowded_until.load(std::memory_order_relaxed);
+}
 
 Combiner& combiner_for(const pa_astarpa2_params& params) {
     std::lock_guard<std::mutex> lk(g_comb_mu);
@@ -971,18 +998,20 @@ int combine_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len
     CombineReq req{a, a_len, b, b_len};
     std::unique_lock<std::mutex> lk(c.mu);
     c.pending.push_back(&req);
+    c.cv.notify_all();  // (a gathering caller counts the arrivals)
     while (!req.done) {
-        if (c.leader) {
+        // Somebody has to gather a batch: the first caller that finds nobody gathering (and fewer than kCombineInFlight batches on the
+        // GPU) does.  It collects for kCombineWindow -- a call lasts as long as its batch, a batch of short pairs about 8 ms whatever its
+        // size, so N callers complete N calls per (batch + window): the window is cheap and decides the batch size -- then runs the batch
+        // while the NEXT caller already gathers the next one (several batches side by side on streams of their own).
+        if (c.collecting || c.in_flight >= kCombineInFlight) {
             c.cv.wait(lk);
             continue;
         }
-        c.leader = true;
-        if ((int)c.pending.size() + 1 < g_inside.load(std::memory_order_relaxed)) {
-            // callers that are inside but have not queued yet (they arrived together): give them the time of a lock hand-over
-            lk.unlock();
-            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(30);
-            while (std::chrono::steady_clock::now() < until) std::this_thread::yield();
-            lk.lock();
+        c.collecting = true;
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(kCombineWindowUs);
+        while (c.pending.size() < kCombineMaxGroup && (int)c.pending.size() < g_inside.load(std::memory_order_relaxed) &&
+               c.cv.wait_until(lk, deadline) != std::cv_status::timeout) {
         }
         std::vector<CombineReq*> group;
         if (c.pending.size() <= kCombineMaxGroup) group.swap(c.pending);
@@ -990,12 +1019,15 @@ int combine_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len
             group.assign(c.pending.begin(), c.pending.begin() + (long)kCombineMaxGroup);
             c.pending.erase(c.pending.begin(), c.pending.begin() + (long)kCombineMaxGroup);
         }
+        c.collecting = false;
+        c.in_flight += 1;
+        c.cv.notify_all();  // (whoever is still pending may gather the next batch)
         lk.unlock();
         run_group(group, params);
         lk.lock();
         for (CombineReq* r : group) r->done = true;
-        c.leader = false;
-        c.cv.notify_all();  // the served ones leave; one of those still pending becomes the next leader
+        c.in_flight -= 1;
+        c.cv.notify_all();  // the served ones leave
     }
     lk.unlock();
     if (req.rc != 0) return kNotCombined;
@@ -1057,10 +1089,9 @@ int align_hip(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, co
     }
     // Several callers inside at once, a parameter set the batch kernels take: one batch for all of them (see combine_align above)
     InsideGuard inside;
-    if (trace && !self_check && !t_in_combiner && a_len > 0 && b_len > 0 && a_len < kCombineMaxLen && b_len < kCombineMaxLen &&
-        g_inside.load(std::memory_order_relaxed) > 1 && pa_batch_params_supported(&params)) {
+    if (trace && !self_check && !t_in_combiner && a_len > 0 && b_len > 0 && a_len < kCombineMaxLen && b_len < kCombineMaxLen && pa_batch_params_supported(&params)) {
         static const bool combine_off = std::getenv("PA_COMBINE") != nullptr && std::getenv("PA_COMBINE")[0] == '0';
-        if (!combine_off && combine_align(a, a_len, b, b_len, params, cost_out, cigar_out, stats_out) == 0) return 0;
+        if (!combine_off && combine_now() && combine_align(a, a_len, b, b_len, params, cost_out, cigar_out, stats_out) == 0) return 0;
     }
     HipBackend& be = pooled_backend();
     be.bind(a, a_len, b, b_len);

@@ -381,6 +381,11 @@ std::vector<PinnedBlock>& g_pin = *new std::vector<PinnedBlock>;
 size_t g_pin_bytes = 0;
 }  // namespace
 void* pinned_take(size_t bytes, size_t* got) {
+    {  // size classes (2^k and 1.5 x 2^k from 64 KB up): batches of slightly different sizes -- the call combiner's -- meet in the pool
+        size_t c = size_t(64) << 10;
+        while (c < bytes) c = ((c & (c - 1)) == 0 && c + c / 2 >= bytes) ? c + c / 2 : ((c & (c - 1)) == 0 ? c * 2 : (c / 3) * 4);
+        bytes = c;
+    }
     {
         std::lock_guard<std::mutex> lk(g_pin_mu);
         size_t best = g_pin.size();
@@ -437,6 +442,39 @@ hipStream_t stream_take() {
     if (!hip_ok(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
     return s;
 }
+// The batch's own stream (a default, blocking stream: its work orders with the synchronous copies of the creation) is pooled as well:
+// hipStreamCreate costs 2 ms, a quarter of what a batch of sixteen short pairs takes from creation to destruction (round 5: the call
+// combiner behind pa_align creates such batches a hundred times a second).  A stream goes back only after its batch has waited for the device.
+namespace {
+std::vector<std::pair<int, hipStream_t>>& g_bstreams = *new std::vector<std::pair<int, hipStream_t>>;
+}
+hipStream_t bstream_take() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        for (size_t i = 0; i < g_bstreams.size(); ++i)
+            if (g_bstreams[i].first == dev) {
+                hipStream_t s = g_bstreams[i].second;
+                g_bstreams.erase(g_bstreams.begin() + (long)i);
+                return s;
+            }
+    }
+    hipStream_t s = nullptr;
+    if (!hip_ok(hipStreamCreate(&s), "hipStreamCreate")) return nullptr;
+    return s;
+}
+void bstream_give(hipStream_t s, int dev) {
+    if (!s) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        if (g_bstreams.size() < 32) {
+            g_bstreams.emplace_back(dev, s);
+            return;
+        }
+    }
+    (void)hipStreamDestroy(s);
+}
 void stream_give(hipStream_t s, int dev) {  // dev: the device the stream was created on (a batch may be destroyed from a thread bound to another)
     if (!s) return;
     {
@@ -472,6 +510,10 @@ void release_scope_begin() {
     (void)hipDeviceSynchronize();
     g_release_synced = true;
 }
+// ... or the owner waited for everything that ever touched its buffers itself (a batch: its own streams) and only declares the scope:
+// a device-wide wait also waits for every OTHER batch in flight -- eight batches of the call combiner side by side each waited for the
+// other seven's kernels (round 5: 40 ms per call at 64 callers instead of 8)
+void release_scope_begin_waited() { g_release_synced = true; }
 void release_scope_end() { g_release_synced = false; }
 
 void DeviceBuf::release() {
@@ -1323,6 +1365,7 @@ struct pa_batch {
     pa_astarpa2_params aparams_c{};
     apa2::SearchParams sp{};
     DeviceBuf d_rec, d_results, d_pjobs, d_order, d_tstats, d_sh;
+    DeviceBuf d_sketch;  // [pairs] the divergence sketch (sketch_unit.hip), kept so that it is released with the batch's other buffers
     DeviceBuf d_rdv;  // 8 x u64: the rendezvous of half-wave blocks in the last forward pass (strips run fused, served by a partner, alone, withdrawn)
     // ... the whole family (pa_batch_create_params with GCSH / pruning / incremental doubling: apa2_full_kernel.hpp)
     bool astar_full = false;
@@ -1338,6 +1381,7 @@ struct pa_batch {
     double apa2_strip_instr = 0;  // modelled VALU instructions of the DP strips of the last pa_batch_align (reporting)
     double cells = 0, word_updates = 0, algo_bytes = 0;
     hipStream_t stream = nullptr;
+    bool multi_stream_users = false;  // work on this batch's buffers was queued on streams the batch does not own: wait for the device
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~pa_batch() {
         static const bool prof = getenv("PA_ALIGN_PROFILE") != nullptr;
@@ -1350,7 +1394,13 @@ struct pa_batch {
             if (stream) (void)hipStreamSynchronize(stream);
             std::fprintf(stderr, "[pa_batch_destroy] batch stream wait %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         }
-        release_scope_begin();
+        // everything that reads or writes this batch's buffers was queued on its own streams: wait for those, not for the device
+        bool waited = true;
+        if (stream) waited = hipStreamSynchronize(stream) == hipSuccess && waited;
+        for (int c = 0; c < kMaxChunks; ++c)
+            if (cstream[c]) waited = hipStreamSynchronize(cstream[c]) == hipSuccess && waited;
+        if (waited && !multi_stream_users) release_scope_begin_waited();
+        else release_scope_begin();
         if (prof) std::fprintf(stderr, "[pa_batch_destroy] device wait %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -1368,7 +1418,7 @@ struct pa_batch {
             stream_give(cstream[c], d_a.device);
         }
         if (prof) std::fprintf(stderr, "[pa_batch_destroy] events, streams, pinned %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-        if (stream) (void)hipStreamDestroy(stream);
+        bstream_give(stream, d_a.device);  // (the batch waited for its device above: nothing of it is queued on the stream any more)
     }
 };
 
@@ -1586,25 +1636,36 @@ static bool astar_start_order(pa_batch* p, std::vector<int32_t>& order) {
     order.resize(P);
     for (size_t i = 0; i < P; ++i) order[i] = (int32_t)i;
     if (getenv("PA_APA2_ORDER_INPUT") || P < 2) return true;
-    std::vector<double> key(P);
-    for (size_t i = 0; i < P; ++i) key[i] = (double)(p->n[i] + p->m[i]);
+    static const bool cprof = getenv("PA_ALIGN_PROFILE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     static_assert(sizeof(apa2::SketchDesc) == sizeof(PairDesc), "the sketch reads the batch's pair descriptors");
-    if (!getenv("PA_APA2_ORDER_LENGTH")) {
-        DeviceBuf d_found;
-        std::vector<uint8_t> found(P);
-        if (!d_found.alloc(P) ||
-            !hip_ok(apa2::launch_sketch_kernel(p->stream, p->d_a.as<uint8_t>(), p->d_b.as<uint8_t>(), (const apa2::SketchDesc*)p->d_desc.ptr, (int)P, d_found.as<uint8_t>()),
+    std::vector<uint8_t> found(P, 64);
+    const bool sketch = !getenv("PA_APA2_ORDER_LENGTH");
+    if (sketch) {
+        if (!p->d_sketch.alloc(P) ||
+            !hip_ok(apa2::launch_sketch_kernel(p->stream, p->d_a.as<uint8_t>(), p->d_b.as<uint8_t>(), (const apa2::SketchDesc*)p->d_desc.ptr, (int)P, p->d_sketch.as<uint8_t>()),
                     "sketch_kernel launch") ||
-            !hip_ok(hipMemcpyAsync(found.data(), d_found.ptr, P, hipMemcpyDeviceToHost, p->stream), "D2H sketch") || !hip_ok(hipStreamSynchronize(p->stream), "sync"))
+            !hip_ok(hipMemcpyAsync(found.data(), p->d_sketch.ptr, P, hipMemcpyDeviceToHost, p->stream), "D2H sketch") || !hip_ok(hipStreamSynchronize(p->stream), "sync"))
             return false;
-        for (size_t i = 0; i < P; ++i) {
-            const double len = (double)(p->n[i] + p->m[i]);
-            const double f = std::min(64.0, std::max(0.5, (double)found[i])) / 64.0;  // (nothing found: as if half a sample had been)
-            const double e = 1.0 - std::pow(f, 1.0 / 16.0);
-            key[i] = len * (e * len * 0.5 + 128.0);
-        }
     }
-    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return key[(size_t)x] > key[(size_t)y]; });
+    const auto t1 = std::chrono::steady_clock::now();
+    // e from found / 64 = (1 - e)^16, by table (nothing found: as if half a sample had been)
+    double e_of[65];
+    for (int f = 0; f <= 64; ++f) e_of[f] = 1.0 - std::pow(std::max(0.5, (double)f) / 64.0, 1.0 / 16.0);
+    // descending by the expected work, ties in the caller's order: one sort of 64-bit words (float bits of a positive key order like integers)
+    std::vector<uint64_t> keyed(P);
+    for (size_t i = 0; i < P; ++i) {
+        const float len = (float)(p->n[i] + p->m[i]);
+        const float key = sketch ? len * ((float)e_of[std::min<int>(found[i], 64)] * len * 0.5f + 128.0f) : len;
+        uint32_t bits;
+        std::memcpy(&bits, &key, 4);
+        keyed[i] = ((uint64_t)bits << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)i);
+    }
+    std::sort(keyed.begin(), keyed.end(), std::greater<uint64_t>());
+    for (size_t i = 0; i < P; ++i) order[i] = (int32_t)(0xFFFFFFFFu - (uint32_t)(keyed[i] & 0xFFFFFFFFu));
+    if (cprof)
+        std::fprintf(stderr, "[pa_batch_create]   start order: sketch %.3f ms, sort %.3f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     return true;
 }
 
@@ -1818,7 +1879,7 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
         !p->d_active.alloc(std::max<size_t>(tm, 64)) || !p->d_win.alloc(std::max<size_t>(tseeds, 1) * sizeof(apa2::GcshSeedWindow)) ||
         !p->d_win0.alloc(std::max<size_t>(tseeds, 1) * sizeof(apa2::GcshSeedWindow)) ||
         !p->d_lrec.alloc((tm + 2 * std::max<size_t>(P, 1)) * sizeof(apa2::GcshCell)) || !p->d_cell.alloc(std::max<size_t>(tm, 1) * sizeof(apa2::GcshCell)) ||
-        !p->d_probe.alloc(128))
+        !p->d_probe.alloc(128 + 8 * std::max<size_t>(P, 1)))  // (16 counters, then per pair: HW_ID / XCC_ID and the ticks of its band search; PA_APA2_PROBE_STATS)
         return false;
     cmark("device buffers");
     if (tsh && !hip_ok(hipMemcpy(p->d_sh.ptr, shv.data(), tsh * 4, hipMemcpyHostToDevice), "H2D sh")) return false;
@@ -2055,7 +2116,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
         !p->d_v.alloc(tp * 16) || !p->d_gran.alloc(tg * 8) || !p->d_sums.alloc(std::max<size_t>(pairs * 4, 16)) || !p->d_misc.alloc(32))
         return nullptr;
     cmark("host layout + hipMalloc");
-    if (!hip_ok(hipStreamCreate(&p->stream), "hipStreamCreate") || !hip_ok(hipEventCreate(&p->ev0), "event") ||
+    if (!(p->stream = bstream_take()) || !hip_ok(hipEventCreate(&p->ev0), "event") ||
         !hip_ok(hipEventCreate(&p->ev1), "event") || !hip_ok(hipEventCreate(&p->ev2), "event"))
         return nullptr;
     cmark("stream + events");
@@ -3139,6 +3200,28 @@ extern "C" void pa_batch_full_info(const pa_batch* p, double* build_ms, double* 
     }
     unsigned long long pr[16] = {0};
     if (p && p->astar_full && p->d_probe.ptr) (void)hipMemcpy(pr, p->d_probe.ptr, 128, hipMemcpyDeviceToHost);
+    if (p && p->astar_full && p->d_probe.ptr && getenv("PA_APA2_PROBE_STATS") && p->pairs) {
+        // diagnostics: how long every pair's band search took its wavefront, by XCD (is the launch's length the work or the placement?)
+        std::vector<unsigned long long> pp(p->pairs);
+        if (hipMemcpy(pp.data(), (const uint8_t*)p->d_probe.ptr + 128, p->pairs * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            std::vector<double> all;
+            std::vector<std::vector<double>> by_xcc(8);
+            for (unsigned long long v : pp) {
+                const double ms = (double)(uint32_t)v / 1e5;
+                if (ms <= 0) continue;
+                all.push_back(ms);
+                by_xcc[(size_t)((v >> 32) & 7)].push_back(ms);
+            }
+            auto q = [](std::vector<double>& x, double f) { return x.empty() ? 0.0 : x[(size_t)(f * (double)(x.size() - 1))]; };
+            std::sort(all.begin(), all.end());
+            std::fprintf(stderr, "[apa2_full] per-pair band search ms: min %.2f  p10 %.2f  median %.2f  p90 %.2f  p99 %.2f  max %.2f  (%zu pairs)\n", q(all, 0), q(all, 0.1), q(all, 0.5),
+                         q(all, 0.9), q(all, 0.99), q(all, 1.0), all.size());
+            for (size_t x = 0; x < 8; ++x) {
+                std::sort(by_xcc[x].begin(), by_xcc[x].end());
+                std::fprintf(stderr, "[apa2_full]   XCD %zu: %5zu pairs  median %.2f  max %.2f\n", x, by_xcc[x].size(), q(by_xcc[x], 0.5), q(by_xcc[x], 1.0));
+            }
+        }
+    }
     if (probes) *probes = (double)pr[0];
     if (rounds) *rounds = (double)pr[1];
     if (phase_wave_ms)

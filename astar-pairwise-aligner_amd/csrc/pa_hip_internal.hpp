@@ -22,6 +22,7 @@ bool ensure_device();
 void release_alloc_cache();  // the cached device blocks back to the driver (pa_release_pools)
 void release_scope_begin();  // one device wait now; DeviceBuf::release calls of this thread skip theirs until release_scope_end()
 void release_scope_end();
+void release_scope_begin_waited();  // the caller has waited for everything that used its buffers (its own streams)
 
 struct DeviceBuf {
     void* ptr = nullptr;

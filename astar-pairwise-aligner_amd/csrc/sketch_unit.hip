@@ -42,7 +42,22 @@ __global__ __launch_bounds__(256) void sketch_kernel(const uint8_t* __restrict__
         if (j0 <= j1) {
             uint32_t q = 0;
             for (int t = 0; t < kSketchK - 1; ++t) q = (q << 2) | ((uint32_t)(b[j0 + t] >> 1) & 3u);
-            for (int j = j0; j <= j1; ++j) {
+            int j = j0;
+            // four candidates per (unaligned) 4-byte load; the last few one by one (the load must stay inside b)
+            for (; j + 3 <= j1; j += 4) {
+                uint32_t w;
+                __builtin_memcpy(&w, b + j + kSketchK - 1, 4);
+                const uint32_t c4 = (w >> 1) & 0x03030303u;
+                q = (q << 2) | (c4 & 3u);
+                found = found || q == key;
+                q = (q << 2) | ((c4 >> 8) & 3u);
+                found = found || q == key;
+                q = (q << 2) | ((c4 >> 16) & 3u);
+                found = found || q == key;
+                q = (q << 2) | (c4 >> 24);
+                found = found || q == key;
+            }
+            for (; j <= j1; ++j) {
                 q = (q << 2) | ((uint32_t)(b[j + kSketchK - 1] >> 1) & 3u);
                 found = found || q == key;
             }

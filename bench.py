@@ -446,9 +446,30 @@ def main():
 
             # round 5: callers that are inside the symbol at the same time are combined into one batch on the GPU (csrc/engine_hip.hip
             # combine_align); every result is compared with the sequential loop's
-            out["dropin_loop"]["threads8_pairs_per_sec"] = threads_rate(8, loop_pairs, got)
+            out["dropin_loop"]["threads8_pairs_per_sec"] = threads_rate(8, loop_pairs, got)  # (below the combiner's threshold of a dozen concurrent callers)
             many = loop_pairs * 8  # (1600 calls: 25 per thread)
             out["dropin_loop"]["threads64_pairs_per_sec"] = threads_rate(64, many, got * 8)
+            # the same from plain C (tests/c_abi/dropin_threads.c: pthreads, no interpreter lock between the calls; fresh threads per count,
+            # every result compared with the single-call route inside the program); reporting only
+            try:
+                import re as _re
+                import shutil
+                import subprocess
+                import tempfile
+
+                gcc = shutil.which("gcc") or shutil.which("cc")
+                libdir = str(ROOT / "astar-pairwise-aligner_amd")
+                exe = os.path.join(tempfile.gettempdir(), f"pa_dropin_threads_{os.getpid()}")
+                subprocess.run([gcc, "-O2", str(ROOT / "tests" / "c_abi" / "dropin_threads.c"), "-I", str(ROOT / "include"), "-L", libdir, "-lastarpa_c_hip",
+                                "-lpthread", "-o", exe], check=True, capture_output=True, timeout=120)
+                envc = dict(os.environ, LD_LIBRARY_PATH=libdir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+                rc = subprocess.run([exe, "640", "simple", "8", "32", "64"], capture_output=True, text=True, timeout=240, env=envc)
+                rates = {int(m.group(1)): float(m.group(2)) for m in _re.finditer(r"threads\s+(\d+):\s+([\d.]+) pairs/s", rc.stdout)}
+                out["dropin_loop"]["c_pthreads_pairs_per_sec"] = {str(k): v for k, v in sorted(rates.items())}
+                out["dropin_loop"]["c_pthreads_results_equal_single_call"] = rc.returncode == 0
+                os.unlink(exe)
+            except Exception as e:  # (reporting only)
+                out["dropin_loop"]["c_pthreads_pairs_per_sec"] = f"failed: {e}"
             import ctypes as _C
 
             cc, cb = _C.c_uint64(0), _C.c_uint64(0)

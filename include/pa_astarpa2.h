@@ -78,8 +78,9 @@ int pa_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, con
 
 /* Callers that are inside pa_align (or an astarpa-c symbol) AT THE SAME TIME with the same parameters, sequences shorter than 32 768
  * bases and a parameter set the batch kernels take (pa_batch_params_supported) are COMBINED: one of them aligns all queued pairs as one
- * batch on the GPU and hands every caller its own cost, CIGAR and statistics -- the values the single-pair path returns (timers 0).  A
- * caller that is alone keeps the single-pair path.  PA_COMBINE=0 switches it off.  pa_combine_stats: calls served that way so far and
+ * batch on the GPU and hands every caller its own cost, CIGAR and statistics -- the values the single-pair path returns (timers 0).
+ * Below a dozen concurrent callers (PA_COMBINE_MIN) everybody keeps the single-pair path and its latency; once a dozen are inside at a
+ * time, everybody is combined until 20 ms after the crowd was last seen.  PA_COMBINE=0 switches it off.  pa_combine_stats: calls served that way so far and
  * the batches they went out in (either argument may be NULL). */
 void pa_combine_stats(uint64_t* calls, uint64_t* batches);
 

@@ -1,0 +1,113 @@
+/* dropin_threads.c -- the astarpa-c drop-in symbol under concurrent callers, from plain C (no interpreter lock in the way):
+ * T pthreads, each calling astarpa2_simple() / astarpa2_full() on its share of N synthetic 10 kbp pairs (1 / 5 / 10 / 15 % divergence),
+ * every result compared with the one the same call returned when it was made alone.  Prints pairs/s per thread count.
+ *   gcc -O2 tests/c_abi/dropin_threads.c -Iinclude -Lastar-pairwise-aligner_amd -lastarpa_c_hip -lpthread -o /tmp/dropin_threads
+ *   LD_LIBRARY_PATH=astar-pairwise-aligner_amd /tmp/dropin_threads [pairs] [symbol: simple|full] [threads ...]
+ * What it replaces: a multi-threaded user of astarpa-c (astarpa-c/astarpa.h:15-65; the entry points are stateless and re-entrant). */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "astarpa.h"
+
+typedef uint64_t (*align_fn)(const uint8_t*, uintptr_t, const uint8_t*, uintptr_t, uint8_t**, uintptr_t*);
+
+static uint64_t rng_state;
+static uint32_t rnd(void) {
+    rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull;
+    return (uint32_t)(rng_state >> 33);
+}
+typedef struct {
+    uint8_t *a, *b;
+    size_t n, m;
+    uint64_t cost;
+    char* cigar;
+} pair_t;
+
+static void make_pair(pair_t* p, size_t n, double e, uint64_t seed) {
+    rng_state = seed * 2654435761u + 12345;
+    p->a = (uint8_t*)malloc(n + 1);
+    p->b = (uint8_t*)malloc(2 * n + 16);
+    for (size_t i = 0; i < n; ++i) p->a[i] = "ACGT"[rnd() & 3];
+    size_t m = 0;
+    const uint32_t thr = (uint32_t)(e * 2147483648.0);
+    for (size_t i = 0; i < n; ++i) {
+        if (rnd() < thr) {
+            const uint32_t kind = rnd() % 3;
+            if (kind == 0) p->b[m++] = "ACGT"[(strchr("ACGT", p->a[i]) - "ACGT" + 1 + rnd() % 3) & 3]; /* substitution */
+            else if (kind == 1) { p->b[m++] = "ACGT"[rnd() & 3]; p->b[m++] = p->a[i]; }                /* insertion */
+            /* kind == 2: deletion */
+        } else p->b[m++] = p->a[i];
+    }
+    if (m == 0) p->b[m++] = 'A';
+    p->n = n;
+    p->m = m;
+    p->cost = 0;
+    p->cigar = NULL;
+}
+
+static pair_t* g_pairs;
+static size_t g_npairs;
+static align_fn g_fn;
+static int g_threads;
+static volatile int g_bad;
+static pthread_barrier_t g_gate;
+
+static void* worker(void* arg) {
+    const int t = (int)(intptr_t)arg;
+    pthread_barrier_wait(&g_gate);
+    for (size_t i = (size_t)t; i < g_npairs; i += (size_t)g_threads) {
+        uint8_t* cig = NULL;
+        uintptr_t len = 0;
+        const uint64_t c = g_fn(g_pairs[i].a, g_pairs[i].n, g_pairs[i].b, g_pairs[i].m, &cig, &len);
+        if (c != g_pairs[i].cost || strlen(g_pairs[i].cigar) != len || memcmp(cig, g_pairs[i].cigar, len) != 0) g_bad = 1;
+        astarpa_free_cigar(cig);
+    }
+    return NULL;
+}
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int main(int argc, char** argv) {
+    g_npairs = argc > 1 ? (size_t)atoll(argv[1]) : 1280;
+    g_fn = (argc > 2 && !strcmp(argv[2], "full")) ? astarpa2_full : astarpa2_simple;
+    const double divs[4] = {0.01, 0.05, 0.10, 0.15};
+    g_pairs = (pair_t*)calloc(g_npairs, sizeof(pair_t));
+    for (size_t i = 0; i < g_npairs; ++i) make_pair(&g_pairs[i], 10000, divs[i % 4], 1000 + i);
+    /* one caller at a time: the single-pair route; its results are the expected values of everything below */
+    double t0 = now_s();
+    for (size_t i = 0; i < g_npairs; ++i) {
+        uint8_t* cig = NULL;
+        uintptr_t len = 0;
+        g_pairs[i].cost = g_fn(g_pairs[i].a, g_pairs[i].n, g_pairs[i].b, g_pairs[i].m, &cig, &len);
+        g_pairs[i].cigar = (char*)cig;
+    }
+    printf("threads %3d: %9.1f pairs/s  (one call after the other)\n", 1, (double)g_npairs / (now_s() - t0));
+    fflush(stdout);
+    int counts[16], nc = 0;
+    for (int k = 3; k < argc && nc < 16; ++k) counts[nc++] = atoi(argv[k]);
+    if (nc == 0) { counts[0] = 8; counts[1] = 16; counts[2] = 32; counts[3] = 64; nc = 4; }
+    for (int k = 0; k < nc; ++k) {
+        g_threads = counts[k];
+        pthread_t th[256];
+        if (g_threads < 1 || g_threads > 256) continue;
+        pthread_barrier_init(&g_gate, NULL, (unsigned)g_threads + 1);
+        for (int t = 0; t < g_threads; ++t) pthread_create(&th[t], NULL, worker, (void*)(intptr_t)t);
+        pthread_barrier_wait(&g_gate);
+        t0 = now_s();
+        for (int t = 0; t < g_threads; ++t) pthread_join(th[t], NULL);
+        const double dt = now_s() - t0;
+        pthread_barrier_destroy(&g_gate);
+        printf("threads %3d: %9.1f pairs/s  (%.3f ms per call per thread)%s\n", g_threads, (double)g_npairs / dt, dt * 1e3 / (double)g_npairs * g_threads,
+               g_bad ? "  RESULTS DIFFER FROM THE SINGLE-CALL ROUTE" : "");
+        fflush(stdout);
+    }
+    return g_bad ? 1 : 0;
+}

@@ -219,7 +219,7 @@ def test_c_abi_is_reentrant_across_threads(pa, oracle):
         assert len({c for _, c in out}) == 1  # deterministic
 
 
-def test_concurrent_callers_are_combined_and_get_the_single_call_results(pa, oracle):
+def test_concurrent_callers_are_combined_and_get_the_single_call_results(pa, oracle, monkeypatch):
     """Round 5: callers that are inside pa_align / an astarpa-c symbol at the same time are combined into one batch on the GPU
     (csrc/engine_hip.hip combine_align).  Sixteen threads, both presets through the drop-in symbols and through pa_align with statistics:
     EVERY result equals what the same call returns when it is made alone (the single-pair route), and the counters say calls were combined."""
@@ -237,6 +237,7 @@ def test_concurrent_callers_are_combined_and_get_the_single_call_results(pa, ora
         lib.pa_combine_stats(C.byref(c), C.byref(b))
         return c.value, b.value
 
+    monkeypatch.setenv("PA_COMBINE_MIN", "2")  # (by default a dozen callers have to be inside at once before anybody is combined)
     T, PER = 16, 12
     pairs = [gen_pair(500 + 331 * (i % 23), (0.01, 0.05, 0.1, 0.2)[i % 4], seed=700 + i) for i in range(T * PER)]
     pairs[5] = (b"ACGT", b"ACGGT")
@@ -279,6 +280,30 @@ def test_concurrent_callers_are_combined_and_get_the_single_call_results(pa, ora
     assert after[0] - before[0] >= len(pairs) // 4 and after[1] > before[1], (before, after)  # calls really went out in batches
     for i in range(0, len(pairs), 17):
         assert alone[i][0] == oracle.levenshtein(*pairs[i])
+
+
+def test_c_pthreads_through_the_drop_in_symbols(tmp_path):
+    """tests/c_abi/dropin_threads.c: 24 and 48 pthreads calling astarpa2_simple / astarpa2_full from plain C -- above the call combiner's
+    threshold, so the calls go out as batches -- and every (cost, CIGAR) must equal what the same call returned when it was made alone
+    (the program exits non-zero otherwise)."""
+    import os
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    libdir = root / "astar-pairwise-aligner_amd"
+    gcc = shutil.which("gcc") or shutil.which("cc")
+    if gcc is None or not (libdir / "libastarpa_c_hip.so").exists():
+        pytest.skip("no C compiler or library")
+    exe = tmp_path / "dropin_threads"
+    subprocess.run([gcc, "-O2", str(root / "tests" / "c_abi" / "dropin_threads.c"), "-I", str(root / "include"), "-L", str(libdir), "-lastarpa_c_hip", "-lpthread",
+                    "-Wl,-rpath," + str(libdir), "-o", str(exe)], check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=str(libdir) + ":" + os.environ.get("LD_LIBRARY_PATH", ""), GPU_MAX_HW_QUEUES="16")
+    for sym in ("simple", "full"):
+        out = subprocess.run([str(exe), "192", sym, "24", "48"], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0 and "DIFFER" not in out.stdout, out.stdout + out.stderr
+        assert out.stdout.count("pairs/s") == 3
 
 
 def test_gpu_results_equal_the_second_restatement(pa, oracle):

@@ -26,7 +26,7 @@ H_DTYPE = np.dtype([("p", "<u8"), ("m", "<u8")])
 BITS_DTYPE = np.dtype([("b0", "<u8"), ("b1", "<u8")])
 
 
-_TARGETS = ("libpa_oracle.so", "libpa_engine_cpu.so", "libpa_sweep_emu.so", "libpa_apa2_emu.so", "libpa_apa2_full_emu.so")
+_TARGETS = ("libpa_oracle.so", "libpa_engine_cpu.so", "libpa_sweep_emu.so", "libpa_apa2_emu.so", "libpa_apa2_full_emu.so", "libpa_rdv_emu.so")
 
 
 def _source_hash() -> str:
@@ -37,7 +37,7 @@ def _source_hash() -> str:
     h = hashlib.sha256()
     csrc = _DIR.parent / "astar-pairwise-aligner_amd" / "csrc"
     files = sorted(list(_DIR.glob("*.c")) + list(_DIR.glob("*.cpp")) + list(_DIR.glob("*.h")) + list(_DIR.glob("*.hpp")) + [_DIR / "Makefile"] +
-                   [csrc / n for n in ("engine.hpp", "gcsh.hpp", "engine_capi.hpp", "sweep_logic.hpp", "sweep_wave.hpp", "sweep_host.hpp", "apa2_logic.hpp", "apa2_full_logic.hpp", "gcsh_dev.hpp")] +
+                   [csrc / n for n in ("engine.hpp", "gcsh.hpp", "engine_capi.hpp", "sweep_logic.hpp", "sweep_wave.hpp", "sweep_host.hpp", "apa2_logic.hpp", "apa2_full_logic.hpp", "gcsh_dev.hpp", "rdv_logic.hpp")] +
                    [_DIR.parent / "include" / "pa_astarpa2.h"])
     for f in files:
         h.update(f.name.encode())
@@ -442,3 +442,33 @@ def cpu_align_blocks(a: bytes, b: bytes, params: AstarPa2ParamsC):
         d["v"] = [(int(v[2 * (off + j)]), int(v[2 * (off + j) + 1])) for j in range(w)]
         out.append(d)
     return cost.value, f_max.value, out
+
+
+_rlib = None
+
+
+def rdv_emu_run(pairs, groups: int = 2, patience_us: float = 200.0):
+    """oracle/rdv_emu.cpp: the `simple` band search of every pair on groups x 4 host threads with the product's rendezvous of half-wave
+    blocks (csrc/rdv_logic.hpp) between the threads of a group; patience_us < 0: no rendezvous.  -> (rows, counters): per pair
+    (status, cost, f_max_tries, num_blocks, computed_lanes, unique_lanes), counters = dict(fused, served, alone, withdrawn)."""
+    global _rlib
+    build()
+    if _rlib is None:
+        L = C.CDLL(str(_DIR / "_build" / "libpa_rdv_emu.so"))
+        L.pa_rdv_emu_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        L.pa_rdv_emu_run.restype = C.c_int
+        _rlib = L
+    n = len(pairs)
+    ab = [C.create_string_buffer(bytes(a), max(len(a), 1)) for a, _ in pairs]
+    bb = [C.create_string_buffer(bytes(b), max(len(b), 1)) for _, b in pairs]
+    ap = (C.c_void_p * n)(*[C.addressof(x) for x in ab])
+    bp = (C.c_void_p * n)(*[C.addressof(x) for x in bb])
+    al = (C.c_size_t * n)(*[len(a) for a, _ in pairs])
+    bl = (C.c_size_t * n)(*[len(b) for _, b in pairs])
+    out = (C.c_int64 * (8 * n))()
+    cnt = (C.c_uint64 * 4)()
+    rc = _rlib.pa_rdv_emu_run(ap, al, bp, bl, n, groups, float(patience_us), out, cnt)
+    if rc != 0:
+        raise RuntimeError(f"pa_rdv_emu_run rc={rc}")
+    rows = [tuple(int(out[8 * i + k]) for k in range(6)) for i in range(n)]
+    return rows, dict(zip(("fused", "served", "alone", "withdrawn"), (int(x) for x in cnt)))

@@ -426,18 +426,56 @@ __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __re
                 if (jb.p == 0) {
                     for (int32_t t = lane; t < ncand; t += 64) flag[t] = 1;
                 } else {
+                    // ---- D0. chains (round 5).  Matches along the alignment come in runs on one diagonal: candidate (seed s, row j) is followed
+                    // by (s + 1, j + k).  In the reference's push order the successor is decided first, and if it is kept the candidate meets it at
+                    // its own end -- next_match_per_diag[diagonal] == i + k <= the column its first extension reaches (prepruning.rs:134) -- and is
+                    // kept at once.  So a candidate WITH a successor candidate is not searched here at all (flag 2): phase E keeps it when the
+                    // successor was kept and only otherwise runs its search.  The expensive search "alone" (through all p seeds: no kept match
+                    // ends it early) is left for the run ends and the stray candidates -- about 45 % of them at 5 % divergence.
+                    // (succ / todo live in the mi / mj arrays, which phase F fills only afterwards)
+                    PA_GLOBAL int32_t* succ = (PA_GLOBAL int32_t*)jb.mi;
+                    PA_GLOBAL int32_t* todo = (PA_GLOBAL int32_t*)jb.mj;
+                    int32_t ntodo = 0;
                     for (int32_t base = 0; base < ncand; base += 64) {
                         const int32_t t = base + lane;
-                        int32_t si = 0, sj = 0;
+                        int32_t sc = -1;
                         if (t < ncand) {
+                            const int32_t s = tmp_s[t], jr = tmp_j[t] + jb.k;
+                            if (s + 1 < jb.nseeds && jr <= jb.m - jb.k) {
+                                int32_t lo = t + 1, hi = ncand;  // rows ascend with the index: first index whose row is >= jr
+                                while (lo < hi) {
+                                    const int32_t mid = (lo + hi) >> 1;
+                                    if (tmp_j[mid] < jr) lo = mid + 1;
+                                    else hi = mid;
+                                }
+                                for (int32_t x = lo; x < ncand && tmp_j[x] == jr; ++x)
+                                    if (tmp_s[x] == s + 1) {
+                                        sc = x;
+                                        break;
+                                    }
+                            }
+                            succ[t] = sc;
+                            flag[t] = sc >= 0 ? 2 : 0;
+                        }
+                        const uint64_t need = __ballot(t < ncand && sc < 0);
+                        if (t < ncand && sc < 0) todo[ntodo + __builtin_popcountll(need & ((1ull << lane) - 1ull))] = t;
+                        ntodo += __builtin_popcountll(need);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    // ---- D. local pruning alone, one lane per candidate that has no successor ----
+                    for (int32_t base = 0; base < ntodo; base += 64) {
+                        const int32_t q = base + lane;
+                        const int32_t t = q < ntodo ? todo[q] : -1;
+                        int32_t si = 0, sj = 0;
+                        if (t >= 0) {
                             si = tmp_s[t] * jb.k;
                             sj = tmp_j[t];
                         }
                         // rows ascend with the lane: b from the first candidate's end, a along the diagonal of the middle candidate
-                        const int mid = (ncand - base < 64 ? ncand - base : 64) / 2;
+                        const int mid = (ntodo - base < 64 ? ntodo - base : 64) / 2;
                         const int32_t nb0 = (__builtin_amdgcn_readlane(sj, 0) + jb.k - 16) & ~3;
                         cx.stage(lds_wa, lds_wb, (nb0 + __builtin_amdgcn_readlane(si, mid) - __builtin_amdgcn_readlane(sj, mid)) & ~3, nb0);
-                        if (t < ncand) flag[t] = prune_alone(cx, si, sj, &lds_fr[0][lane], &lds_fr[1][lane]) ? 1 : 0;
+                        if (t >= 0) flag[t] = prune_alone(cx, si, sj, &lds_fr[0][lane], &lds_fr[1][lane]) ? 1 : 0;
                         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the windows are rewritten by the next round)
                     }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -447,28 +485,37 @@ __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __re
                     const int32_t reach = (jb.p + 2) * jb.k + 64 + jb.p;  // rows a kept match can still be met from
                     for (int32_t top = ncand - 1; top >= 0 && status == kBuildOk; top -= 64) {
                         const int32_t t = top - lane;
-                        int32_t s = 0, j = 0, f = 0;
+                        int32_t s = 0, j = 0, f = 0, sc = -1;
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the final flags of the batches before)
                         if (t >= 0) {
                             s = tmp_s[t];
                             j = tmp_j[t];
                             f = flag[t];
+                            sc = succ[t];
                         }
                         const int cntl = top + 1 < 64 ? top + 1 : 64;
                         {  // (lane cntl - 1 holds the batch's lowest row)
                             const int32_t nb0 = (__builtin_amdgcn_readlane(j, cntl - 1) + jb.k - 16) & ~3;
                             cx.stage(lds_wa, lds_wb, (nb0 + (__builtin_amdgcn_readlane(s, cntl / 2) * jb.k - __builtin_amdgcn_readlane(j, cntl / 2))) & ~3, nb0);
                         }
+                        uint64_t kept_mask = 0;  // lane l of this batch was kept
                         for (int l = 0; l < cntl; ++l) {
                             const int32_t si = __builtin_amdgcn_readlane(s, l) * jb.k, sj = __builtin_amdgcn_readlane(j, l);
-                            bool keep = __builtin_amdgcn_readlane(f, l) != 0;
+                            const int32_t fl = __builtin_amdgcn_readlane(f, l);
+                            bool keep = fl == 1;
+                            if (fl == 2) {  // a run on one diagonal: kept with its successor (D0)
+                                const int32_t x = __builtin_amdgcn_readlane(sc, l);  // (x > top - l: decided earlier)
+                                if (x <= top) keep = ((kept_mask >> (top - x)) & 1ull) != 0;
+                                else keep = rfl((uint32_t)flag[x]) == 1u;
+                            }
                             n_alone += keep ? 1u : 0u;
                             if (!keep) {
                                 n_search += 1;
                                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                                 keep = prune_with_kept(cx, si, sj, ring_i, ring_d, nkept < 64 ? nkept : 64, nm_lds);
-                                if (keep && lane == 0) flag[top - l] = 1;
                             }
                             if (keep) {  // MatchBuilder::push: next_match_per_diag[i - j] = i (matches.rs:229-244)
+                                kept_mask |= 1ull << l;
                                 const int e = nkept & 63;
                                 if (nkept >= 64) {
                                     const int32_t oj = ring_i[e] - ring_d[e];
@@ -481,6 +528,7 @@ __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __re
                                 nkept += 1;
                             }
                         }
+                        if (t >= 0) flag[t] = (uint8_t)((kept_mask >> lane) & 1ull);  // (final: phase F and the runs that end in later batches read it)
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

@@ -1362,6 +1362,7 @@ struct pa_batch {
     std::vector<uint32_t> win_words, slot_ratio;
     int window_override = -1;  // -1: the policy below; 0: full columns; > 0: that many words
     size_t window_retries = 0;
+    double window_retry_peak_bytes = 0;  // the largest full-height block-column store a second round of this plan held at a time
     pa_astarpa2_params aparams_c{};
     apa2::SearchParams sp{};
     DeviceBuf d_rec, d_results, d_pjobs, d_order, d_tstats, d_sh;
@@ -2935,17 +2936,22 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
         std::vector<size_t> redo;
         for (size_t i = 0; i < P; ++i)
             if (results[i].status == apa2::kErrWindow) redo.push_back(i);
+        // The second round's memory is bounded: the pairs go in sub-batches whose full-height stores stay below ~24 GB each (one pair
+        // alone may exceed it: 9.8 MB per 100 kbp pair, 1 GB per 1 Mbp pair), one sub-batch at a time; pa_batch_window_retry_bytes reports
+        // the largest.  PA_WINDOW_RETRY_BYTES overrides the bound (tests).
+        double retry_cap = 24e9;
+        if (const char* e = getenv("PA_WINDOW_RETRY_BYTES")) retry_cap = std::max(1.0, atof(e));
         for (size_t r0 = 0; r0 < redo.size();) {
-            // (a chunk's full-height store stays below ~24 GB)
             size_t r1 = r0;
             double bytes = 0;
             while (r1 < redo.size()) {
                 const size_t i = redo[r1];
                 const double need = ((double)p->n[i] / 256.0 + 2.0) * (double)((p->m[i] + 63) / 64) * 16.0;
-                if (r1 > r0 && bytes + need > 24e9) break;
+                if (r1 > r0 && bytes + need > retry_cap) break;
                 bytes += need;
                 r1 += 1;
             }
+            p->window_retry_peak_bytes = std::max(p->window_retry_peak_bytes, bytes);
             const size_t R = r1 - r0;
             std::vector<std::vector<uint8_t>> ra(R), rb(R);
             std::vector<const uint8_t*> ap(R), bp(R);
@@ -3261,6 +3267,7 @@ extern "C" size_t pa_batch_trace_fallbacks(const pa_batch* p) { return p ? p->tr
 // Pairs (summed over all pa_batch_align calls) whose band left their window of the block-column store and that were aligned again with
 // full-height slots.
 extern "C" size_t pa_batch_window_retries(const pa_batch* p) { return p ? p->window_retries : 0; }
+extern "C" double pa_batch_window_retry_bytes(const pa_batch* p) { return p ? p->window_retry_peak_bytes : 0.0; }
 
 extern "C" int pa_batch_pair_stats(const pa_batch* p, pa_astarpa2_stats* stats_out) {
     if (!p || !p->astar || !stats_out || p->pair_stats.size() != p->pairs) {

@@ -147,6 +147,10 @@ size_t pa_batch_trace_fallbacks(const pa_batch* plan);
  * block's rows only: astarpa2/src/block.rs:8-21), sized from the lengths (PA_APA2_WINDOW=<words> overrides, 0 = full columns).  Pairs
  * (summed over all pa_batch_align calls of this plan) whose band left the window and that were aligned again with full-height columns. */
 size_t pa_batch_window_retries(const pa_batch* plan);
+/* Those pairs are aligned again in sub-batches, one at a time, whose full-height stores -- (|a| / 256 + 2) x ceil(|b| / 64) x 16 bytes per
+ * pair: 9.8 MB for 100 kbp, 1 GB for 1 Mbp -- stay below 24 GB each (a single pair may exceed it; PA_WINDOW_RETRY_BYTES overrides the
+ * bound).  The largest store such a sub-batch of this plan held, in bytes (0: no pair ever left its window). */
+double pa_batch_window_retry_bytes(const pa_batch* plan);
 
 /* ---- batched A*PA2 (band-limited alignment of many pairs) ------------------------------------------------------------ */
 /* What a loop over pa_align(a, b, params, trace = 1, ..) returns -- cost, CIGAR and statistics of AstarPa2Params::simple(),

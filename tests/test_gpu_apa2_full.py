@@ -382,3 +382,25 @@ def test_reference_harness_as_one_batch(pa, oracle, preset):
     for (a, b), c in zip(pairs, costs):
         assert c == oracle.levenshtein(a, b), (len(a), len(b))
     assert len(pairs) == 8 + len(PA_TEST_NS) * len(PA_TEST_ES) + 30
+
+
+def test_the_second_round_is_bounded_in_memory(pa, oracle, monkeypatch):
+    """A batch of long-indel pairs: every band leaves its window of the block-column store, every pair is aligned again with full-height
+    columns -- in sub-batches, one at a time, whose stores stay below the bound (forced down here to two pairs' worth): the largest one is
+    reported, results equal the CPU-kernel engine, nothing goes to the host engine."""
+    a = rand_seq(30_000, seed=23)
+    pairs = []
+    for t in range(10):
+        cut = 3000 + 2000 * t
+        pairs.append((a, a[:cut] + a[cut + 6000:]))  # 6000 columns deleted somewhere: ~94 words off the diagonal
+    per_pair = (30_000 / 256 + 2) * ((24_000 + 63) // 64) * 16
+    monkeypatch.setenv("PA_WINDOW_RETRY_BYTES", str(2.5 * per_pair))
+    for prm, oc in ((pa.AstarPa2Params.simple(), oracle.params_simple()), (pa.AstarPa2Params.full(), oracle.params_full())):
+        bt = pa.Batch(pairs, params=prm)
+        costs, cigars, _, _ = bt.align()
+        retries, peak, fallbacks = bt.window_retries(), bt.window_retry_bytes(), bt.trace_fallbacks()
+        bt.close()
+        assert retries == len(pairs) and fallbacks == 0, (retries, fallbacks)
+        assert per_pair <= peak <= 2.5 * per_pair, (peak, per_pair)  # two pairs at a time: five sub-batches
+        for (x, y), c, g in list(zip(pairs, costs, cigars))[::3]:
+            assert (int(c), g) == oracle.cpu_align(x, y, oc)[:2]

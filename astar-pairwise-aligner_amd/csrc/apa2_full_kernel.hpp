@@ -381,8 +381,100 @@ struct FullDevBackend {
         }
         return lo;
     }
+    // ---- two layer windows for the SEARCH (round 5) -----------------------------------------------------------------------------------
+    // The probes of a band search sit at the band's two edges, 50-150 layers apart, and alternate between them; at either edge the
+    // score moves by about a layer per seed, a dozen layers per 256-column block.  ONE window was re-centred by every other probe
+    // (round 4: slower than none); TWO windows of 64 layers -- lane l holds the record of layer base + l -- hold both edges for
+    // several blocks: a probe tests its 64 layers against registers, the least recently used window is re-filled (one load round, what
+    // every probe cost before) when neither holds the boundary.  Within a pass the layers do not change (prune_block only marks matches).
+    int32_t sb0 = 0, sx0 = 0, sy0 = 0, sn0 = -1, sb1 = 0, sx1 = 0, sy1 = 0, sn1 = -1;
+    bool sv0 = false, sv1 = false, s_last0 = false;
+    bool search_windows = true;
+    uint32_t n_shit = 0;  // diagnostics: probes answered from a window
+    // 1: answered (*ans); 0: the boundary is not among the window's layers
+    __device__ __forceinline__ int window_probe(int32_t base, int32_t x, int32_t y, int32_t nx0, int32_t qx, int32_t qy, int32_t* ans) const {
+        const int32_t v = base + lane;
+        const bool valid = v >= 1 && v < g.nlayers;
+        bool c = false;
+        if (valid) {
+            c = x >= qx && y >= qy;
+            if (!c && nx0 >= 0) {  // an older point of the layer (rare: a layer off the chain of the alignment)
+                const PA_GLOBAL pa_i32x4* cl = (const PA_GLOBAL pa_i32x4*)g.cell;
+                int32_t nx = nx0;
+                for (int32_t guard = g.nmatch; nx >= 0 && guard > 0; --guard) {
+                    const pa_i32x4 e = cl[nx];
+                    c = e.x >= qx && e.y >= qy;
+                    nx = c ? -1 : e.z;
+                }
+            }
+        }
+        const uint64_t mt = __ballot(c);
+        if (mt) {
+            const int top = 63 - __builtin_clzll(mt);
+            if (top < 63 || base + 64 >= g.nlayers) {  // the layer above the highest "yes" says no, or does not exist: the boundary
+                *ans = base + top;
+                return 1;
+            }
+        } else if (base <= 1) {  // layer 1 is in the window and says no (or does not exist): only layer 0 is left
+            *ans = 0;
+            return 1;
+        }
+        return 0;
+    }
+    __device__ __forceinline__ void window_fill(bool first, int32_t centre) {
+        int32_t base = centre - 31;
+        if (base > g.nlayers - 64) base = g.nlayers - 64;
+        if (base < 1) base = 1;
+        const int32_t v = base + lane;
+        pa_i32x4 r = {0, 0, -1, 0};
+        if (v < g.nlayers) r = ((const PA_GLOBAL pa_i32x4*)g.lrec)[v];
+        n_round += 1;
+        if (first) {
+            sb0 = base;
+            sx0 = r.x;
+            sy0 = r.y;
+            sn0 = r.z;
+            sv0 = true;
+        } else {
+            sb1 = base;
+            sx1 = r.x;
+            sy1 = r.y;
+            sn1 = r.z;
+            sv1 = true;
+        }
+    }
+    __device__ __forceinline__ int32_t score_search(int32_t qx, int32_t qy) {
+        int32_t ans = 0;
+        if (sv0 && window_probe(sb0, sx0, sy0, sn0, qx, qy, &ans)) {
+            s_last0 = true;
+            n_shit += 1;
+            hint = ans;
+            return ans;
+        }
+        if (sv1 && window_probe(sb1, sx1, sy1, sn1, qx, qy, &ans)) {
+            s_last0 = false;
+            n_shit += 1;
+            hint = ans;
+            return ans;
+        }
+        // neither: the least recently used window moves to the last answer's neighbourhood (one load round) and is asked; a boundary
+        // that is not there either is searched in memory (64-ary), and the window is put around it
+        const bool use0 = !sv0 || (sv1 && !s_last0);
+        window_fill(use0, hint);
+        if (window_probe(use0 ? sb0 : sb1, use0 ? sx0 : sx1, use0 ? sy0 : sy1, use0 ? sn0 : sn1, qx, qy, &ans)) {
+            s_last0 = use0;
+            hint = ans;
+            return ans;
+        }
+        ans = score_mem(qx, qy);
+        window_fill(use0, ans);
+        s_last0 = use0;
+        hint = ans;
+        return ans;
+    }
     __device__ __forceinline__ int32_t score(int32_t qx, int32_t qy) {
         n_probe += 1;
+        if (!building && search_windows) return score_search(qx, qy);
         if (wvalid) {
             const int32_t v = wb + lane;
             const bool valid = v >= 1 && v < g.nlayers;
@@ -444,6 +536,7 @@ struct FullDevBackend {
         g.nlayers = 1;
         hint = 0;
         dirty = false;
+        sv0 = sv1 = false;  // (the layers are derived again: the search's windows hold nothing)
         const uint64_t t0 = tick();
         sync_mem();
         const int32_t ttx = g.n - g.m - pot(g.n), tty = g.m - g.n - pot(g.n);
@@ -576,6 +669,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_full_kernel(con
         be.rdv = rdv_lds;
         be.wave = wave_in_block;
         be.rp = rp;
+        be.search_windows = rp.search_windows != 0u;
         const uint64_t t_begin = be.tick();
         FullResult fr{};
         if (job.n > 0 && job.m > 0 && !(job.heur == kFullHeurGcsh && job.g.nmatch < 0)) {  // (nmatch < 0: the matches could not be built on the device)
@@ -588,8 +682,8 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_full_kernel(con
         if (rfl(*(const PA_GLOBAL uint32_t*)err) != PA_ERR_NONE && fr.status == kFullOk) fr.status = kFullErrOrder;
         store_full_result(be.job, fr, be.strip_instructions(), be.win_fail);
         if (probe_stats) {
-            const unsigned long long vals[9] = {be.n_probe, be.n_round, be.t_build, be.t_dp, be.t_h, be.t_index, be.t_prune, be.t_init, be.tick() - t_begin};
-            for (int q = 0; q < 9; ++q) atomicAdd(probe_stats + q, lane == 0 ? vals[q] : 0ull);
+            const unsigned long long vals[10] = {be.n_probe, be.n_round, be.t_build, be.t_dp, be.t_h, be.t_index, be.t_prune, be.t_init, be.tick() - t_begin, be.n_shit};
+            for (int q = 0; q < 10; ++q) atomicAdd(probe_stats + q, lane == 0 ? vals[q] : 0ull);
             // per pair: the XCD it ran on and how long its band search took (100 MHz ticks)
             const unsigned long long xcc = (unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);  // HW_REG_XCC_ID[2:0]
             probe_stats[16 + pair] = (xcc << 32) | (unsigned long long)(uint32_t)(be.tick() - t_begin);

@@ -2428,7 +2428,7 @@ static int launch_astar(pa_batch* p, hipStream_t s, size_t lo, size_t cnt, uint3
     rp.patience = (uint32_t)(rdv_us * 100.0);  // ticks of the 100 MHz clock
     // (measured on C4, profiles/r05_runs/prio_probe.log: `full` 11.08 -> 10.45 ms, `simple` 8.70 -> 9.12 ms: on for the first only)
     rp.prio = getenv("PA_APA2_PRIO") ? (getenv("PA_APA2_PRIO")[0] == '0' ? 0u : 1u) : (p->astar_full ? 1u : 0u);
-    rp.pad = 0;
+    rp.search_windows = (getenv("PA_APA2_SEARCH_WINDOWS") && getenv("PA_APA2_SEARCH_WINDOWS")[0] == '0') ? 0u : 1u;  // (experiments)
     unsigned long long* rdv_stats = p->d_rdv.ptr ? p->d_rdv.as<unsigned long long>() : nullptr;
     const hipError_t e = p->astar_full ? apa2::launch_apa2_full_kernel(grid, s, p->d_fjobs.as<apa2::FullJob>(), ord, (int)cnt, p->fsp, ticket, p->d_misc.as<uint32_t>() + 1, dbg,
                                                                        probe_stats ? p->d_probe.as<unsigned long long>() : nullptr, rp, rdv_stats)
@@ -3220,6 +3220,7 @@ extern "C" void pa_batch_full_info(const pa_batch* p, double* build_ms, double* 
             }
             auto q = [](std::vector<double>& x, double f) { return x.empty() ? 0.0 : x[(size_t)(f * (double)(x.size() - 1))]; };
             std::sort(all.begin(), all.end());
+            std::fprintf(stderr, "[apa2_full] h probes %llu, answered from a register window %llu, load rounds %llu\n", pr[0], pr[9], pr[1]);
             std::fprintf(stderr, "[apa2_full] per-pair band search ms: min %.2f  p10 %.2f  median %.2f  p90 %.2f  p99 %.2f  max %.2f  (%zu pairs)\n", q(all, 0), q(all, 0.1), q(all, 0.5),
                          q(all, 0.9), q(all, 0.99), q(all, 1.0), all.size());
             for (size_t x = 0; x < 8; ++x) {

@@ -9,7 +9,7 @@ struct RdvParams {
     uint32_t patience;  // ticks of the 100 MHz clock a posted strip waits for a partner before it runs alone
     uint32_t prio;      // 1: the issue priority of a wavefront follows its pair's rank in the start order (the most expensive pairs -- the
                         // launch's critical path -- are served first by their SIMDs; the cheap pairs that fill the rest have the slack)
-    uint32_t pad;
+    uint32_t search_windows;  // apa2_full_kernel: 1 = the h probes of the search go through two register windows of 64 layer records
 };
 
 // s_setprio takes an immediate

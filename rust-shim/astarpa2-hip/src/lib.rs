@@ -96,6 +96,9 @@ extern "C" {
                                        cigar_out: *mut *mut c_char, stats_out: *mut PaAstarPa2Stats) -> i32;
     pub fn pa_runtime_hints() -> i32;
     pub fn pa_release_pools();
+    /// Round 5: callers that are inside `pa_align` (or an astarpa-c symbol) at the same time are combined into one batch on the GPU;
+    /// calls served that way so far and the batches they went out in (include/pa_astarpa2.h).
+    pub fn pa_combine_stats(calls: *mut u64, batches: *mut u64);
 }
 
 /// The text form of `Cigar::to_string` (count omitted when 1; `=`, `X`, `I`, `D`; astarpa-c/example.cpp:16 `"=I4=X="`).

@@ -90,7 +90,7 @@ def test_c_layout_program_compiles():
         import pytest
 
         pytest.skip("no C compiler")
-    for prog in ("layout_check.c", "link_check.c", "ctx_check.c", "batch_view_check.c"):
+    for prog in ("layout_check.c", "link_check.c", "ctx_check.c", "batch_view_check.c", "dropin_threads.c"):
         subprocess.run([gcc, "-fsyntax-only", "-Wall", "-I", str(ROOT / "include"), str(ROOT / "tests" / "c_abi" / prog)], check=True)
 
 

@@ -2151,13 +2151,36 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
                 const size_t end = std::min(total, base + kChunk);
                 if (used[buf]) ok = hip_ok(hipEventSynchronize(done[buf]), "event sync");
                 while (pair < pairs && off[pair] + len[pair] <= base) ++pair;
-                size_t cur = base;  // only the padding between two sequences needs zeroing
+                // the pieces of this chunk: (pair, first byte, end, end of the piece before) -- only the padding between two sequences
+                // needs zeroing.  A big chunk is gathered by several threads (round 5: one thread copies 12-16 GB/s, less than the link
+                // takes; the C4 batch's 200 MB: 12.5 ms of its 16 ms creation)
+                struct Piece {
+                    size_t q, lo, hi, prev;
+                };
+                std::vector<Piece> pieces;
+                size_t cur = base;
                 for (size_t q = pair; q < pairs && off[q] < end; ++q) {
                     const size_t lo = std::max(off[q], base), hi = std::min(off[q] + len[q], end);
                     if (lo >= hi) continue;
-                    if (lo > cur) std::memset(stage[buf] + (cur - base), 0, lo - cur);
-                    std::memcpy(stage[buf] + (lo - base), src[q] + (lo - off[q]), hi - lo);
+                    pieces.push_back(Piece{q, lo, hi, cur});
                     cur = hi;
+                }
+                uint8_t* const dst = stage[buf];
+                auto gather = [&, dst, base](size_t p0, size_t p1) {
+                    for (size_t t = p0; t < p1; ++t) {
+                        const Piece& pc = pieces[t];
+                        if (pc.lo > pc.prev) std::memset(dst + (pc.prev - base), 0, pc.lo - pc.prev);
+                        std::memcpy(dst + (pc.lo - base), src[pc.q] + (pc.lo - off[pc.q]), pc.hi - pc.lo);
+                    }
+                };
+                const size_t nthreads = (end - base >= (size_t(8) << 20) && pieces.size() >= 8) ? 4 : 1;
+                if (nthreads > 1) {
+                    std::vector<std::thread> th;
+                    for (size_t t = 1; t < nthreads; ++t) th.emplace_back(gather, pieces.size() * t / nthreads, pieces.size() * (t + 1) / nthreads);
+                    gather(0, pieces.size() / nthreads);
+                    for (auto& x : th) x.join();
+                } else {
+                    gather(0, pieces.size());
                 }
                 if (end > cur) std::memset(stage[buf] + (cur - base), 0, end - cur);
                 ok = ok && hip_ok(hipMemcpyAsync(dev + base, stage[buf], end - base, hipMemcpyHostToDevice, p->stream), "H2D sequences") &&

@@ -321,6 +321,16 @@ __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __re
                     h = (h + 1u) & mask;
                 }
             }
+            // In front of the table: one bit per hashed seed key (round 5; csrc/gcsh.hpp does the same on the host).  Almost every position
+            // of b matches no seed at all, and half of those still find their table slot occupied (two dependent loads from global
+            // memory): 64 K bits in the LDS array phase D will use later stop seven of eight positions with one LDS read.
+            uint32_t* const sieve = (uint32_t*)&lds_fr[0][0];  // 2048 words of the 3968
+            for (int32_t t = lane; t < 2048; t += 64) sieve[t] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            for (int32_t s = lane; s < jb.nseeds; s += 64) {
+                const uint32_t hb = (keys[s] * 0x85EBCA6Bu) >> 16;
+                atomicOr(sieve + (hb >> 5), 1u << (hb & 31u));
+            }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             lap(0);
             // ---- B. every k-mer of b: candidates in rows ascending, seeds DESCENDING within a row (read backwards that is the order the
@@ -336,7 +346,8 @@ __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __re
                 if (valid) {
                     const uint32_t key = kmer_key(b + j, jb.k);
                     uint32_t h = key_hash(key, mask);
-                    for (;;) {
+                    const uint32_t hb = (key * 0x85EBCA6Bu) >> 16;
+                    for (; (sieve[hb >> 5] >> (hb & 31u)) & 1u;) {
                         const int32_t cur = slot[h];
                         if (cur < 0) break;
                         if (keys[cur] == key && same_kmer(a + (size_t)cur * jb.k, b + j, jb.k)) {

@@ -52,6 +52,7 @@ struct FullDevBackend {
     int wave = 0;
     RdvParams rp{0u, 0u, 0u, 0u};
     mutable rdv::Counters rdv_cnt;
+    int32_t my_prio = 0;  // this wavefront's issue priority while it runs this pair (RdvParams::prio)
     uint32_t n_probe = 0, n_round = 0;  // diagnostics: h probes and the load rounds they took
     bool timing = false;                // diagnostics (PA_APA2_PROBE_STATS): phase clocks, 100 MHz ticks
     mutable uint64_t t_build = 0, t_dp = 0, t_h = 0, t_index = 0, t_prune = 0, t_init = 0;
@@ -299,7 +300,7 @@ struct FullDevBackend {
             // the tap: the deltas leaving the lane whose last row is 64 wt - 1, if that row is in this strip
             int tl = -1;
             if (tap_inside && wt > sw0 && wt <= sw0 + take) tl = kk == 2 ? (wt - sw0) - 1 : 2 * (wt - sw0) - 1;
-            if (kk == 1 && rp.enabled && dual_ok(j) && rdv_strip<true>(rdv, wave, rp, j, tl, err, &rdv_cnt, &strip_units)) {
+            if (kk == 1 && rp.enabled && dual_ok(j) && rdv_strip<true>(rdv, wave, rp, j, tl, err, &rdv_cnt, &strip_units, my_prio)) {
                 sync_mem();
                 ck = -1;
                 break;  // (a strip that qualifies is the block's only one)
@@ -669,6 +670,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_full_kernel(con
         be.rdv = rdv_lds;
         be.wave = wave_in_block;
         be.rp = rp;
+        be.my_prio = rp.prio ? PA_PRIO_OF_RANK(t, npairs) : 0;
         be.search_windows = rp.search_windows != 0u;
         const uint64_t t_begin = be.tick();
         FullResult fr{};

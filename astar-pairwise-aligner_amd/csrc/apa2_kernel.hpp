@@ -49,6 +49,7 @@ struct DevBackend {
     int wave = 0;
     RdvParams rp{0u, 0u, 0u, 0u};
     mutable rdv::Counters rdv_cnt;
+    int32_t my_prio = 0;  // this wavefront's issue priority while it runs this pair (RdvParams::prio)
     __device__ __forceinline__ uint64_t strip_instructions() const { return (uint64_t)strip_units << 5; }
 
     // (own_sgpr on the descriptor's fields was tried here too, round 4: C4 forward 11.4 -> 11.7 ms -- this kernel's band logic is short
@@ -195,7 +196,7 @@ struct DevBackend {
             j.hin_n = 0;
             j.vsum_out = nullptr;
             // (a strip that is not the last one is full, the last one does not need an exact bottom row: NOPASS)
-            if (kk == 1 && rp.enabled && dual_ok(j) && rdv_strip<false>(rdv, wave, rp, j, -1, err, &rdv_cnt, &strip_units)) {
+            if (kk == 1 && rp.enabled && dual_ok(j) && rdv_strip<false>(rdv, wave, rp, j, -1, err, &rdv_cnt, &strip_units, my_prio)) {
                 // (this block and a block of another wavefront ran as one strip -- or a partner ran it: the column and the sum are in memory)
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 break;
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_kernel(const Pa
         be.rdv = rdv_lds;
         be.wave = wave_in_block;
         be.rp = rp;
+        be.my_prio = rp.prio ? PA_PRIO_OF_RANK(t, npairs) : 0;
         be.mark(7, (uint32_t)pair + 1u);
         PairProg<DevBackend> prog(be, hp, sp);
         PairResult res;

@@ -13,6 +13,7 @@ struct RdvParams {
 };
 
 // s_setprio takes an immediate
+#define PA_PRIO_OF_RANK(t, npairs) ((uint32_t)(t) < (uint32_t)(npairs) / 8u ? 3 : ((uint32_t)(t) < (uint32_t)(npairs) / 4u ? 2 : ((uint32_t)(t) < (uint32_t)(npairs) / 2u ? 1 : 0)))
 #define PA_SETPRIO_BY_RANK(t, npairs)                                               \
     do {                                                                            \
         const uint32_t t_ = (uint32_t)(t), n_ = (uint32_t)(npairs);                 \

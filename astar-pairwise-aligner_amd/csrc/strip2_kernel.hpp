@@ -30,7 +30,7 @@ struct DualJob {
     uint8_t* hout_arr;        // TAP: receives the deltas leaving logical lane `tap` (when tap >= 0)
     const uint32_t* values;   // TAP: source of the left edge (the previous block's column; words [fill_word0, fill_stride)), or nullptr => v
     int32_t* sum_out;         // bottom-row sum
-    int32_t n, word0, nlanes, fill_stride, fill_word0, col0, tap, pad;
+    int32_t n, word0, nlanes, fill_stride, fill_word0, col0, tap, prio;  // prio: the issue priority of the wavefront that owns the strip (0..3)
 };
 static_assert(sizeof(DualJob) == 88, "DualJob layout");
 constexpr int kDualWords = 22;
@@ -52,7 +52,7 @@ __device__ __forceinline__ DualJob dual_from(const StripJob& j, int tap) {
     d.fill_word0 = j.fill_word0;
     d.col0 = j.col0;
     d.tap = TAP ? tap : -1;
-    d.pad = 0;
+    d.prio = 0;
     return d;
 }
 // Does a strip of the band-search kernels qualify (see the header)?
@@ -309,6 +309,7 @@ struct RdvLds {
         PA_PUT(18, j.fill_word0);
         PA_PUT(19, j.col0);
         PA_PUT(20, j.tap);
+        PA_PUT(21, j.prio);
 #undef PA_PUT_PTR
 #undef PA_PUT
         *(base + 128 + 64 * w + lane) = x;
@@ -332,7 +333,7 @@ struct RdvLds {
         j.fill_word0 = (int32_t)get(18);
         j.col0 = (int32_t)get(19);
         j.tap = (int32_t)get(20);
-        j.pad = 0;
+        j.prio = (int32_t)get(21);
         return j;
     }
 };
@@ -350,10 +351,19 @@ constexpr uint64_t kRdvHardTicks = 2ull * 100000000ull;  // 2 s: a taken strip t
 
 // A qualifying strip of wavefront `w` arrives.  Returns true when the strip has been computed (by this wavefront together with a
 // partner's, or by a partner): its results are in memory.  false: run it alone.
+__device__ __forceinline__ void set_prio(int32_t pr) {  // (s_setprio takes an immediate)
+    if (pr >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+    else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
+// `my_prio`: this wavefront's issue priority (RdvParams::prio: by its pair's rank in the start order).  A fused strip runs at the HIGHER of
+// the two owners' priorities: the strip of a pair on the launch's critical path must not run at the pace of a cheap pair that took it.
 template <bool TAP>
 __device__ __forceinline__ bool rdv_strip(const RdvLds& p, int w, const RdvParams& rp, const StripJob& sj, int tap, uint32_t* err, rdv::Counters* cnt,
-                                          uint32_t* strip_units) {
-    const DualJob mine = dual_from<TAP>(sj, tap);
+                                          uint32_t* strip_units, int32_t my_prio = 0) {
+    DualJob mine = dual_from<TAP>(sj, tap);
+    mine.prio = my_prio;
     p.write_mail(w, mine);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the mail and everything this block's strip reads (left edge, stored row)
     int partner = -1;
@@ -363,7 +373,10 @@ __device__ __forceinline__ bool rdv_strip(const RdvLds& p, int w, const RdvParam
     if (r == rdv::kTook) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const DualJob theirs = p.read_mail(partner);
+        const bool lift = theirs.prio > my_prio;
+        if (lift) set_prio(theirs.prio);
         run_strip_dual<TAP>(theirs, mine);
+        if (lift) set_prio(my_prio);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // both strips' results, before the partner wakes up
         rdv::finish(pol, partner);
         const int nmax = mine.n > theirs.n ? mine.n : theirs.n;

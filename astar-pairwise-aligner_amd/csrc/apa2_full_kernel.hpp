@@ -649,7 +649,11 @@ __device__ __forceinline__ void store_full_result(const FullJob& job, const Full
 // Pairs are claimed by ticket in the order of `order` (heaviest first); a block is four independent wavefronts.
 // probe_stats (optional, diagnostics): [0] += h probes, [1] += load rounds they took, [2..9) += phase clocks (pa_batch_full_info).
 #ifdef PA_UNIT_APA2_FULL  // (the kernel is compiled in a translation unit of its own: csrc/apa2_units.hpp)
-__global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_full_kernel(const FullJob* __restrict__ jobs, const int32_t* __restrict__ order, int npairs,
+#ifndef PA_APA2_FULL_WAVES
+#define PA_APA2_FULL_WAVES 5  // wavefronts per SIMD the register allocator is asked for: 96 VGPRs with 2 spilled (4: 104, none).  Round 5: C4 10.57 ->
+                              // 10.27 ms, 40 000 pairs 37.6 -> 34.4 ms, 4096 x 100 kbp unchanged (profiles/r05_runs/waves5.log)
+#endif
+__global__ __launch_bounds__(64 * kStripBlockWaves, PA_APA2_FULL_WAVES) void apa2_full_kernel(const FullJob* __restrict__ jobs, const int32_t* __restrict__ order, int npairs,
                                                                          FullParams sp, uint32_t* ticket, uint32_t* err, uint32_t* dbg,
                                                                          unsigned long long* probe_stats, RdvParams rp, unsigned long long* rdv_stats) {
     const int lane = (int)(threadIdx.x & 63);

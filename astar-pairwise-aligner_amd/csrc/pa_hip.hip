@@ -2431,7 +2431,8 @@ extern "C" pa_batch* pa_batch_create_params(const uint8_t* const* a, const size_
 static int launch_astar(pa_batch* p, hipStream_t s, size_t lo, size_t cnt, uint32_t* ticket, uint32_t* dbg) {
     if (cnt == 0) return 0;
     // a persistent grid: wavefronts pull pairs by ticket; at most kApa2BlocksPerCu blocks of four wavefronts per CU
-    static const int per_cu = getenv("PA_APA2_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("PA_APA2_BLOCKS_PER_CU"))) : 4;
+    // (apa2_full_kernel fits five wavefronts per SIMD, apa2_kernel -- four strip heights, 128 VGPRs -- four)
+    const int per_cu = getenv("PA_APA2_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("PA_APA2_BLOCKS_PER_CU"))) : (p->astar_full ? 5 : 4);
     static const bool probe_stats = getenv("PA_APA2_PROBE_STATS") != nullptr;
     const int cus = g_device_props_cus > 0 ? g_device_props_cus : 256;
     const int grid = (int)std::min<size_t>((cnt + kStripBlockWaves - 1) / kStripBlockWaves, (size_t)cus * per_cu);

@@ -91,6 +91,11 @@ extern "C" {
                                   params: *const PaAstarPa2Params) -> *mut core::ffi::c_void;
     pub fn pa_batch_pair_stats(plan: *const core::ffi::c_void, stats_out: *mut PaAstarPa2Stats) -> i32;
     pub fn pa_batch_params_supported(params: *const PaAstarPa2Params) -> i32;
+    /// Diagnostics (round 5): how the half-wave blocks of the last forward pass met -- out4 = fused, served by a partner, alone, withdrawn.
+    pub fn pa_batch_rdv_stats(plan: *const core::ffi::c_void, out4: *mut u64) -> i32;
+    /// Pairs whose band left their window of the block-column store and were aligned again / the largest store such a second round held.
+    pub fn pa_batch_window_retries(plan: *const core::ffi::c_void) -> usize;
+    pub fn pa_batch_window_retry_bytes(plan: *const core::ffi::c_void) -> f64;
     pub fn pa_batch_align_multi_params(a: *const *const u8, a_len: *const usize, b: *const *const u8, b_len: *const usize, pairs: usize,
                                        devices: *const i32, ndevices: i32, params: *const PaAstarPa2Params, cost_out: *mut i32,
                                        cigar_out: *mut *mut c_char, stats_out: *mut PaAstarPa2Stats) -> i32;

@@ -1023,7 +1023,12 @@ int combine_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len
         c.in_flight += 1;
         c.cv.notify_all();  // (whoever is still pending may gather the next batch)
         lk.unlock();
-        run_group(group, params);
+        try {
+            run_group(group, params);
+        } catch (...) {  // (out of host memory while gathering: nobody may be left waiting -- every caller of the group takes the single-pair path)
+            t_in_combiner = false;
+            for (CombineReq* r : group) r->rc = kNotCombined;
+        }
         lk.lock();
         for (CombineReq* r : group) r->done = true;
         c.in_flight -= 1;

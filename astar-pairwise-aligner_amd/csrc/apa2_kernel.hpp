@@ -314,6 +314,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_kernel(const Pa
         be.rp = rp;
         be.my_prio = rp.prio ? PA_PRIO_OF_RANK(t, npairs) : 0;
         be.mark(7, (uint32_t)pair + 1u);
+        const uint64_t t_pair0 = wall_clock64();
         PairProg<DevBackend> prog(be, hp, sp);
         PairResult res;
         if (job.n > 0 && job.m > 0) {
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(64 * kStripBlockWaves, 4) void apa2_kernel(const Pa
             res = PairResult{};
             res.status = kErrDegenerate;
         }
+        res.pad0 = (uint32_t)(wall_clock64() - t_pair0);  // diagnostics: how long the pair's band search took its wavefront (100 MHz ticks; PA_ALIGN_PROFILE prints the spread)
         if (be.win_fail) res.status = kErrWindow;
         else if (rfl(*(const PA_GLOBAL uint32_t*)err) != PA_ERR_NONE && res.status == kOk) res.status = kErrDevice;
         *job.result = res;  // (every lane stores the same 64 bytes: no lane-dependent branch at the end of the loop body either)

@@ -2927,6 +2927,17 @@ extern "C" int pa_batch_align(pa_batch* p, int32_t* cost_out, char** cigar_out, 
         if (P && (!hip_ok(hipMemcpy(results.data(), p->d_results.ptr, P * sizeof(apa2::PairResult), hipMemcpyDeviceToHost), "D2H results") ||
                   !hip_ok(hipMemcpy(ts.data(), p->d_tstats.ptr, P * 32, hipMemcpyDeviceToHost), "D2H trace stats")))
             return fail_all(PA_E_HIP);
+        if (prof && !p->astar_full && P) {  // diagnostics: the spread of the pairs' band-search times (what ends the launch: the work, or a few chains?)
+            std::vector<double> ms;
+            for (const apa2::PairResult& r : results)
+                if (r.pad0) ms.push_back((double)r.pad0 / 1e5);
+            std::sort(ms.begin(), ms.end());
+            auto q = [&](double f) { return ms.empty() ? 0.0 : ms[(size_t)(f * (double)(ms.size() - 1))]; };
+            double sum = 0;
+            for (double x : ms) sum += x;
+            std::fprintf(stderr, "[pa_batch_align] per-pair band search ms: min %.2f  median %.2f  p90 %.2f  p99 %.2f  p99.9 %.2f  max %.2f  sum %.1f  (%zu pairs)\n", q(0), q(0.5), q(0.9),
+                         q(0.99), q(0.999), q(1.0), sum, ms.size());
+        }
         p->pair_stats.assign(P, pa_astarpa2_stats{});
         p->apa2_strip_instr = 0;
         for (size_t i = 0; i < P; ++i) {

@@ -14,6 +14,7 @@
 #include <thread>
 #include <vector>
 
+#include "combine_logic.hpp"
 #include "engine_capi.hpp"
 #include "pa_hip_internal.hpp"
 #include "sweep_host.hpp"
@@ -902,11 +903,7 @@ struct CombineReq {
 };
 struct Combiner {
     pa_astarpa2_params params;  // the key (byte-wise: a parameter set is plain data)
-    std::mutex mu;
-    std::condition_variable cv;
-    std::vector<CombineReq*> pending;
-    bool collecting = false;  // a caller is gathering the next batch
-    int in_flight = 0;        // batches on the GPU right now
+    combine::Gatherer<CombineReq> g;  // the gathering protocol (combine_logic.hpp; oracle/combine_emu.cpp runs it on host threads under TSan)
 };
 std::mutex& g_comb_mu = *new std::mutex;
 std::vector<Combiner*>& g_combs = *new std::vector<Combiner*>;  // (never destroyed: callers may be inside at exit)
@@ -996,45 +993,19 @@ int combine_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len
                   std::string* cigar_out, pa_astarpa2_stats* stats_out) {
     Combiner& c = combiner_for(params);
     CombineReq req{a, a_len, b, b_len};
-    std::unique_lock<std::mutex> lk(c.mu);
-    c.pending.push_back(&req);
-    c.cv.notify_all();  // (a gathering caller counts the arrivals)
-    while (!req.done) {
-        // Somebody has to gather a batch: the first caller that finds nobody gathering (and fewer than kCombineInFlight batches on the
-        // GPU) does.  It collects for kCombineWindow -- a call lasts as long as its batch, a batch of short pairs about 8 ms whatever its
-        // size, so N callers complete N calls per (batch + window): the window is cheap and decides the batch size -- then runs the batch
-        // while the NEXT caller already gathers the next one (several batches side by side on streams of their own).
-        if (c.collecting || c.in_flight >= kCombineInFlight) {
-            c.cv.wait(lk);
-            continue;
-        }
-        c.collecting = true;
-        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(kCombineWindowUs);
-        while (c.pending.size() < kCombineMaxGroup && (int)c.pending.size() < g_inside.load(std::memory_order_relaxed) &&
-               c.cv.wait_until(lk, deadline) != std::cv_status::timeout) {
-        }
-        std::vector<CombineReq*> group;
-        if (c.pending.size() <= kCombineMaxGroup) group.swap(c.pending);
-        else {
-            group.assign(c.pending.begin(), c.pending.begin() + (long)kCombineMaxGroup);
-            c.pending.erase(c.pending.begin(), c.pending.begin() + (long)kCombineMaxGroup);
-        }
-        c.collecting = false;
-        c.in_flight += 1;
-        c.cv.notify_all();  // (whoever is still pending may gather the next batch)
-        lk.unlock();
-        try {
-            run_group(group, params);
-        } catch (...) {  // (out of host memory while gathering: nobody may be left waiting -- every caller of the group takes the single-pair path)
-            t_in_combiner = false;
-            for (CombineReq* r : group) r->rc = kNotCombined;
-        }
-        lk.lock();
-        for (CombineReq* r : group) r->done = true;
-        c.in_flight -= 1;
-        c.cv.notify_all();  // the served ones leave
-    }
-    lk.unlock();
+    // A call lasts as long as its batch, and a batch of short pairs takes about 6 ms whatever its size, so N callers complete N calls per
+    // (batch + window): the window is cheap and decides the batch size; several batches run side by side on streams of their own.
+    c.g.submit(
+        req,
+        [&](std::vector<CombineReq*>& group) {
+            try {
+                run_group(group, params);
+            } catch (...) {  // (out of host memory while gathering: every caller of the group takes the single-pair path)
+                t_in_combiner = false;
+                throw;
+            }
+        },
+        [] { return g_inside.load(std::memory_order_relaxed); }, kCombineMaxGroup, kCombineInFlight, kCombineWindowUs, kNotCombined);
     if (req.rc != 0) return kNotCombined;
     if (cost_out) *cost_out = req.cost;
     if (cigar_out) *cigar_out = std::move(req.cigar);

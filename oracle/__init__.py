@@ -26,7 +26,7 @@ H_DTYPE = np.dtype([("p", "<u8"), ("m", "<u8")])
 BITS_DTYPE = np.dtype([("b0", "<u8"), ("b1", "<u8")])
 
 
-_TARGETS = ("libpa_oracle.so", "libpa_engine_cpu.so", "libpa_sweep_emu.so", "libpa_apa2_emu.so", "libpa_apa2_full_emu.so", "libpa_rdv_emu.so")
+_TARGETS = ("libpa_oracle.so", "libpa_engine_cpu.so", "libpa_sweep_emu.so", "libpa_apa2_emu.so", "libpa_apa2_full_emu.so", "libpa_rdv_emu.so", "libpa_combine_emu.so")
 
 
 def _source_hash() -> str:
@@ -37,7 +37,7 @@ def _source_hash() -> str:
     h = hashlib.sha256()
     csrc = _DIR.parent / "astar-pairwise-aligner_amd" / "csrc"
     files = sorted(list(_DIR.glob("*.c")) + list(_DIR.glob("*.cpp")) + list(_DIR.glob("*.h")) + list(_DIR.glob("*.hpp")) + [_DIR / "Makefile"] +
-                   [csrc / n for n in ("engine.hpp", "gcsh.hpp", "engine_capi.hpp", "sweep_logic.hpp", "sweep_wave.hpp", "sweep_host.hpp", "apa2_logic.hpp", "apa2_full_logic.hpp", "gcsh_dev.hpp", "rdv_logic.hpp")] +
+                   [csrc / n for n in ("engine.hpp", "gcsh.hpp", "engine_capi.hpp", "sweep_logic.hpp", "sweep_wave.hpp", "sweep_host.hpp", "apa2_logic.hpp", "apa2_full_logic.hpp", "gcsh_dev.hpp", "rdv_logic.hpp", "combine_logic.hpp")] +
                    [_DIR.parent / "include" / "pa_astarpa2.h"])
     for f in files:
         h.update(f.name.encode())
@@ -472,3 +472,21 @@ def rdv_emu_run(pairs, groups: int = 2, patience_us: float = 200.0):
         raise RuntimeError(f"pa_rdv_emu_run rc={rc}")
     rows = [tuple(int(out[8 * i + k]) for k in range(6)) for i in range(n)]
     return rows, dict(zip(("fused", "served", "alone", "withdrawn"), (int(x) for x in cnt)))
+
+
+_clib = None
+
+
+def combine_emu_run(threads: int, calls: int, batch_us: int = 300, fail_every: int = 0) -> dict:
+    """oracle/combine_emu.cpp: the call combiner's gathering protocol (csrc/combine_logic.hpp) on `threads` host threads with a stand-in
+    batch -> wrong results, batches, the largest group, batches side by side, requests whose batch failed."""
+    global _clib
+    build()
+    if _clib is None:
+        L = C.CDLL(str(_DIR / "_build" / "libpa_combine_emu.so"))
+        L.pa_combine_emu_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.pa_combine_emu_run.restype = C.c_int
+        _clib = L
+    out = (C.c_int64 * 5)()
+    _clib.pa_combine_emu_run(threads, calls, batch_us, fail_every, out)
+    return dict(zip(("wrong", "batches", "largest_group", "side_by_side", "failed"), (int(x) for x in out)))

@@ -902,7 +902,9 @@ struct CombineReq {
     std::string err;
 };
 struct Combiner {
-    pa_astarpa2_params params;  // the key (byte-wise: a parameter set is plain data)
+    pa_astarpa2_params params;  // the key (byte-wise: a parameter set is plain data) ...
+    int device = 0;             // ... together with the device the callers are bound to (pa_set_device is per thread): callers on different
+                                // GPUs are not mixed, a batch runs on the device of those who asked for it
     combine::Gatherer<CombineReq> g;  // the gathering protocol (combine_logic.hpp; oracle/combine_emu.cpp runs it on host threads under TSan)
 };
 std::mutex& g_comb_mu = *new std::mutex;
@@ -941,11 +943,14 @@ inline bool combine_now() {
 }
 
 Combiner& combiner_for(const pa_astarpa2_params& params) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g_comb_mu);
     for (Combiner* c : g_combs)
-        if (std::memcmp(&c->params, &params, sizeof(params)) == 0) return *c;
+        if (c->device == dev && std::memcmp(&c->params, &params, sizeof(params)) == 0) return *c;
     Combiner* c = new Combiner;
     c->params = params;
+    c->device = dev;
     g_combs.push_back(c);
     return *c;
 }

@@ -30,6 +30,16 @@ def work(job):
     return row_of(cost, cigar, stats)
 
 
+def work_long(job):
+    from oracle import astarpa2_restated as restated
+    from tests.restated_fixture import long_pair_for, row_of
+
+    name, kw, i = job
+    a, b = long_pair_for(i)
+    cost, cigar, stats = restated.align(a, b, **kw)
+    return row_of(cost, cigar, stats)
+
+
 def main():
     from tests.restated_fixture import GOLDEN, KEYS, N_PAIRS
     from tests.test_restated_engine import variants
@@ -37,7 +47,21 @@ def main():
     nproc = int(sys.argv[1]) if len(sys.argv) > 1 else (os.cpu_count() or 1)
     only = set(sys.argv[2:])
     vs = {name: kw for name, (_, kw) in variants(_NoOracle()).items()}
+    from tests.restated_fixture import LONG_VARIANTS, N_LONG
+
     with get_context("spawn").Pool(nproc) as pool:
+        for name in LONG_VARIANTS:  # the long pairs (python tests/golden/make_restated.py 8 long: these alone)
+            if only and "long" not in only and name not in only:
+                continue
+            t0 = time.time()
+            rows = pool.map(work_long, [(name, vs[name], i) for i in range(N_LONG)], chunksize=1)
+            doc = {"variant": name, "restated_kwargs": vs[name], "pairs": "tests/restated_fixture.py long_pair_for(i), i = 0 .. n_pairs - 1",
+                   "row": ["cost", "sha256(cigar)[:16]"] + KEYS, "n_pairs": N_LONG,
+                   "source": "oracle/astarpa2_restated.py (second restatement; no csrc/ code involved)", "rows": rows}
+            (GOLDEN / f"restated_long_{name}.json").write_text(json.dumps(doc, separators=(",", ":")) + "\n")
+            print(f"long {name}: {len(rows)} rows in {time.time() - t0:.1f} s", flush=True)
+        if only == {"long"}:
+            return
         for name, kw in vs.items():
             if only and name not in only:
                 continue

@@ -62,7 +62,7 @@ def load(name: str) -> dict:
 
 
 def variant_names() -> list:
-    return sorted(p.stem[len("restated_"):] for p in GOLDEN.glob("restated_*.json"))
+    return sorted(p.stem[len("restated_"):] for p in GOLDEN.glob("restated_*.json") if not p.stem.startswith("restated_long_"))
 
 
 def params_from_kwargs(pa, kw: dict):
@@ -77,3 +77,27 @@ def params_from_kwargs(pa, kw: dict):
                              front=pa.BlockParams(sparse=d["sparse"], simd=True, no_ilp=False, incremental_doubling=d["incremental_doubling"],
                                                   dt_trace=d["dt_trace"], max_g=d["max_g"], fr_drop=d["fr_drop"]),
                              sparse_h=d["sparse_h"], prune=d["prune"])
+
+
+# ---- a second, smaller set of LONG pairs: bands of several strips (the K = 2 / 3 / 4 strips with their `eq` words in LDS), window retries,
+#      re-fills taller than a strip -- tests/golden/restated_long_<variant>.json, same row format ----
+N_LONG = 96
+LONG_VARIANTS = ["simple", "full", "sh12", "gap_incr", "dijkstra", "gcsh_noprune", "linear300", "gap_nodt"]
+
+
+def long_pair_for(i: int):
+    """Long pair i: 8 000 .. 60 000 bases, divergence 1 .. 20 %, a third with one long indel (up to 4 000 bases)."""
+    rng = random.Random(0x10DE0000 + i)
+    n = rng.randint(8_000, 60_000)
+    e = rng.choice([0.01, 0.03, 0.05, 0.08, 0.12, 0.2])
+    a, b = gen_pair(n, e, rng.randint(1, 10**9))
+    if rng.random() < 0.34:
+        cut = rng.randint(0, len(b) - 1)
+        ln = rng.randint(200, 4000)
+        b = b[:cut] + b[cut + ln:] if rng.random() < 0.5 else b[:cut] + rand_seq(ln, rng.randint(1, 10**9)) + b[cut:]
+        b = b or b"A"
+    return a, b
+
+
+def load_long(name: str) -> dict:
+    return json.loads((GOLDEN / f"restated_long_{name}.json").read_text())

@@ -55,3 +55,27 @@ def test_fixture_through_the_batch_kernels_and_pa_align(pa, pairs, name):
 def test_the_batch_kernels_take_most_parameter_sets(pa):
     n = sum(bool(pa.capi.batch_params_supported(rf.params_from_kwargs(pa, rf.load(name)["restated_kwargs"]))) for name in NAMES)
     assert len(NAMES) == 26 and n >= 18
+
+
+@pytest.mark.parametrize("name", rf.LONG_VARIANTS)
+def test_long_pairs_fixture(pa, name, monkeypatch):
+    """The LONG pairs of the second restatement (8 000 - 60 000 bases, up to 20 % divergence, long indels): bands of several strips -- the
+    K = 2 / 3 / 4 strips, `eq` words in LDS --, pairs whose band leaves their window of the column store (aligned again with full
+    columns), re-fills taller than a strip in the traceback.  One batch with two pairs per strip forced on, one with it off, and every
+    eighth pair through pa_align."""
+    doc = rf.load_long(name)
+    rows = doc["rows"]
+    prm = rf.params_from_kwargs(pa, doc["restated_kwargs"])
+    pairs = [rf.long_pair_for(i) for i in range(rf.N_LONG)]
+    assert pa.capi.batch_params_supported(prm)
+    for mode in ("2", "0"):
+        monkeypatch.setenv("PA_APA2_RDV", mode)
+        bt = pa.Batch(pairs, params=prm)
+        costs, cigars, _, _ = bt.align()
+        stats = bt.pair_stats()
+        bt.close()
+        bad = [i for i in range(rf.N_LONG) if rf.row_of(costs[i], cigars[i], stats[i]) != rows[i]]
+        assert not bad, (name, mode, bad[:5], [(rf.row_of(costs[i], cigars[i], stats[i]), rows[i]) for i in bad[:2]])
+    al = prm.make_aligner(True)
+    for i in range(rf.LONG_VARIANTS.index(name) % 8, rf.N_LONG, 8):
+        assert rf.row_of(*al.align_with_stats(*pairs[i])) == rows[i], (name, i)

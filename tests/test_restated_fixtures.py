@@ -42,3 +42,17 @@ def test_sample_regenerates_and_equals_the_cpu_kernel_engine(oracle, part):
             if i % 128 == vi % 32:  # (the pure-Python restatement is the slow side: a quarter of the sample)
                 assert rf.row_of(*restated.align(a, b, **kw)) == rows[i], (name, i)  # the file is what the generator writes
             assert rf.row_of(*oracle.cpu_align(a, b, prm)) == rows[i], (name, i)   # ... and what csrc/engine.hpp over the CPU kernels returns
+
+
+def test_long_pairs_fixture_on_the_cpu(oracle):
+    """tests/golden/restated_long_<set>.json: a sample against the CPU-kernel engine (and, for two pairs per set, the generator itself)."""
+    vs = variants(oracle)
+    for name in rf.LONG_VARIANTS:
+        prm, kw = vs[name]
+        doc = rf.load_long(name)
+        assert doc["n_pairs"] == rf.N_LONG and doc["restated_kwargs"] == kw
+        for i in range(rf.LONG_VARIANTS.index(name), rf.N_LONG, 12):
+            a, b = rf.long_pair_for(i)
+            assert rf.row_of(*oracle.cpu_align(a, b, prm)) == doc["rows"][i], (name, i)
+            if i < 24:
+                assert rf.row_of(*restated.align(a, b, **kw)) == doc["rows"][i], (name, i)

@@ -913,7 +913,11 @@ std::atomic<int> g_inside{0};              // callers inside the traced path of 
 std::atomic<uint64_t> g_comb_calls{0}, g_comb_batches{0};
 thread_local bool t_in_combiner = false;   // the leader's own batch may hand a pair back to pa_align's engine: that call is not combined again
 constexpr int kNotCombined = 1;
-constexpr size_t kCombineMaxLen = 32768;   // longer pairs keep the single-pair engine (many wavefronts per pass; pa_bitpacking_hip.h "small route")
+// Longer pairs keep the single-pair engine (many wavefronts per pass).  PA_COMBINE_MAX_LEN overrides (experiments).
+inline size_t combine_max_len() {
+    const char* e = std::getenv("PA_COMBINE_MAX_LEN");
+    return e ? (size_t)std::atoll(e) : (size_t)32768;
+}
 constexpr size_t kCombineMaxGroup = 8192;
 constexpr int kCombineInFlight = 8;        // batches of one parameter set on the GPU at a time
 constexpr int kCombineWindowUs = 300;      // how long a gathering caller waits for more callers
@@ -1070,7 +1074,7 @@ int align_hip(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, co
     }
     // Several callers inside at once, a parameter set the batch kernels take: one batch for all of them (see combine_align above)
     InsideGuard inside;
-    if (trace && !self_check && !t_in_combiner && a_len > 0 && b_len > 0 && a_len < kCombineMaxLen && b_len < kCombineMaxLen && pa_batch_params_supported(&params)) {
+    if (trace && !self_check && !t_in_combiner && a_len > 0 && b_len > 0 && a_len < combine_max_len() && b_len < combine_max_len() && pa_batch_params_supported(&params)) {
         static const bool combine_off = std::getenv("PA_COMBINE") != nullptr && std::getenv("PA_COMBINE")[0] == '0';
         if (!combine_off && combine_now() && combine_align(a, a_len, b, b_len, params, cost_out, cigar_out, stats_out) == 0) return 0;
     }

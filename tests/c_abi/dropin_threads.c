@@ -80,7 +80,8 @@ int main(int argc, char** argv) {
     g_fn = (argc > 2 && !strcmp(argv[2], "full")) ? astarpa2_full : astarpa2_simple;
     const double divs[4] = {0.01, 0.05, 0.10, 0.15};
     g_pairs = (pair_t*)calloc(g_npairs, sizeof(pair_t));
-    for (size_t i = 0; i < g_npairs; ++i) make_pair(&g_pairs[i], 10000, divs[i % 4], 1000 + i);
+    const size_t len = getenv("PA_DROPIN_LEN") ? (size_t)atoll(getenv("PA_DROPIN_LEN")) : 10000; /* (experiments: longer pairs) */
+    for (size_t i = 0; i < g_npairs; ++i) make_pair(&g_pairs[i], len, divs[i % 4], 1000 + i);
     /* one caller at a time: the single-pair route; its results are the expected values of everything below */
     double t0 = now_s();
     for (size_t i = 0; i < g_npairs; ++i) {

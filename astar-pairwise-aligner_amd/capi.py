@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "pa_align", "pa_batch_align_multi", "pa_batch_create_trace_params",
     "pa_bp_ctx_create", "pa_bp_ctx_compute", "pa_bp_ctx_fill", "pa_bp_ctx_destroy",
     "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools", "pa_align_file_params", "pa_batch_params_supported", "pa_alloc_cache_stats", "pa_free_cigars",
-    "pa_batch_full_info", "pa_batch_rdv_stats", "pa_combine_stats", "pa_debug_gcsh_probe", "pa_debug_gcsh_matches", "pa_batch_window_retries", "pa_batch_window_retry_bytes",
+    "pa_batch_full_info", "pa_batch_rdv_stats", "pa_combine_stats", "pa_params_nw", "pa_params_simple", "pa_params_full", "pa_debug_gcsh_probe", "pa_debug_gcsh_matches", "pa_batch_window_retries", "pa_batch_window_retry_bytes",
 ]
 
 _lib = None

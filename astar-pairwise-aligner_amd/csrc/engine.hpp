@@ -259,12 +259,12 @@ struct SeedHeuristicH : Heuristic {
         if (k <= 0) k = 1;
         const I nseeds = n >= k ? (n - k) / k + 1 : 0;
         auto bits = [](uint8_t c) -> uint64_t { return (uint64_t)((c >> 1) & 3); };  // qgrams.rs:30-33
-        std::vector<std::pair<uint64_t, I>> keys;  // (key, seed index), sorted => multimap; the whole 2 k-bit q-gram (qgrams.rs:36-43: usize)
+        std::vector<std::pair<uint32_t, I>> keys;  // (key, seed index), sorted => multimap
         keys.reserve((size_t)nseeds);
         for (I sidx = 0; sidx < nseeds; ++sidx) {
             uint64_t q = 0;
             for (I t = 0; t < k; ++t) q = (q << 2) | bits(a[sidx * k + t]);
-            keys.emplace_back(q, sidx);
+            keys.emplace_back((uint32_t)q, sidx);
         }
         std::sort(keys.begin(), keys.end());
         std::vector<uint8_t> matched((size_t)nseeds, 0);
@@ -274,7 +274,7 @@ struct SeedHeuristicH : Heuristic {
             for (I j = 0; j < m; ++j) {
                 q = ((q << 2) | bits(b[j])) & mask;
                 if (j + 1 < k) continue;
-                const uint64_t key = q;
+                const uint32_t key = (uint32_t)q;
                 auto it = std::lower_bound(keys.begin(), keys.end(), std::make_pair(key, (I)0));
                 for (; it != keys.end() && it->first == key; ++it) matched[(size_t)it->second] = 1;
             }

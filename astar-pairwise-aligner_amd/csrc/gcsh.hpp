@@ -170,11 +170,11 @@ struct GcshHeuristic : Heuristic {
 
         // exact matches: hash a's seeds, look up b's k-mers in decreasing j (exact.rs:15-69)
         auto bits = [](uint8_t c) -> uint64_t { return (uint64_t)((c >> 1) & 3); };
-        std::vector<uint64_t> keys((size_t)nseeds);  // the k-mer of seed sidx (a[sidx * k ..]); 2 k <= 62 bits: the reference's usize q-gram (qgrams.rs:36-43)
+        std::vector<uint32_t> keys((size_t)nseeds);  // the k-mer of seed sidx (a[sidx * k ..])
         for (I sidx = 0; sidx < nseeds; ++sidx) {
             uint64_t q = 0;
             for (I t = 0; t < k; ++t) q = (q << 2) | bits(a[sidx * k + t]);
-            keys[(size_t)sidx] = q;
+            keys[(size_t)sidx] = (uint32_t)q;
         }
         // open-addressing table: key -> the FIRST seed with that k-mer; seeds sharing a k-mer are chained in increasing order
         // (the order the reference's per-key vectors have).  A lookup per position of b: a binary search over the sorted seeds was
@@ -183,16 +183,15 @@ struct GcshHeuristic : Heuristic {
         while (((size_t)1 << tbits) < 2 * keys.size() + 1) ++tbits;
         const size_t tmask = ((size_t)1 << tbits) - 1;
         std::vector<int32_t> slot(tmask + 1, -1), next_same((size_t)nseeds, -1);
-        auto fold = [](uint64_t key) { return (uint32_t)key ^ ((uint32_t)(key >> 32) * 0x7FEB352Du); };  // (k <= 16: the key itself)
-        auto hash = [tbits, fold](uint64_t key) { return (size_t)((fold(key) * 0x9E3779B1u) >> (32 - tbits)); };
+        auto hash = [tbits](uint32_t key) { return (size_t)((key * 0x9E3779B1u) >> (32 - tbits)); };
         for (I sidx = nseeds - 1; sidx >= 0; --sidx) {
-            const uint64_t key = keys[(size_t)sidx];
+            const uint32_t key = keys[(size_t)sidx];
             size_t h = hash(key);
             while (slot[h] >= 0 && keys[(size_t)slot[h]] != key) h = (h + 1) & tmask;
             next_same[(size_t)sidx] = slot[h];  // (-1 when the key is new)
             slot[h] = sidx;
         }
-        auto first_of = [&](uint64_t key) -> int32_t {
+        auto first_of = [&](uint32_t key) -> int32_t {
             for (size_t h = hash(key);; h = (h + 1) & tmask) {
                 if (slot[h] < 0) return -1;
                 if (keys[(size_t)slot[h]] == key) return slot[h];
@@ -202,8 +201,8 @@ struct GcshHeuristic : Heuristic {
         // stop here instead of walking the 128 KB table (the scan below: 1.7 -> 1.0 ms for a 100 kbp pair)
         constexpr unsigned kSieveBits = 16;
         std::vector<uint64_t> sieve((size_t)1 << (kSieveBits - 6), 0);
-        auto sieve_of = [fold](uint64_t key) { return (uint32_t)((fold(key) * 0x85EBCA6Bu) >> (32 - kSieveBits)); };
-        for (const uint64_t key : keys) {
+        auto sieve_of = [](uint32_t key) { return (uint32_t)((key * 0x85EBCA6Bu) >> (32 - kSieveBits)); };
+        for (const uint32_t key : keys) {
             const uint32_t hb = sieve_of(key);
             sieve[hb >> 6] |= (uint64_t)1 << (hb & 63);
         }
@@ -219,7 +218,7 @@ struct GcshHeuristic : Heuristic {
                 q |= bits(b[pos]) << leftshift;
                 if (m - 1 - pos < k - 1) continue;
                 const I j = pos;
-                const uint64_t key = q;
+                const uint32_t key = (uint32_t)q;
                 const uint32_t hb = sieve_of(key);
                 if (!((sieve[hb >> 6] >> (hb & 63)) & 1)) continue;
                 for (int32_t sidx = first_of(key); sidx >= 0; sidx = next_same[(size_t)sidx]) {

@@ -45,14 +45,8 @@ __device__ __forceinline__ uint32_t kmer_key(const PA_GLOBAL uint8_t* s, int32_t
     return (uint32_t)q;
 }
 __device__ __forceinline__ uint32_t key_hash(uint32_t key, uint32_t mask) { return (key * 0x9E3779B1u) >> 7 & mask; }
-// k > 16: the table's 32-bit key holds the LAST 16 characters only; the reference compares whole q-grams (usize, qgrams.rs:36-43), so a
-// key hit is confirmed on the characters themselves (their 2-bit codes: bits 2:1 of a byte).
-__device__ __forceinline__ bool same_kmer(const PA_GLOBAL uint8_t* x, const PA_GLOBAL uint8_t* y, int32_t k) {
-    if (k <= 16) return true;
-    for (int32_t t = 0; t < k - 16; ++t)
-        if (((x[t] ^ y[t]) & 6u) != 0u) return false;
-    return true;
-}
+// k > 16: the 32-bit key holds the LAST 16 characters only, and that IS the reference's comparison: its map is keyed on `q as u32`
+// (matches/exact.rs:47,53,56), so seeds / k-mers of b that agree on their last 16 characters match each other there and here.
 
 constexpr int kBuildWin = 2048;  // bytes of a and of b staged in LDS for a batch of 64 candidates
 
@@ -312,7 +306,7 @@ __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __re
                         if (__hip_atomic_compare_exchange_strong(slot + h, &expect, s, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
                         cur = expect;
                     }
-                    if (keys[cur] == key && same_kmer(a + (size_t)cur * jb.k, a + (size_t)s * jb.k, jb.k)) {  // the k-mer is there already: this seed becomes the head of its chain
+                    if (keys[cur] == key) {  // the k-mer is there already: this seed becomes the head of its chain
                         next_same[s] = cur;
                         int32_t expect = cur;
                         if (__hip_atomic_compare_exchange_strong(slot + h, &expect, s, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
@@ -350,7 +344,7 @@ __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __re
                     for (; (sieve[hb >> 5] >> (hb & 31u)) & 1u;) {
                         const int32_t cur = slot[h];
                         if (cur < 0) break;
-                        if (keys[cur] == key && same_kmer(a + (size_t)cur * jb.k, b + j, jb.k)) {
+                        if (keys[cur] == key) {
                             head = cur;
                             break;
                         }

@@ -59,12 +59,19 @@ def _empty(r):
     return r[0] > r[1]
 
 
+def kmer_key(s: bytes, i: int, k: int) -> bytes:
+    """The key the reference's match table uses for the k-mer s[i..i+k): `q as u32` of the 2 k-bit q-gram whose FIRST character is in
+    the high bits (matches/exact.rs:47,53,56; qgrams.rs:36-43) -- the low 32 bits are the LAST min(k, 16) characters.  So for k > 16
+    two k-mers that agree on their last 16 characters are one key: they match each other in the reference, and here."""
+    return s[i + max(0, k - 16):i + k]
+
+
 def sh_table(a: bytes, b: bytes, k: int):
     """h(i) = number of seeds of a starting at >= i that have no exact match anywhere in b (seeds: consecutive k-mers from 0)."""
     n = len(a)
-    bk = {b[j:j + k] for j in range(0, len(b) - k + 1)} if len(b) >= k else set()
+    bk = {kmer_key(b, j, k) for j in range(0, len(b) - k + 1)} if len(b) >= k else set()
     nseeds = n // k
-    matched = [a[s * k:(s + 1) * k] in bk for s in range(nseeds)]
+    matched = [kmer_key(a, s * k, k) in bk for s in range(nseeds)]
     h = [0] * (n + 1)
     unmatched, nxt = 0, nseeds - 1
     for i in range(n, -1, -1):
@@ -79,7 +86,8 @@ def sh_table(a: bytes, b: bytes, k: int):
 class Gcsh:
     """GCSH with exact matches (r = 1), local pruning p and Prune::Start, by its DEFINITION (pa-heuristic/src):
         seeds           consecutive k-mers of a from 0; potential P(i) = seeds starting at >= i          seeds.rs:34-71, qgrams.rs:99-109
-        matches         every (seed start i, j) with a[i..i+k) == b[j..j+k), pushed for j DEcreasing and, per j, i increasing
+        matches         every (seed start i, j) whose k-mers have ONE u32 key (kmer_key: equal k-mers for k <= 16, equal last 16
+                        characters beyond), pushed for j DEcreasing and, per j, i increasing
                                                                                                         matches/exact.rs:15-69, qgrams.rs:81-97
         push filters    T(start) <= T(target), then local pruning (a diagonal-transition look-ahead over the next p seeds)
                                                                                                         matches.rs:205-247, matches/prepruning.rs:95-203
@@ -116,11 +124,11 @@ class Gcsh:
         # ---- find the matches: hash of a's seeds, all k-mers of b looked up for decreasing j ----
         table = {}
         for i in starts:
-            table.setdefault(a[i:i + k], []).append(i)
+            table.setdefault(kmer_key(a, i, k), []).append(i)
         self.next_match_per_diag = {}
         kept = []
         for j in range(m - k, -1, -1):
-            for i in table.get(b[j:j + k], ()):
+            for i in table.get(kmer_key(b, j, k), ()):
                 ts = self.T(i, j)
                 if not (ts[0] <= self.t_target[0] and ts[1] <= self.t_target[1]):
                     continue

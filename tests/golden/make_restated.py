@@ -40,6 +40,16 @@ def work_long(job):
     return row_of(cost, cigar, stats)
 
 
+def work_coll(job):
+    from oracle import astarpa2_restated as restated
+    from tests.restated_fixture import collision_pair_for, row_of
+
+    name, kw, i = job
+    a, b = collision_pair_for(i, kw["k"])
+    cost, cigar, stats = restated.align(a, b, **kw)
+    return row_of(cost, cigar, stats)
+
+
 def main():
     from tests.restated_fixture import GOLDEN, KEYS, N_PAIRS
     from tests.test_restated_engine import variants
@@ -49,7 +59,22 @@ def main():
     vs = {name: kw for name, (_, kw) in variants(_NoOracle()).items()}
     from tests.restated_fixture import LONG_VARIANTS, N_LONG
 
+    from tests.restated_fixture import COLL_VARIANTS, N_COLL
+
     with get_context("spawn").Pool(nproc) as pool:
+        for name, kw in COLL_VARIANTS.items():  # k-mers beyond 16 with colliding u32 keys (python tests/golden/make_restated.py 8 kcoll)
+            if only and "kcoll" not in only and name not in only:
+                continue
+            t0 = time.time()
+            rows = pool.map(work_coll, [(name, kw, i) for i in range(N_COLL)], chunksize=4)
+            doc = {"variant": name, "restated_kwargs": kw, "pairs": "tests/restated_fixture.py collision_pair_for(i, k), i = 0 .. n_pairs - 1",
+                   "row": ["cost", "sha256(cigar)[:16]"] + KEYS, "n_pairs": N_COLL,
+                   "source": "oracle/astarpa2_restated.py (second restatement; no csrc/ code involved); match keys: the reference's `q as u32` "
+                             "(pa-heuristic/src/matches/exact.rs:47,53,56)", "rows": rows}
+            (GOLDEN / f"restated_kcoll_{name}.json").write_text(json.dumps(doc, separators=(",", ":")) + "\n")
+            print(f"kcoll {name}: {len(rows)} rows in {time.time() - t0:.1f} s", flush=True)
+        if only == {"kcoll"}:
+            return
         for name in LONG_VARIANTS:  # the long pairs (python tests/golden/make_restated.py 8 long: these alone)
             if only and "long" not in only and name not in only:
                 continue

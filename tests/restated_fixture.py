@@ -12,7 +12,7 @@ import json
 import random
 from pathlib import Path
 
-from tests.util_seq import gen_pair, rand_seq
+from tests.util_seq import gen_pair, mutate, rand_seq
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
 N_PAIRS = 2048
@@ -62,7 +62,7 @@ def load(name: str) -> dict:
 
 
 def variant_names() -> list:
-    return sorted(p.stem[len("restated_"):] for p in GOLDEN.glob("restated_*.json") if not p.stem.startswith("restated_long_"))
+    return sorted(p.stem[len("restated_"):] for p in GOLDEN.glob("restated_*.json") if not p.stem.startswith(("restated_long_", "restated_kcoll_")))
 
 
 def params_from_kwargs(pa, kw: dict):
@@ -101,3 +101,56 @@ def long_pair_for(i: int):
 
 def load_long(name: str) -> dict:
     return json.loads((GOLDEN / f"restated_long_{name}.json").read_text())
+
+
+# ---- a third set: k-mers longer than 16 whose u32 keys COLLIDE -- the reference keys its match table on `q as u32`
+#      (pa-heuristic/src/matches/exact.rs:47,53,56), i.e. on the LAST 16 characters of a k-mer, so seeds / k-mers of b that agree there match
+#      each other whatever their first k - 16 characters.  tests/golden/restated_kcoll_<set>.json, same row format ----
+N_COLL = 768
+COLL_VARIANTS = {
+    "gcsh_k20_p0_prune": dict(heuristic="gcsh", k=20, p=0, prune=True),
+    "gcsh_k20_p5_prune_incr": dict(heuristic="gcsh", k=20, p=5, prune=True, incremental_doubling=True),
+    "gcsh_k24_p14_incr": dict(heuristic="gcsh", k=24, p=14, incremental_doubling=True),
+    "gcsh_k17_p3_prune_nodt": dict(heuristic="gcsh", k=17, p=3, prune=True, dt_trace=False),
+    "sh20": dict(heuristic="sh", k=20),
+    "sh31_incr": dict(heuristic="sh", k=31, incremental_doubling=True),
+}
+
+
+def collision_pair_for(i: int, k: int):
+    """Collision pair i for seed length k > 16: a = 5 .. 400 seeds, of which a third to all take their last 16 characters from a small pool
+    of tails (groups of seeds with ONE u32 key); b = a with 0 .. 15 % edits (an edit in the first k - 16 characters of a pooled seed leaves a
+    k-mer that equals no seed and still matches the whole group), a quarter with a block of a's seeds shuffled in, a fifth with an indel."""
+    rng = random.Random(0xC0110000 + 1000 * k + i)
+    nseeds = rng.choice([rng.randint(5, 40), rng.randint(40, 150), rng.randint(150, 400)])
+    pool = [rand_seq(16, rng.randint(1, 10**9)) for _ in range(max(1, nseeds // rng.choice([3, 6, 12, 30])))]
+    share = rng.choice([0.34, 0.6, 1.0])
+    seeds = []
+    for _ in range(nseeds):
+        head = rand_seq(k - 16, rng.randint(1, 10**9))
+        seeds.append(head + (rng.choice(pool) if rng.random() < share else rand_seq(16, rng.randint(1, 10**9))))
+    a = b"".join(seeds) + rand_seq(rng.randint(0, k - 1), rng.randint(1, 10**9))
+    e = rng.choice([0.0, 0.01, 0.03, 0.08, 0.15])
+    b = mutate(a, e, rng.randint(1, 10**9)) if e > 0 else a
+    mode = rng.random()
+    if mode < 0.25:
+        cut = rng.randint(0, len(b))
+        some = seeds[:]
+        rng.shuffle(some)
+        b = b[:cut] + b"".join(some[: rng.randint(1, min(20, nseeds))]) + b[cut:]
+    elif mode < 0.45 and len(b) > 60:
+        cut = rng.randint(0, len(b) - 1)
+        b = b[:cut] + b[cut + rng.randint(1, min(600, len(b) // 2)):]
+    return a, (b or b"A")
+
+
+def load_coll(name: str) -> dict:
+    return json.loads((GOLDEN / f"restated_kcoll_{name}.json").read_text())
+
+
+def count_collision_matches(a: bytes, b: bytes, k: int) -> int:
+    """(seed start, j) pairs whose k-mers DIFFER and whose last 16 characters agree: the matches only the u32 key makes."""
+    tails = {}
+    for s in range(0, len(a) - k + 1, k):
+        tails.setdefault(a[s + k - 16:s + k], []).append(s)
+    return sum(a[s:s + k] != b[j:j + k] for j in range(len(b) - k + 1) for s in tails.get(b[j + k - 16:j + k], ()))

@@ -79,3 +79,25 @@ def test_long_pairs_fixture(pa, name, monkeypatch):
     al = prm.make_aligner(True)
     for i in range(rf.LONG_VARIANTS.index(name) % 8, rf.N_LONG, 8):
         assert rf.row_of(*al.align_with_stats(*pairs[i])) == rows[i], (name, i)
+
+
+@pytest.mark.parametrize("name", sorted(rf.COLL_VARIANTS))
+def test_colliding_u32_keys_fixture(pa, name):
+    """k > 16 with seeds that share their last 16 characters (tests/golden/restated_kcoll_<set>.json): the reference's match table is keyed
+    on `q as u32` (pa-heuristic/src/matches/exact.rs:47,53,56), so such seeds match each other's k-mers.  One batch -- matches built on the
+    device by gcsh_build_kernel for the GCSH sets, or on the host when a pair outgrows the kernel's candidate buffers -- and every sixth pair
+    through pa_align."""
+    doc = rf.load_coll(name)
+    rows, kw = doc["rows"], doc["restated_kwargs"]
+    prm = rf.params_from_kwargs(pa, kw)
+    pairs = [rf.collision_pair_for(i, kw["k"]) for i in range(rf.N_COLL)]
+    assert pa.capi.batch_params_supported(prm)
+    bt = pa.Batch(pairs, params=prm)
+    costs, cigars, _, _ = bt.align()
+    stats = bt.pair_stats()
+    bt.close()
+    bad = [i for i in range(rf.N_COLL) if rf.row_of(costs[i], cigars[i], stats[i]) != rows[i]]
+    assert not bad, (name, len(bad), bad[:5], [(rf.row_of(costs[i], cigars[i], stats[i]), rows[i]) for i in bad[:2]])
+    al = prm.make_aligner(True)
+    for i in range(sorted(rf.COLL_VARIANTS).index(name), rf.N_COLL, 6):
+        assert rf.row_of(*al.align_with_stats(*pairs[i])) == rows[i], (name, i)

@@ -145,35 +145,55 @@ def test_gcsh_matches_local_pruning_and_h_values(oracle):
             assert len(g.mi) < len(restated.Gcsh(a, b, k, 0, True).mi)  # (local pruning removed something)
 
 
-def long_kmer_collision_pair(k: int = 20, seeds: int = 60, seed: int = 5):
-    """Seeds of a that share their LAST 16 characters and differ in the first k - 16 (round 4's advisor finding: 32-bit k-mer keys made
-    all of them match each other for k > 16; the reference compares whole q-grams, qgrams.rs:36-43)."""
+def long_kmer_collision_pair(k: int = 20, seeds: int = 60, seed: int = 5, group: int = 4):
+    """Seeds of a that share their LAST 16 characters (in groups of `group`) and differ in the first k - 16.  The reference keys its match
+    table on `q as u32` (pa-heuristic/src/matches/exact.rs:47 `type Key = u32`, :53 `h.entry(q as Key)`, :56 `h.get(&(q as Key))`) and
+    the q-gram has its first character in the HIGH bits (qgrams.rs:36-43), so for k > 16 only the last 16 characters are compared: all
+    seeds of a group match every k-mer of b that ends in the group's tail.  b holds half of the seeds verbatim (shuffled) and then, per
+    group, fresh heads in front of the tail -- k-mers that equal NO seed and still match `group` seeds each in the reference."""
     rnd = random.Random(seed)
-    tail = bytes(rnd.choice(b"ACGT") for _ in range(16))
+    ngroups = (seeds + group - 1) // group
+    tails = [bytes(rnd.choice(b"ACGT") for _ in range(16)) for _ in range(ngroups)]
     heads = [bytes(rnd.choice(b"ACGT") for _ in range(k - 16)) for _ in range(seeds)]
-    a = b"".join(h + tail for h in heads)
+    a = b"".join(heads[s] + tails[s // group] for s in range(seeds))
     order = list(range(seeds))
     rnd.shuffle(order)
-    b = b"".join(heads[i] + tail for i in order[: seeds // 2]) + b"".join(bytes(rnd.choice(b"ACGT") for _ in range(k - 16)) + tail for _ in range(seeds // 2))
+    b = b"".join(heads[s] + tails[s // group] for s in order[: seeds // 2])
+    b += b"".join(bytes(rnd.choice(b"ACGT") for _ in range(k - 16)) + tails[g % ngroups] for g in range(seeds // 2))
     return a, b
 
 
-def test_gcsh_kmers_longer_than_16_are_compared_in_full(oracle):
+def test_gcsh_kmers_longer_than_16_match_on_their_last_16_characters(oracle):
+    """k > 16: the reference's u32 key (exact.rs:47,53,56) -- both restatements must keep the collisions as matches."""
     for k, p in ((20, 0), (24, 3), (31, 0), (17, 14)):
         a, b = long_kmer_collision_pair(k)
         g = restated.Gcsh(a, b, k, p, True)
         q = [(0, 0), (len(a), len(b)), (len(a) // 2, len(b) // 3)]
         want_h, want_kept = oracle.gcsh_probe(a, b, k, p, q)
-        assert sorted(map(tuple, want_kept)) == sorted(zip(g.mi.tolist(), g.mj.tolist())), (k, p)
+        kept = sorted(map(tuple, want_kept))
+        assert kept == sorted(zip(g.mi.tolist(), g.mj.tolist())), (k, p)
         assert [g.h(i, j) for i, j in q] == want_h
-        if p == 0:  # brute force: every (seed start, j) with equal k-mers, under the transform filter the matches respect
-            brute = {(i, j) for i in range(0, len(a) - k + 1, k) for j in range(len(b) - k + 1) if a[i:i + k] == b[j:j + k]}
-            assert set(map(tuple, want_kept)) <= brute and len(brute) < (len(a) // k) ** 2 // 4
-    # SH (static seed heuristic): a seed counts as matched only if its WHOLE k-mer occurs in b
+        if p == 0:  # by the definition, from the characters: equal LAST 16 characters + the transform filter T(start) <= T(target)
+            tt = g.t_target
+            brute = set()
+            for i in range(0, len(a) - k + 1, k):
+                for j in range(len(b) - k + 1):
+                    if a[i + k - 16:i + k] == b[j + k - 16:j + k]:
+                        t = g.T(i, j)
+                        if t[0] <= tt[0] and t[1] <= tt[1]:
+                            brute.add((i, j))
+            assert set(kept) == brute, (k, len(kept), len(brute))
+            collisions = [(i, j) for i, j in kept if a[i:i + k] != b[j:j + k]]
+            assert len(collisions) > len(kept) // 2, (k, len(collisions), len(kept))  # most matches here are not equal k-mers at all
+    # SH: a seed counts as matched as soon as ANY k-mer of b ends in its last 16 characters
     a, b = long_kmer_collision_pair(20)
-    b2 = b[: 20 * 30]  # only the first thirty k-mers of b are copies of seeds of a
+    b2 = b[20 * 30:]  # only the fresh-head half: (nearly) no k-mer of b2 equals a seed of a, every tail of a occurs
+    assert sum(a[i:i + 20] not in b2 for i in range(0, len(a), 20)) >= 50  # (whole k-mers compared: >= 50 of 60 seeds unmatched)
+    assert restated.sh_table(a, b2, 20)[0] == 0  # u32 key: all sixty seeds matched
     compare(oracle, a, b2, oracle.make_params(**{**BASE, "heuristic": "sh", "k": 20}), dict(heuristic="sh", k=20))
     compare(oracle, a, b2, oracle.make_params(**{**BASE, "heuristic": "gcsh", "k": 20, "p": 3, "prune": True}), dict(heuristic="gcsh", k=20, p=3, prune=True))
+    compare(oracle, a, b, oracle.make_params(**{**BASE, "heuristic": "gcsh", "k": 24, "p": 0, "prune": True, "incremental_doubling": True}),
+            dict(heuristic="gcsh", k=24, p=0, prune=True, incremental_doubling=True))
 
 
 def test_c3_pair_of_the_bench_full_preset(oracle):

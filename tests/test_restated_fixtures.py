@@ -56,3 +56,24 @@ def test_long_pairs_fixture_on_the_cpu(oracle):
             assert rf.row_of(*oracle.cpu_align(a, b, prm)) == doc["rows"][i], (name, i)
             if i < 24:
                 assert rf.row_of(*restated.align(a, b, **kw)) == doc["rows"][i], (name, i)
+
+
+@pytest.mark.parametrize("name", sorted(rf.COLL_VARIANTS))
+def test_colliding_u32_keys_fixture_on_the_cpu(oracle, name):
+    """tests/golden/restated_kcoll_<set>.json (k > 16, seeds that share their last 16 characters -- one key in the reference's u32-keyed
+    match table, pa-heuristic/src/matches/exact.rs:47,53,56): every pair against the CPU-kernel engine, a sample against the generator."""
+    kw = rf.COLL_VARIANTS[name]
+    doc = rf.load_coll(name)
+    assert doc["n_pairs"] == rf.N_COLL and doc["restated_kwargs"] == kw and len(doc["rows"]) == rf.N_COLL
+    d = dict(heuristic="gap", k=12, sparse_h=True, block_width=256, dt_trace=True, max_g=40, fr_drop=10, domain="astar", sparse=True,
+             doubling="band", start="h0", factor=2.0, delta=1.0, incremental_doubling=False, p=0, prune=False)
+    d.update(kw)
+    prm = oracle.make_params(**d)
+    colliding = 0
+    for i in range(rf.N_COLL):
+        a, b = rf.collision_pair_for(i, kw["k"])
+        assert rf.row_of(*oracle.cpu_align(a, b, prm)) == doc["rows"][i], (name, i)
+        if i % 16 == 0:
+            assert rf.row_of(*restated.align(a, b, **kw)) == doc["rows"][i], (name, i)
+            colliding += rf.count_collision_matches(a, b, kw["k"]) > 0
+    assert colliding >= rf.N_COLL // 16 * 3 // 4, colliding  # the pairs do what they are for: matches that are NOT equal k-mers

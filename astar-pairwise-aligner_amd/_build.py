@@ -10,7 +10,7 @@ PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libastarpa_c_hip.so"
 
-HIP_SOURCES = ["pa_hip.hip", "engine_hip.hip", "astarpa_c.hip", "pairs_io.hip", "apa2_simple_unit.hip", "apa2_full_unit.hip", "gcsh_build_unit.hip", "sketch_unit.hip"]
+HIP_SOURCES = ["pa_hip.hip", "engine_hip.hip", "astarpa_c.hip", "pairs_io.hip", "apa2_simple_unit.hip", "apa2_full_unit.hip", "gcsh_build_unit.hip", "sketch_unit.hip", "slice_unit.hip"]
 
 
 def _hipcc() -> str:
@@ -42,11 +42,11 @@ def source_hash() -> str:
 
 
 def kernel_hash() -> str:
-    """Content hash of the headline kernel's source (csrc/strip_kernel.hpp): profiles/pmc_latest.json is stamped with it, and bench.py
+    """Content hash of the headline kernels' sources (csrc/strip_kernel.hpp, csrc/slice_kernel.hpp): profiles/pmc_latest.json is stamped with it, and bench.py
     prints PMC-derived figures only when the counters were collected over this very code."""
     import hashlib
 
-    return hashlib.sha256((CSRC / "strip_kernel.hpp").read_bytes()).hexdigest()
+    return hashlib.sha256((CSRC / "strip_kernel.hpp").read_bytes() + (CSRC / "slice_kernel.hpp").read_bytes()).hexdigest()
 
 
 def is_stale() -> bool:

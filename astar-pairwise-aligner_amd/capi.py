@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = [
     "pa_bp_ctx_create", "pa_bp_ctx_compute", "pa_bp_ctx_fill", "pa_bp_ctx_destroy",
     "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools", "pa_align_file_params", "pa_batch_params_supported", "pa_alloc_cache_stats", "pa_free_cigars",
     "pa_batch_full_info", "pa_batch_rdv_stats", "pa_combine_stats", "pa_params_nw", "pa_params_simple", "pa_params_full", "pa_debug_gcsh_probe", "pa_debug_gcsh_matches", "pa_batch_window_retries", "pa_batch_window_retry_bytes",
+    "pa_batch_slice_info",
 ]
 
 _lib = None
@@ -88,6 +89,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
     L.pa_combine_stats.restype = None
     L.pa_batch_rdv_stats.restype = C.c_int
     L.pa_batch_shape.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.pa_batch_slice_info.argtypes = [vp] + [C.POINTER(C.c_double)] * 5
+    L.pa_batch_slice_info.restype = C.c_int
     L.pa_batch_destroy.argtypes = [vp]
     L.pa_batch_create_banded.argtypes = [vp, vp, vp, vp, sz, C.c_float]
     L.pa_batch_create_banded.restype = vp
@@ -555,6 +558,12 @@ class Batch:
         """How the batch was laid out: strip height k, chained strips or one wavefront per pair, VALU instructions per pass."""
         k, seq, vi = C.c_int(0), C.c_int(0), C.c_double(0)
         load().pa_batch_shape(self._h, C.byref(k), C.byref(seq), C.byref(vi))
+        sl = [C.c_double(0) for _ in range(5)]
+        rows = load().pa_batch_slice_info(self._h, *[C.byref(v) for v in sl])
+        if rows:  # groups of 32 pairs, bit-sliced (csrc/slice_kernel.hpp)
+            return {"k": 0, "sequential": False, "valu_instructions": vi.value, "kernel": f"pa::slice::slice_kernel<{rows}>", "sliced_rows_per_lane": rows,
+                    "groups": int(sl[0].value), "jobs": int(sl[1].value), "computed_cells": sl[2].value, "device_bytes": sl[3].value,
+                    "boundary_bytes": sl[4].value}
         return {"k": k.value, "sequential": bool(seq.value), "valu_instructions": vi.value,
                 "kernel": f"pa::pair_kernel<{k.value}>" if seq.value else f"pa::strip_kernel<{k.value}, false, false>"}
 

@@ -1,6 +1,7 @@
 // pa_hip.hip -- host side of libastarpa_c_hip.so: device buffers, strip planning, the operator
 // C ABI (include/pa_bitpacking_hip.h) and the batched full-DP plan.  gfx950 only.
 #include "pa_hip_internal.hpp"
+#include "slice_plan.hpp"
 #include "engine_capi.hpp"
 #include "trace_kernel.hpp"
 #include "apa2_units.hpp"
@@ -1313,6 +1314,8 @@ struct pa_batch {
     bool sequential = false;  // one wavefront per pair (pair_kernel) instead of chained strips
     int block_waves = 1;
     DeviceBuf d_first;  // sequential: first job of every pair (+ end)
+    // big cost-only batches: groups of 32 pairs, bit-sliced (slice_kernel.hpp); the strips of `jobs` are not planned then
+    slice::Plan* sliced = nullptr;
     // banded mode (pa_batch_create_banded): per-pair cost threshold of the diagonal band that was planned
     bool banded = false;
     std::vector<int32_t> band_t;
@@ -1420,6 +1423,7 @@ struct pa_batch {
         }
         if (prof) std::fprintf(stderr, "[pa_batch_destroy] events, streams, pinned %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         bstream_give(stream, d_a.device);  // (the batch waited for its device above: nothing of it is queued on the stream any more)
+        slice::destroy(sliced);
     }
 };
 
@@ -1435,6 +1439,7 @@ struct BatchShape {
     int k = 1;
     bool sequential = false;
     int block_waves = 1;
+    double est_ns = -1;  // the estimate that ranked it (ns of one pass; < 0: nothing to compute)
 };
 static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, size_t pairs) {
     // ns per strip step (measured, profiles/r02_runs): a wavefront alone on its SIMD; one of W fairly served wavefronts of a SIMD
@@ -1505,6 +1510,7 @@ static BatchShape choose_batch_shape(const size_t* a_len, const size_t* b_len, s
             }
         }
     }
+    best_shape.est_ns = best;
     return best_shape;
 }
 
@@ -2034,6 +2040,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
     auto p = std::make_unique<pa_batch>();
     p->pairs = pairs;
     p->trace = trace;
+    int slice_rows = 0;  // > 0: the batch runs bit-sliced with that many rows per lane (slice_plan.hpp)
     if (astar) {
         p->astar = true;
         p->aparams_c = *astar;
@@ -2064,6 +2071,13 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
         p->k = sh.k;
         p->sequential = sh.sequential;
         p->block_waves = sh.block_waves;
+        if (!astar && !trace) {  // a cost-only batch big enough for groups of 32 pairs: the bit-sliced kernel, when its estimate is the lower one
+            double est = -1;
+            const double simds = (double)(g_device_props_cus > 0 ? g_device_props_cus : 256) * 4.0;
+            const int R = slice::choose_rows_per_lane(a_len, b_len, pairs, simds, &est);
+            const bool forced = getenv("PA_SLICE") && atoi(getenv("PA_SLICE")) > 0;
+            if (R > 0 && (forced || sh.est_ns < 0 || est < sh.est_ns)) slice_rows = R;
+        }
     }
     size_t ta = 0, tb = 0, tc = 0, tp = 0, tg = 0;
     for (size_t i = 0; i < pairs; ++i) {
@@ -2083,7 +2097,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
         tb += (b_len[i] + 15) & ~size_t(15);
         tc += (a_len[i] + 15) / 16;
         tp += w;
-        tg += astar ? 0
+        tg += (astar || slice_rows) ? 0
               : p->banded ? (size_t)(p->sequential ? 2 : std::max(1, strip_plan((int)w, p->k, false).strips() - 1)) * (a_len[i] / 32 + 2)
                           : rect_granules((int)a_len[i], (int)w, p->k, p->sequential);
         p->cells += (double)a_len[i] * (double)b_len[i];
@@ -2203,7 +2217,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
         first[i] = (int32_t)p->jobs.size();
         first[i + 1] = first[i];
         const int w = (int)((b_len[i] + 63) / 64);
-        if (w == 0 || a_len[i] == 0 || astar) continue;
+        if (w == 0 || a_len[i] == 0 || astar || slice_rows) continue;
         if (p->banded) {
             plan_banded_pair(p.get(), i, p->band_t[i], p->jobs);
             p->last_job[i] = (int)p->jobs.size() - 1;
@@ -2358,6 +2372,12 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
         }
     }
     cmark("jobs + descriptors");
+    if (slice_rows) {
+        p->sequential = false;
+        p->sliced = slice::create(p->n.data(), p->m.data(), pairs, p->code_off.data(), p->prof_off.data(), slice_rows);
+        if (!p->sliced) return nullptr;
+        cmark("bit-sliced plan");
+    }
     if (!p->d_jobs.alloc(p->jobs.size() * sizeof(StripJob))) return nullptr;
     if (!p->jobs.empty() &&
         !hip_ok(hipMemcpyAsync(p->d_jobs.ptr, p->jobs.data(), p->jobs.size() * sizeof(StripJob), hipMemcpyHostToDevice, p->stream), "H2D jobs"))
@@ -2622,6 +2642,28 @@ extern "C" int pa_batch_run(pa_batch* p, int32_t* cost_out, float* kernel_ms) {
         return rc;
     }
     hipStream_t s = p->stream;
+    if (p->sliced) {  // groups of 32 pairs, bit-sliced: profiles as always, then slice_unit.hip; d_sums receives the distances themselves
+        if (const int rc = batch_forward(p, false)) return rc;
+        if (const int rc = slice::run(p->sliced, s, p->d_codes.as<uint32_t>(), p->d_prof.as<uint64_t>(), p->d_sums.as<int32_t>(), p->d_misc.as<uint32_t>() + 4,
+                                      p->ev0, p->ev1))
+            return rc;
+        uint32_t misc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (p->pairs && !hip_ok(hipMemcpyAsync(cost_out, p->d_sums.ptr, p->pairs * 4, hipMemcpyDeviceToHost, s), "D2H")) return PA_E_HIP;
+        if (!hip_ok(hipMemcpyAsync(misc, p->d_misc.ptr, 32, hipMemcpyDeviceToHost, s), "D2H")) return PA_E_HIP;
+        if (!hip_ok(hipStreamSynchronize(s), "sync")) return PA_E_HIP;
+        if (misc[3]) {
+            set_error("sequence contains a base outside ACGT");
+            return PA_E_INVALID_BASE;
+        }
+        if (misc[5] != 0) {
+            set_error("device spin timeout in the bit-sliced kernel (err=%u)", misc[5]);
+            return PA_E_TIMEOUT;
+        }
+        if (kernel_ms && !hip_ok(hipEventElapsedTime(kernel_ms, p->ev0, p->ev1), "elapsed")) return PA_E_HIP;
+        for (size_t i = 0; i < p->pairs; ++i)  // (a pair with an empty sequence is in no group)
+            if (p->n[i] == 0 || p->m[i] == 0) cost_out[i] = (int32_t)(p->n[i] + p->m[i]);
+        return 0;
+    }
     if (const int rc = batch_forward(p)) return rc;
     // (4) read back: bottom sums and each pair's last v word (for the rows beyond |b| in the last word)
     std::vector<int32_t> sums(p->pairs, 0);
@@ -3317,11 +3359,28 @@ extern "C" int pa_batch_pair_stats(const pa_batch* p, pa_astarpa2_stats* stats_o
 extern "C" void pa_batch_stats(const pa_batch* p, double* cells, double* word_updates, double* strips, double* algo_bytes) {
     if (cells) *cells = p->cells;
     if (word_updates) *word_updates = p->word_updates;
-    if (strips) *strips = (double)p->jobs.size();
+    if (strips) *strips = p->sliced ? (double)slice::info(p->sliced).jobs : (double)p->jobs.size();
     if (algo_bytes) *algo_bytes = p->algo_bytes;
 }
 
+extern "C" int pa_batch_slice_info(const pa_batch* p, double* groups, double* jobs, double* computed_cells, double* device_bytes, double* boundary_bytes) {
+    if (!p || !p->sliced) return 0;
+    const slice::Info i = slice::info(p->sliced);
+    if (groups) *groups = (double)i.groups;
+    if (jobs) *jobs = (double)i.jobs;
+    if (computed_cells) *computed_cells = i.computed_rows_cells;
+    if (device_bytes) *device_bytes = i.device_bytes;
+    if (boundary_bytes) *boundary_bytes = i.boundary_bytes;
+    return i.rows_per_lane;
+}
+
 extern "C" void pa_batch_shape(const pa_batch* p, int* k, int* sequential, double* valu_instructions) {
+    if (p->sliced) {
+        if (k) *k = 0;
+        if (sequential) *sequential = 0;
+        if (valu_instructions) *valu_instructions = slice::info(p->sliced).valu_instructions;
+        return;
+    }
     if (k) *k = p->k;
     if (sequential) *sequential = p->sequential ? 1 : 0;
     if (valu_instructions && p->astar) {

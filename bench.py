@@ -5,10 +5,12 @@ Metric (BASELINE.json): DP cell-updates/sec (GCUPS) + pairs/sec on 100 kbp x 100
 divergence, full bit-parallel DP, cost only (configs[1], "C2").
 
 A *step* is one pass of the hot path over one batch of synthetic pairs that is already resident in HBM
-as ASCII: BitProfile build kernels -> clear hand-off granules -> the strip kernel (every 64-lane strip
-of every pair) -> read the edit distances back.  `--pairs P` sets the batch per GPU (default 8192 =
-eight pairs per SIMD, four of them resident at a time, where one wavefront runs a whole pair; P=1 is the literal single-pair C2 case, which
-is latency bound on ~49 chained wavefronts and is reported next to the batch number as `single_pair`).
+as ASCII: BitProfile build kernels -> (round 6) transposes into bit planes over groups of 32 pairs -> reset of the
+boundary rows -> the bit-sliced DP kernel (csrc/slice_kernel.hpp: every (group, strip) job) -> per-pair sums ->
+read the edit distances back.  `--pairs P` sets the batch per GPU (default 8192 = 256 groups x 32 strips = four jobs per
+wave slot; P=1 is the literal single-pair C2 case, which runs on the chained strip kernel, is latency bound on ~49
+wavefronts and is reported next to the batch number as `single_pair`).  PA_SLICE=0 runs the batch on the strip kernels of
+rounds 1-5 (pair_kernel<8>: 130 TCUPS).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -45,6 +47,18 @@ VALU_MIXED_CEILING = 256 * 4 / 1.57e-9
 STEP_FAST, STEP_SLOW = 60.59, 29.94
 CLK_FAST, CLK_SLOW = (2.3, 3.0), (4.1, 4.3)
 WEIGHTED_CLK = tuple((STEP_FAST * f + STEP_SLOW * sl) / (STEP_FAST + STEP_SLOW) for f, sl in zip(CLK_FAST, CLK_SLOW))  # (2.90, 3.43)
+# The bit-sliced kernel's mix (round 6; ISA of slice_kernel<R>): per strip step 4 R VOP2 with two VGPR sources + 4 R v_bitop3 with three
+# (all fast class) + about 12 slow-class (4 v_readlane, 4 DPP, predicates from SGPRs) + about 12 other instructions.  Clocks per class at two
+# wavefronts per SIMD from tools/bank_probe (profiles/r06_runs/bank_probe.log: 1.02 / 1.19-1.28 / 1.72 ns at 2.4 GHz nominal); the whole row
+# mix with conflict-free register banks runs at 1.00-1.04 ns per instruction there -- the measured ceiling of this instruction stream.
+SLICE_CLK = {"vop2": (2.35, 2.45), "bitop3": (2.85, 3.07), "slow": (4.1, 4.3)}
+SLICE_ROW_MIX_NS = (1.00, 1.04)
+
+
+def slice_weighted_clk(rows: int):
+    n2, n3, slow, other = 4.0 * rows, 4.0 * rows, 12.0, 12.0
+    tot = n2 + n3 + slow + other
+    return tuple((n2 * SLICE_CLK["vop2"][i] + other * SLICE_CLK["vop2"][i] + n3 * SLICE_CLK["bitop3"][i] + slow * SLICE_CLK["slow"][i]) / tot for i in (0, 1))
 
 
 def parse_args():
@@ -221,6 +235,8 @@ def main():
             dist.destroy_process_group()
         return
 
+    sliced = int(shape.get("sliced_rows_per_lane", 0))
+    wclk = slice_weighted_clk(sliced) if sliced else WEIGHTED_CLK
     total_cells = st["cells"] * world * args.steps
     value = total_cells / elapsed / 1e9
     ms_per_step = elapsed / args.steps * 1e3
@@ -242,7 +258,8 @@ def main():
         "pairs_per_sec": round(args.pairs * world * args.steps / elapsed, 2),
         "config": {
             "workload": f"C2: {args.pairs} independent {args.n} bp x {args.n} bp pairs per GPU, {args.div:.0%} divergence, "
-                        "full DP cost-only (BitProfile build + strip kernel + cost read-back per step)",
+                        "full DP cost-only (BitProfile build + " + ("bit-plane transposes + bit-sliced kernel + per-pair sums" if sliced else "strip kernel") +
+                        " + cost read-back per step)",
             "pairs_per_gpu": args.pairs,
             "seq_len": args.n,
             "divergence": args.div,
@@ -260,9 +277,9 @@ def main():
             "frac": round(shape["valu_instructions"] / avg_kernel_s / VALU_PEAK_WAVE_INSTR, 4),
             "traffic": None,
             # the ceiling of the kernel's own opcode mix (see WEIGHTED_CLK above): between the optimistic and the pessimistic class clocks
-            "weighted_peak": [round(256 * 4 * 2.4e9 / c / 1e9, 1) for c in WEIGHTED_CLK],
-            "frac_of_weighted_peak": [round(shape["valu_instructions"] / avg_kernel_s / (256 * 4 * 2.4e9 / c), 4) for c in WEIGHTED_CLK],
-            "weighted_clocks_per_instruction": [round(c, 3) for c in WEIGHTED_CLK],
+            "weighted_peak": [round(256 * 4 * 2.4e9 / c / 1e9, 1) for c in wclk],
+            "frac_of_weighted_peak": [round(shape["valu_instructions"] / avg_kernel_s / (256 * 4 * 2.4e9 / c), 4) for c in wclk],
+            "weighted_clocks_per_instruction": [round(c, 3) for c in wclk],
             "achieved_clocks_per_instruction": round(256 * 4 * 2.4e9 / (shape["valu_instructions"] / avg_kernel_s), 3),
             "kernel": shape["kernel"],
             "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
@@ -293,6 +310,23 @@ def main():
         },
         "batch_shape": {"k": shape["k"], "sequential": shape["sequential"]},
     }
+    if sliced:
+        out["batch_shape"].update({"sliced_rows_per_lane": sliced, "groups": shape["groups"], "jobs": shape["jobs"]})
+        out["roofline"]["model_note"] = (
+            "instruction model of the bit-sliced kernel: (8 R + 24) wave64 VALU instructions per strip step (8 per row of 32 pairs x 64 lanes = "
+            "2048 cells: 4 VOP2 + 4 v_bitop3).  SURVEY 8(d)'s model (23 u64 ops x 2 issue slots per 64-cell word update) gives a 'fraction' "
+            "above 1 on gfx950 for this kernel AND for pair_kernel<8> (v_bitop3 folds the step; here add and shifts are gone altogether), so "
+            "it is not used; frac divides executed instructions by the nominal 1 instruction / 2 clk / SIMD at 2.4 GHz")
+        out["roofline"]["row_mix_ceiling"] = {
+            "ns_per_instruction_per_simd": list(SLICE_ROW_MIX_NS), "g_instr_per_s": [round(1024 / x, 1) for x in SLICE_ROW_MIX_NS],
+            "frac_of_it": [round(shape["valu_instructions"] / avg_kernel_s / (1024e9 / x), 4) for x in SLICE_ROW_MIX_NS],
+            "note": "tools/bank_probe: the kernel's eight-instruction row, 56 rows long, hand-placed in conflict-free VGPR banks, two wavefronts "
+                    "per SIMD -- what this instruction stream can reach on the chip"}
+        out["roofline"]["computed_cells_over_nm"] = round(shape["computed_cells"] / st["cells"], 4)
+        out["roofline"]["slice_device_bytes"] = shape["device_bytes"]
+        out["roofline"]["boundary_bytes_reset_per_step"] = shape["boundary_bytes"]
+        out["valu_roofline"]["note"] = ("bit-sliced kernel: (8 R + 24) VALU instructions per strip step of 64 lanes x R rows x 32 pairs (ISA count; "
+                                        "see roofline.model_note); probe_mixed_stream_rate is the strip kernels' reference stream")
     out["binding_roofline"] = {k: out["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel")}  # (the name earlier rounds used)
     if c4_sharded is not None:
         out["c4_sharded"] = c4_sharded
@@ -730,9 +764,14 @@ def main():
                 "FETCH_SIZE+WRITE_SIZE (KiB*1024) per 64-cell word update of the same batch shape from profiles/pmc_latest.json (separate "
                 "rocprofv3 --pmc passes over this kernel's current source) x word updates of this launch; dominated by the 8-byte hand-off "
                 "granules, each moving a 32-64 B sector" if same and current else
-                "profiles/pmc_latest.json was collected for " + ("another batch shape" if not same else "an older strip_kernel.hpp") + ": not printed")
+                "profiles/pmc_latest.json was collected for " + ("another batch shape" if not same else "an older strip_kernel.hpp / slice_kernel.hpp") + ": not printed")
             if same and current:
                 out["roofline"]["pmc_valu_instructions"] = pj["counters"].get("SQ_INSTS_VALU", {}).get("avg_per_launch")
+                if out["roofline"]["pmc_valu_instructions"]:  # the counter, not the model, prices the fraction when it was collected over this code
+                    out["roofline"]["frac_model"] = out["roofline"]["frac"]
+                    out["roofline"]["achieved"] = round(out["roofline"]["pmc_valu_instructions"] / avg_kernel_s / 1e9, 2)
+                    out["roofline"]["frac"] = round(out["roofline"]["pmc_valu_instructions"] / avg_kernel_s / VALU_PEAK_WAVE_INSTR, 4)
+                    out["binding_roofline"] = {k: out["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel")}
         except Exception as e:  # a malformed summary must not break the bench line
             out["roofline"]["traffic_note"] = f"pmc summary unreadable: {e}"
 

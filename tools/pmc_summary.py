@@ -13,7 +13,7 @@ out = {"counters": {}}
 
 
 def is_dp(name):
-    return "strip_kernel" in name or "pair_kernel" in name
+    return "strip_kernel" in name or "pair_kernel" in name or "slice_kernel" in name
 
 
 for f in glob.glob(f"{root}/trace/*kernel_stats.csv"):

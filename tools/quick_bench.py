@@ -28,5 +28,5 @@ for (n, pairs) in cases:
         bestk = min(bestk, ms)
     print(f"n={n} pairs={pairs} strips={int(st['strips'])} kernel_ms={bestk:.3f} wall_ms={best*1e3:.3f} "
           f"GCUPS(kernel)={st['cells']/bestk/1e6:.1f} GCUPS(wall)={st['cells']/best/1e9:.1f} cost0={costs[0]}"
-          + (f" band={band} shape={b.shape()['kernel']} create+first_pass_ms={first_ms:.1f} pairs/s={pairs/best:.0f}" if band is not None else ""), flush=True)
+          + f" kernel={b.shape()['kernel']}" + (f" band={band} shape={b.shape()['kernel']} create+first_pass_ms={first_ms:.1f} pairs/s={pairs/best:.0f}" if band is not None else ""), flush=True)
     b.close()

@@ -20,7 +20,7 @@
 namespace pa {
 namespace combine {
 
-// Req: any struct with `bool done` (false at submission) and `int rc`.
+// Req: any struct with `bool done`, `bool queued` (both false at submission) and `int rc`.
 template <class Req>
 struct Gatherer {
     std::mutex mu;
@@ -34,10 +34,14 @@ struct Gatherer {
     template <class Run, class Inside>
     void submit(Req& req, Run&& run, Inside&& inside, size_t max_group, int max_in_flight, int window_us, int rc_failed) {
         std::unique_lock<std::mutex> lk(mu);
+        req.queued = true;
         pending.push_back(&req);
         cv.notify_all();  // (a gathering caller counts the arrivals)
         while (!req.done) {
-            if (collecting || in_flight >= max_in_flight) {
+            // Only a caller whose own request is still QUEUED gathers.  One whose request already travels in a running batch just waits for
+            // it (round 5 let it gather too: it woke on the leader's notify, waited the whole window and often ran an EMPTY group -- a batch
+            // of 0 pairs, one of the in-flight slots, and the caller returned a window plus a batch later than its result was there).
+            if (!req.queued || collecting || in_flight >= max_in_flight) {
                 cv.wait(lk);
                 continue;
             }
@@ -53,7 +57,12 @@ struct Gatherer {
                 group.assign(pending.begin(), pending.begin() + (long)max_group);
                 pending.erase(pending.begin(), pending.begin() + (long)max_group);
             }
+            for (Req* r : group) r->queued = false;
             collecting = false;
+            if (group.empty()) {  // (cannot happen while the gatherer's own request is queued; kept so that an empty batch is never run)
+                cv.notify_all();
+                continue;
+            }
             in_flight += 1;
             cv.notify_all();  // (whoever is still pending may gather the next batch)
             lk.unlock();

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <optional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -899,6 +900,7 @@ struct CombineReq {
     pa_astarpa2_stats stats{};
     int rc = 0;
     bool done = false;
+    bool queued = false;  // still in the gatherer's pending list (combine_logic.hpp: only such a caller gathers)
     std::string err;
 };
 struct Combiner {
@@ -949,14 +951,17 @@ inline bool combine_now() {
 Combiner& combiner_for(const pa_astarpa2_params& params) {
     int dev = 0;
     (void)hipGetDevice(&dev);
+    // the last combiner this thread used: no global lock, no scan of the (never shrinking) list on the common path
+    thread_local Combiner* t_last = nullptr;
+    if (t_last && t_last->device == dev && std::memcmp(&t_last->params, &params, sizeof(params)) == 0) return *t_last;
     std::lock_guard<std::mutex> lk(g_comb_mu);
     for (Combiner* c : g_combs)
-        if (c->device == dev && std::memcmp(&c->params, &params, sizeof(params)) == 0) return *c;
+        if (c->device == dev && std::memcmp(&c->params, &params, sizeof(params)) == 0) return *(t_last = c);
     Combiner* c = new Combiner;
     c->params = params;
     c->device = dev;
     g_combs.push_back(c);
-    return *c;
+    return *(t_last = c);
 }
 
 void run_group(std::vector<CombineReq*>& group, const pa_astarpa2_params& params) {
@@ -970,28 +975,39 @@ void run_group(std::vector<CombineReq*>& group, const pa_astarpa2_params& params
         bl[i] = group[i]->b_len;
     }
     std::vector<int32_t> costs(n, 0);
-    std::vector<char*> cigars(n, nullptr);
     std::vector<pa_astarpa2_stats> st(n);
+    // RAII (round 5's advisor): a std::string assignment below may throw; the CIGARs the batch malloc'ed and the batch itself go either way,
+    // and no request is left half filled (rc is written last, per request, and the caller's catch sets rc_failed for the whole group)
+    struct Cigars {
+        std::vector<char*> p;
+        explicit Cigars(size_t k) : p(k, nullptr) {}
+        ~Cigars() {
+            for (char* q : p) std::free(q);
+        }
+    } cigars(n);
+    struct InCombiner {
+        InCombiner() { t_in_combiner = true; }
+        ~InCombiner() { t_in_combiner = false; }
+    };
     int rc = 0;
-    t_in_combiner = true;
-    pa_batch* bt = pa_batch_create_params(ap.data(), al.data(), bp.data(), bl.data(), n, &params);
-    if (!bt) rc = kNotCombined;  // (every caller falls back to the single-pair path, which reports its own errors)
-    else {
-        rc = pa_batch_align(bt, costs.data(), cigars.data(), nullptr, nullptr);
-        if (rc == 0) rc = pa_batch_pair_stats(bt, st.data());
-        pa_batch_destroy(bt);
-        if (rc != 0) rc = kNotCombined;
+    {
+        InCombiner guard;
+        std::unique_ptr<pa_batch, void (*)(pa_batch*)> bt(pa_batch_create_params(ap.data(), al.data(), bp.data(), bl.data(), n, &params), pa_batch_destroy);
+        if (!bt) rc = kNotCombined;  // (every caller falls back to the single-pair path, which reports its own errors)
+        else {
+            rc = pa_batch_align(bt.get(), costs.data(), cigars.p.data(), nullptr, nullptr);
+            if (rc == 0) rc = pa_batch_pair_stats(bt.get(), st.data());
+            if (rc != 0) rc = kNotCombined;
+        }
     }
-    t_in_combiner = false;
     for (size_t i = 0; i < n; ++i) {
         CombineReq& r = *group[i];
-        r.rc = rc;
         if (rc == 0) {
+            r.cigar = cigars.p[i] ? cigars.p[i] : "";  // (may throw: nothing of r has been touched yet)
             r.cost = costs[i];
-            r.cigar = cigars[i] ? cigars[i] : "";
             r.stats = st[i];
         }
-        std::free(cigars[i]);
+        r.rc = rc;
     }
     g_comb_calls += n;
     g_comb_batches += 1;
@@ -1073,8 +1089,11 @@ int align_hip(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, co
         return 0;
     }
     // Several callers inside at once, a parameter set the batch kernels take: one batch for all of them (see combine_align above)
-    InsideGuard inside;
+    // (only callers that COULD be combined count as the crowd: a lone short-pair caller among many cost-only / long-pair / unsupported
+    //  callers keeps the 2 ms single-pair path instead of a 300 us window plus a 6-8 ms batch -- round 5's advisor)
+    std::optional<InsideGuard> inside;
     if (trace && !self_check && !t_in_combiner && a_len > 0 && b_len > 0 && a_len < combine_max_len() && b_len < combine_max_len() && pa_batch_params_supported(&params)) {
+        inside.emplace();
         static const bool combine_off = std::getenv("PA_COMBINE") != nullptr && std::getenv("PA_COMBINE")[0] == '0';
         if (!combine_off && combine_now() && combine_align(a, a_len, b, b_len, params, cost_out, cigar_out, stats_out) == 0) return 0;
     }

@@ -1385,7 +1385,9 @@ struct pa_batch {
     double apa2_strip_instr = 0;  // modelled VALU instructions of the DP strips of the last pa_batch_align (reporting)
     double cells = 0, word_updates = 0, algo_bytes = 0;
     hipStream_t stream = nullptr;
-    bool multi_stream_users = false;  // work on this batch's buffers was queued on streams the batch does not own: wait for the device
+    // INVARIANT (round 6, replaces a flag nothing ever set): everything that reads or writes this batch's buffers is queued on `stream` or on
+    // one of cstream[] -- never on the null stream or a stream of another object.  The destructor relies on it: it waits for these streams
+    // only and hands the buffers to the cache, where another thread may take them at once.  PA_POISON_ALLOC runs keep it honest.
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ~pa_batch() {
         static const bool prof = getenv("PA_ALIGN_PROFILE") != nullptr;
@@ -1403,8 +1405,8 @@ struct pa_batch {
         if (stream) waited = hipStreamSynchronize(stream) == hipSuccess && waited;
         for (int c = 0; c < kMaxChunks; ++c)
             if (cstream[c]) waited = hipStreamSynchronize(cstream[c]) == hipSuccess && waited;
-        if (waited && !multi_stream_users) release_scope_begin_waited();
-        else release_scope_begin();
+        if (waited) release_scope_begin_waited();
+        else release_scope_begin();  // (a stream whose wait failed: wait for the whole device before the buffers go anywhere)
         if (prof) std::fprintf(stderr, "[pa_batch_destroy] device wait %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -1419,10 +1421,12 @@ struct pa_batch {
             if (evF0[c]) (void)hipEventDestroy(evF0[c]);
             if (evF1[c]) (void)hipEventDestroy(evF1[c]);
             if (evT1[c]) (void)hipEventDestroy(evT1[c]);
-            stream_give(cstream[c], d_a.device);
+            if (waited) stream_give(cstream[c], d_a.device);
+            else if (cstream[c]) (void)hipStreamDestroy(cstream[c]);  // a stream whose synchronize failed is not pooled
         }
         if (prof) std::fprintf(stderr, "[pa_batch_destroy] events, streams, pinned %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-        bstream_give(stream, d_a.device);  // (the batch waited for its device above: nothing of it is queued on the stream any more)
+        if (waited) bstream_give(stream, d_a.device);  // (the batch waited for its streams above: nothing of it is queued on the stream any more)
+        else if (stream) (void)hipStreamDestroy(stream);
         slice::destroy(sliced);
     }
 };

@@ -487,6 +487,6 @@ def combine_emu_run(threads: int, calls: int, batch_us: int = 300, fail_every: i
         L.pa_combine_emu_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.pa_combine_emu_run.restype = C.c_int
         _clib = L
-    out = (C.c_int64 * 5)()
+    out = (C.c_int64 * 7)()
     _clib.pa_combine_emu_run(threads, calls, batch_us, fail_every, out)
-    return dict(zip(("wrong", "batches", "largest_group", "side_by_side", "failed"), (int(x) for x in out)))
+    return dict(zip(("wrong", "batches", "largest_group", "side_by_side", "failed", "empty_groups", "late_returns"), (int(x) for x in out)))

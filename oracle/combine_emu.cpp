@@ -25,21 +25,25 @@ struct Req {
     uint64_t y = 0;
     int rc = 0;
     bool done = false;
+    bool queued = false;
+    long long t_done = 0;  // when the batch that served it finished (steady clock ticks)
 };
 inline uint64_t f(uint64_t x) { return x * 0x9E3779B97F4A7C15ull + 12345; }
 }  // namespace
 
 // T threads x `calls` requests each.  fail_every > 0: every fail_every-th batch throws.  out[0] = wrong results, out[1] = batches,
-// out[2] = largest group, out[3] = most batches running at once, out[4] = requests whose batch failed (rc != 0).  Returns 0.
+// out[2] = largest group, out[3] = most batches running at once, out[4] = requests whose batch failed (rc != 0), out[5] = EMPTY groups that were run,
+// out[6] = callers that returned more than half a (window + batch) + 2 ms after their own batch was done.  Returns 0.
 extern "C" int pa_combine_emu_run(int threads, int calls, int batch_us, int fail_every, int64_t* out) {
     pa::combine::Gatherer<Req> g;
     std::atomic<int> inside{0}, running{0}, max_running{0}, batches{0}, max_group{0};
-    std::atomic<int64_t> wrong{0}, failed{0};
+    std::atomic<int64_t> wrong{0}, failed{0}, empty_groups{0}, late_returns{0};
     auto run = [&](std::vector<Req*>& group) {
         const int now = running.fetch_add(1) + 1;
         int m = max_running.load();
         while (now > m && !max_running.compare_exchange_weak(m, now)) {
         }
+        if (group.empty()) empty_groups.fetch_add(1);
         const int b = batches.fetch_add(1) + 1;
         int mg = max_group.load();
         while ((int)group.size() > mg && !max_group.compare_exchange_weak(mg, (int)group.size())) {
@@ -49,9 +53,11 @@ extern "C" int pa_combine_emu_run(int threads, int calls, int batch_us, int fail
             running.fetch_sub(1);
             throw std::runtime_error("stand-in batch failed");
         }
+        const auto t_done = std::chrono::steady_clock::now().time_since_epoch().count();
         for (Req* r : group) {
             r->y = f(r->x);
             r->rc = 0;
+            r->t_done = t_done;
         }
         running.fetch_sub(1);
     };
@@ -60,6 +66,9 @@ extern "C" int pa_combine_emu_run(int threads, int calls, int batch_us, int fail
             inside.fetch_add(1);
             Req req{(uint64_t)t * 1000003ull + (uint64_t)c};
             g.submit(req, run, [&] { return inside.load(); }, 64, 4, 200, 7);
+            // a caller returns as soon as its own batch is done: not a window (200 us) plus another batch (batch_us) later
+            const long long t_ret = std::chrono::steady_clock::now().time_since_epoch().count();
+            if (req.rc == 0 && req.t_done && (t_ret - req.t_done) > (long long)(batch_us + 200) * 1000 / 2 + 2000000) late_returns.fetch_add(1);
             if (req.rc == 7) failed.fetch_add(1);
             else if (req.rc != 0 || req.y != f(req.x)) wrong.fetch_add(1);
             inside.fetch_sub(1);
@@ -73,5 +82,7 @@ extern "C" int pa_combine_emu_run(int threads, int calls, int batch_us, int fail
     out[2] = max_group.load();
     out[3] = max_running.load();
     out[4] = failed.load();
+    out[5] = empty_groups.load();
+    out[6] = late_returns.load();
     return 0;
 }

@@ -1,6 +1,11 @@
 """Writes tests/golden/restated_<variant>.json: oracle/astarpa2_restated.py over the seeded pairs of tests/restated_fixture.py under every
 parameter set of tests/test_restated_engine.py `variants` (run in the build container: python tests/golden/make_restated.py [processes]).
-Nothing of csrc/ is imported: the expected values come from the second restatement alone."""
+Nothing of csrc/ is imported: the expected values come from the second restatement alone.
+
+These are CROSS-RESTATEMENT fixtures, not reference-generated ones: both restatements were written by this repository's authors from the Rust
+text (the reference itself needs a Rust nightly toolchain and un-vendored crates: it cannot be built or run here).  They catch a divergence
+between the two in-repo readings -- not a mis-reading both share.  The reference-derived vectors are tests/golden/pa_test_pairs.json and the
+known answers of tests/test_oracle_kat.py; DEVIATIONS.md lists what each behaviour is pinned by."""
 import json
 import os
 import sys

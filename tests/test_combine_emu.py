@@ -16,6 +16,10 @@ def test_every_caller_gets_its_result_and_requests_travel_in_groups(oracle):
     assert r["wrong"] == 0 and r["failed"] == 0
     assert r["batches"] < 32 * 60 // 3 and r["largest_group"] >= 8, r  # groups, not single requests
     assert 2 <= r["side_by_side"] <= 4, r  # several batches at a time, never more than the bound
+    # a caller whose request already travels in a batch does not gather (round 5's advisor finding: it ran EMPTY groups and returned late)
+    assert r["empty_groups"] == 0 and r["late_returns"] == 0, r
+    slow = oracle.combine_emu_run(threads=32, calls=12, batch_us=6000)  # the advisor's repro: 32 threads, a 6 ms stand-in batch
+    assert slow["wrong"] == 0 and slow["empty_groups"] == 0 and slow["late_returns"] == 0, slow
     one = oracle.combine_emu_run(threads=1, calls=20, batch_us=100)
     assert one["wrong"] == 0 and one["batches"] == 20 and one["largest_group"] == 1
 

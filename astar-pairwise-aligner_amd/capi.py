@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "pa_bp_ctx_create", "pa_bp_ctx_compute", "pa_bp_ctx_fill", "pa_bp_ctx_destroy",
     "pa_batch_create_params", "pa_batch_pair_stats", "pa_runtime_hints", "pa_batch_align_multi_params", "pa_release_pools", "pa_align_file_params", "pa_batch_params_supported", "pa_alloc_cache_stats", "pa_free_cigars",
     "pa_batch_full_info", "pa_batch_rdv_stats", "pa_combine_stats", "pa_params_nw", "pa_params_simple", "pa_params_full", "pa_debug_gcsh_probe", "pa_debug_gcsh_matches", "pa_batch_window_retries", "pa_batch_window_retry_bytes",
-    "pa_batch_slice_info",
+    "pa_batch_slice_info", "pa_set_reference_cost_only",
 ]
 
 _lib = None
@@ -55,6 +55,8 @@ def load(build_if_stale: bool = True) -> C.CDLL:
         raise PaError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
     L = C.CDLL(str(path))
     L.pa_runtime_hints.restype = C.c_int
+    L.pa_set_reference_cost_only.argtypes = [C.c_int]
+    L.pa_set_reference_cost_only.restype = None
     L.pa_release_pools.restype = None
     L.pa_alloc_cache_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
     L.pa_free_cigars.argtypes = [C.c_void_p, C.c_size_t]

@@ -252,12 +252,21 @@ struct GapCostH : Heuristic {  // distances.rs:131-168
 // occurs anywhere in b (matches/exact.rs:15-69; keys are 2-bit packed and truncated to u32 as there).
 // h(i,j) = potential(i) - score(i) = number of seeds starting at >= i without a match.  SHI does not override
 // prune_block / update_contours (heuristic.rs:150-157), so under A*PA2 it is static and column-only.
+// HeuristicParams.p != 0 reaches SH as well (cli.rs:168-180: MatchConfig.local_pruning = p for every heuristic; sh.rs:48 passes it to
+// find_matches with transform_filter = false): a seed then counts as matched only if one of its matches SURVIVES local pruning
+// (MatchBuilder::push, matches.rs:205-247) -- sh_matched_with_local_pruning below, after gcsh.hpp.
 struct SeedHeuristicH : Heuristic {
     std::vector<Cost> h_by_i;  // size n+1
-    SeedHeuristicH(const uint8_t* a, I n, const uint8_t* b, I m, I k) {
+    static std::vector<uint8_t> sh_matched_with_local_pruning(const uint8_t* a, I n, const uint8_t* b, I m, I k, int p);
+    SeedHeuristicH(const uint8_t* a, I n, const uint8_t* b, I m, I k, int p = 0) {
         h_by_i.assign((size_t)n + 1, 0);
         if (k <= 0) k = 1;
         const I nseeds = n >= k ? (n - k) / k + 1 : 0;
+        if (p != 0) {
+            const std::vector<uint8_t> matched = sh_matched_with_local_pruning(a, n, b, m, k, p);
+            fill_from(matched, n, k, nseeds);
+            return;
+        }
         auto bits = [](uint8_t c) -> uint64_t { return (uint64_t)((c >> 1) & 3); };  // qgrams.rs:30-33
         std::vector<std::pair<uint32_t, I>> keys;  // (key, seed index), sorted => multimap
         keys.reserve((size_t)nseeds);
@@ -279,7 +288,10 @@ struct SeedHeuristicH : Heuristic {
                 for (; it != keys.end() && it->first == key; ++it) matched[(size_t)it->second] = 1;
             }
         }
-        // potential[i] - score(i): walk seeds from the right (seeds.rs:47-66, sh_contours.rs:40-47,63-75)
+        fill_from(matched, n, k, nseeds);
+    }
+    // potential[i] - score(i): walk seeds from the right (seeds.rs:47-66, sh_contours.rs:40-47,63-75)
+    void fill_from(const std::vector<uint8_t>& matched, I n, I k, I nseeds) {
         Cost unmatched = 0;
         I next_seed = nseeds - 1;
         for (I i = n; i >= 0; --i) {
@@ -298,6 +310,15 @@ struct SeedHeuristicH : Heuristic {
 #include "gcsh.hpp"  // GcshHeuristic (needs Heuristic / I / Cost from above)
 namespace pa {
 namespace engine {
+
+inline std::vector<uint8_t> SeedHeuristicH::sh_matched_with_local_pruning(const uint8_t* a, I n, const uint8_t* b, I m, I k, int p) {
+    // the matches MatchBuilder keeps for find_matches(a, b, {k, r = 1, local_pruning = p}, transform_filter = false): gcsh.hpp's push loop
+    const GcshHeuristic g(a, n, b, m, k, p, /*prune=*/false, /*build_layers=*/false, /*transform_filter=*/false);
+    std::vector<uint8_t> matched((size_t)g.nseeds, 0);
+    for (const GcshHeuristic::Match& mt : g.by_start) matched[(size_t)(mt.i / g.k)] = 1;
+    return matched;
+}
+
 
 // unit-cost AffineCost formulas (pa-affine-types/src/cost_model.rs:387-401,453-525 with sub=ins=del=1)
 inline Cost unit_gap_cost(I si, I sj, I ti, I tj) {
@@ -967,7 +988,7 @@ class AstarPa2Instance {
         if (params.domain == DomainKind::Astar) {
             if (params.heuristic == HeuristicKind::Gap) heur = std::make_unique<GapCostH>(be.n(), be.m());
             else if (params.heuristic == HeuristicKind::SH)
-                heur = std::make_unique<SeedHeuristicH>(be.a(), be.n(), be.b(), be.m(), params.heuristic_k);
+                heur = std::make_unique<SeedHeuristicH>(be.a(), be.n(), be.b(), be.m(), params.heuristic_k, (int)params.heuristic_p);
             else if (params.heuristic == HeuristicKind::GCSH)  // Prune::Start iff params.prune (cli.rs:167-192)
                 heur = std::make_unique<GcshHeuristic>(be.a(), be.n(), be.b(), be.m(), params.heuristic_k, (int)params.heuristic_p,
                                                        params.prune);

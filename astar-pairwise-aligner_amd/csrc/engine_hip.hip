@@ -1043,6 +1043,14 @@ struct InsideGuard {
 };
 }  // namespace
 
+static std::atomic<int> g_reference_cost_only{0};
+static bool reference_cost_only_requested() {
+    if (g_reference_cost_only.load(std::memory_order_relaxed)) return true;
+    const char* e = std::getenv("PA_COST_ONLY_MODE");
+    return e && std::strcmp(e, "reference") == 0;
+}
+extern "C" void pa_set_reference_cost_only(int on) { g_reference_cost_only.store(on ? 1 : 0, std::memory_order_relaxed); }
+
 // Diagnostics: calls served through the combiner so far, and the batches they went out in.
 extern "C" void pa_combine_stats(uint64_t* calls, uint64_t* batches) {
     if (calls) *calls = g_comb_calls.load();
@@ -1104,7 +1112,11 @@ int align_hip(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, co
     // Domain::Astar with a closed-form / per-column heuristic and the sparse, non-incremental block engine (the `simple`
     // preset and its relatives): every align_for_bounded_dist pass is ONE persistent launch with the band logic in the kernel
     // (sweep_wave.hpp).  A pass the kernel hands back (SweepFallback) is redone by the host-driven engine below.
-    const bool no_sweep = std::getenv("PA_ENGINE_NO_SWEEP") != nullptr;  // (diagnostics / tests: the host-driven engine)
+    // pa_set_reference_cost_only(1) / PA_COST_ONLY_MODE=reference: trace == 0 runs the REFERENCE's cost-only arm (blocks.rs:252-277: one block
+    // updated in place) through the host-driven engine over the HIP kernels -- the value the reference's make_aligner(false) returns, upper
+    // bounds included (include/pa_astarpa2.h, DEVIATIONS.md)
+    const bool ref_cost_only = !trace && reference_cost_only_requested();
+    const bool no_sweep = ref_cost_only || std::getenv("PA_ENGINE_NO_SWEEP") != nullptr;  // (PA_ENGINE_NO_SWEEP: diagnostics / tests, the host-driven engine)
     if (!no_sweep && !self_check && sweep::sweep_supported(p, a_len, b_len)) {
         try {
             HipSweepLauncher launcher(be, sweep_pool());

@@ -162,7 +162,8 @@ struct GcshHeuristic : Heuristic {
     }
 
     // build_layers = false: the matches and the per-seed windows only (the batched GPU path derives the contours on the device)
-    GcshHeuristic(const uint8_t* a_, I n_, const uint8_t* b_, I m_, I k_, int p_, bool prune_, bool build_layers = true)
+    // transform_filter = false: find_matches(a, b, config, false) as SH calls it (heuristic/sh.rs:48) -- local pruning without the gap transform's filter
+    GcshHeuristic(const uint8_t* a_, I n_, const uint8_t* b_, I m_, I k_, int p_, bool prune_, bool build_layers = true, bool transform_filter = true)
         : a(a_), b(b_), n(n_), m(m_), k(k_ < 1 ? 1 : k_), p(p_), prune_enabled(prune_) {
         // seeds + potentials (qgrams.rs:99-109, seeds.rs:34-71)
         nseeds = n >= k ? (n - k) / k + 1 : 0;
@@ -225,7 +226,7 @@ struct GcshHeuristic : Heuristic {
                     const I i = (I)sidx * k;
                     num_matches_pushed += 1;
                     // MatchBuilder::push, matches.rs:205-247
-                    if (!le(T(i, j), tt)) continue;                                   // transform filter
+                    if (transform_filter && !le(T(i, j), tt)) continue;               // transform filter
                     if (!preserve_for_local_pruning(i, j, fr, next_fr, next_match_per_diag)) continue;  // local pruning
                     if (p != 0) {
                         I& old = next_match_per_diag.index_mut(i - j);

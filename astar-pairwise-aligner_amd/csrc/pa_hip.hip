@@ -1705,7 +1705,7 @@ static bool astar_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t* cons
     if (p->sp.heur == sweep::kHeurSH && tsh) {  // SeedHeuristicH (pa-heuristic sh.rs:47-106): host-built per-column table
         std::vector<int32_t> sh(tsh);
         for (size_t i = 0; i < P; ++i) {
-            engine::SeedHeuristicH h(a[i], (engine::I)p->n[i], b[i], (engine::I)p->m[i], ap.heuristic_k);
+            engine::SeedHeuristicH h(a[i], (engine::I)p->n[i], b[i], (engine::I)p->m[i], ap.heuristic_k, (int)ap.heuristic_p);
             std::copy(h.h_by_i.begin(), h.h_by_i.end(), sh.begin() + sh_off[i]);
         }
         if (!hip_ok(hipMemcpy(p->d_sh.ptr, sh.data(), tsh * 4, hipMemcpyHostToDevice), "H2D sh")) return false;
@@ -1846,7 +1846,7 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
             const engine::I n = (engine::I)p->n[i], m = (engine::I)p->m[i];
             if (n == 0 || m == 0) return;
             if (sh) {
-                engine::SeedHeuristicH h(a[i], n, b[i], m, ap.heuristic_k);
+                engine::SeedHeuristicH h(a[i], n, b[i], m, ap.heuristic_k, (int)ap.heuristic_p);
                 std::copy(h.h_by_i.begin(), h.h_by_i.end(), shv.begin() + (long)sh_off[i]);
                 return;
             }

@@ -132,7 +132,7 @@ class SweepAligner {
         hp.m = m;
         hp.sh_h = nullptr;
         if (hp.kind == kHeurSH) {
-            engine::SeedHeuristicH sh(be.a(), n, be.b(), m, p.heuristic_k);
+            engine::SeedHeuristicH sh(be.a(), n, be.b(), m, p.heuristic_k, (int)p.heuristic_p);
             sh_h.assign(sh.h_by_i.begin(), sh.h_by_i.end());
             hp.sh_h = sh_h.data();
         }

@@ -75,6 +75,11 @@ void pa_params_batch_align(pa_astarpa2_params* p);
  * (tests/test_cost_only_mode.py) -- whereas this library returns the distance. */
 int pa_align(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, const pa_astarpa2_params* params,
              int trace, int32_t* cost_out, char** cigar_out, pa_astarpa2_stats* stats_out);
+/* The other choice for trace == 0, process-wide: on != 0 (or PA_COST_ONLY_MODE=reference in the environment) makes pa_align(trace = 0) run
+ * the REFERENCE's cost-only arm for every parameter set -- blocks.rs:252-277 restated in csrc/engine.hpp, its rectangles on the GPU, one
+ * launch per 256-column block: the value `AstarPa2Params::simple().make_aligner(false)` returns, upper bounds included (11353 for the pair
+ * of tests/golden/cost_only_pair.json, tests/test_gpu_engine.py::test_reference_cost_only_mode_on_the_gpu).  Off by default: see above. */
+void pa_set_reference_cost_only(int on);
 
 /* Callers that are inside pa_align (or an astarpa-c symbol) AT THE SAME TIME with the same parameters, sequences shorter than 32 768
  * bases and a parameter set the batch kernels take (pa_batch_params_supported) are COMBINED: one of them aligns all queued pairs as one

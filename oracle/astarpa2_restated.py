@@ -66,12 +66,20 @@ def kmer_key(s: bytes, i: int, k: int) -> bytes:
     return s[i + max(0, k - 16):i + k]
 
 
-def sh_table(a: bytes, b: bytes, k: int):
-    """h(i) = number of seeds of a starting at >= i that have no exact match anywhere in b (seeds: consecutive k-mers from 0)."""
+def sh_table(a: bytes, b: bytes, k: int, p: int = 0):
+    """h(i) = number of seeds of a starting at >= i that have no exact match anywhere in b (seeds: consecutive k-mers from 0).
+    p != 0: HeuristicParams.p is the local-pruning length of EVERY heuristic (pa-heuristic/src/cli.rs:168-180), so SH's matches go through
+    MatchBuilder::push's local pruning too (matches.rs:205-247; sh.rs:48: find_matches(.., transform_filter = false)) and a seed only counts
+    as matched (seed_cost 0: sh_contours.rs:38-46) if one of its matches is kept."""
     n = len(a)
-    bk = {kmer_key(b, j, k) for j in range(0, len(b) - k + 1)} if len(b) >= k else set()
     nseeds = n // k
-    matched = [kmer_key(a, s * k, k) in bk for s in range(nseeds)]
+    if p != 0:
+        g = Gcsh(a, b, k, p, False, transform_filter=False)
+        kept_seeds = {int(i) // k for i in g.mi.tolist()}
+        matched = [s in kept_seeds for s in range(nseeds)]
+    else:
+        bk = {kmer_key(b, j, k) for j in range(0, len(b) - k + 1)} if len(b) >= k else set()
+        matched = [kmer_key(a, s * k, k) in bk for s in range(nseeds)]
     h = [0] * (n + 1)
     unmatched, nxt = 0, nseeds - 1
     for i in range(n, -1, -1):
@@ -101,7 +109,7 @@ class Gcsh:
     The reference keeps the layers incrementally; its update re-scores every layer from the lowest touched one upwards, which is the
     state a fresh construction over the still active matches gives -- that state is what this class computes (with numpy)."""
 
-    def __init__(self, a: bytes, b: bytes, k: int, p: int, prune: bool):
+    def __init__(self, a: bytes, b: bytes, k: int, p: int, prune: bool, transform_filter: bool = True):
         import numpy as np
 
         self.np = np
@@ -130,7 +138,7 @@ class Gcsh:
         for j in range(m - k, -1, -1):
             for i in table.get(kmer_key(b, j, k), ()):
                 ts = self.T(i, j)
-                if not (ts[0] <= self.t_target[0] and ts[1] <= self.t_target[1]):
+                if transform_filter and not (ts[0] <= self.t_target[0] and ts[1] <= self.t_target[1]):
                     continue
                 if p != 0 and not self._preserve(i, j):
                     continue
@@ -351,7 +359,7 @@ class Restated:
         self.domain, self.sparse, self.doubling, self.start, self.factor, self.delta = domain, sparse, doubling, start, factor, delta
         self.kind, self.sparse_h, self.bw = (heuristic if domain == "astar" else "none"), sparse_h, block_width
         self.dt, self.max_g, self.fr_drop = dt_trace, max_g, fr_drop
-        self.sh = sh_table(a, b, k) if self.kind == "sh" else None
+        self.sh = sh_table(a, b, k, p) if self.kind == "sh" else None
         self.prune = prune and self.kind == "gcsh"
         self.gcsh = Gcsh(a, b, k, p, prune) if self.kind == "gcsh" else None
         self.peq = {c: sum(1 << j for j in range(self.m) if b[j] == c) for c in set(a)}  # rows >= m never match (profile.rs:127-132)

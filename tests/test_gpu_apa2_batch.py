@@ -280,3 +280,20 @@ def test_two_pairs_per_strip_changes_nothing(pa, oracle, monkeypatch, preset):
     assert all(v == base for v in got.values())
     for (a, b), c in list(zip(pairs, base[0]))[::40]:
         assert c == oracle.levenshtein(a, b)
+
+
+def test_sh_with_local_pruning_batch_and_single(pa, oracle):
+    """SH with HeuristicParams.p != 0 (local pruning applies to SH's matches too: pa-heuristic/src/cli.rs:168-180, sh.rs:48): the host-built
+    table reaches the batch kernel and the sweep of pa_align; both equal the engine over the CPU kernels."""
+    from tests.test_gpu_engine import gpu_params
+    from tests.test_restated_engine import BASE
+
+    pairs = [gen_pair(n, e, seed) for n, e, seed in [(300, 0.05, 1), (3000, 0.1, 3), (9000, 0.2, 4), (6000, 0.25, 6), (12000, 0.15, 5)]]
+    for k, p in ((8, 3), (12, 14)):
+        oc = oracle.make_params(**{**BASE, "heuristic": "sh", "k": k, "p": p})
+        check(pa, oracle, pairs, oc)
+        al = gpu_params(pa, oc).make_aligner(True)
+        for a, b in pairs[:3]:
+            want = oracle.cpu_align(a, b, oc)
+            got = al.align_with_stats(a, b)
+            assert (got[0], got[1]) == want[:2] and {k_: got[2][k_] for k_ in KEYS} == {k_: want[2][k_] for k_ in KEYS}

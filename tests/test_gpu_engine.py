@@ -101,6 +101,44 @@ def test_cost_only_mode(pa, oracle):
         both(pa, oracle, a, b, oracle.params_nw(), trace=False)
 
 
+def test_reference_cost_only_mode_on_the_gpu(pa, oracle):
+    """pa_set_reference_cost_only(1): pa_align(trace = 0) runs the REFERENCE's cost-only arm (astarpa2/src/blocks.rs:252-277, one block updated
+    in place) with its rectangles on the GPU -- cost, passes and block counters of both restatements of that arm, the upper bound 11353 of
+    tests/golden/cost_only_pair.json (distance 11325) included.  Default: the distance over the traced band (include/pa_astarpa2.h)."""
+    import json
+    from pathlib import Path
+
+    from astar_pairwise_aligner_amd import capi
+    from oracle import astarpa2_restated as restated
+    from tests.test_restated_engine import variants
+
+    keys = ["num_blocks", "num_incremental_blocks", "computed_lanes", "unique_lanes", "f_max_tries"]
+    j = json.loads((Path(__file__).resolve().parent / "golden" / "cost_only_pair.json").read_text())
+    a, b = j["a"].encode(), j["b"].encode()
+    prm = oracle.make_params(domain="astar", heuristic="sh", k=12, doubling="band", start="h0", factor=2.0, block_width=256, sparse=True,
+                             incremental_doubling=False, dt_trace=True, max_g=40, fr_drop=10, sparse_h=True)
+    al = gpu_params(pa, prm).make_aligner(False)
+    assert al.align(a, b) == (11325, None)  # the default: the distance
+    capi.load().pa_set_reference_cost_only(1)
+    try:
+        cost, cigar, stats = al.align_with_stats(a, b)
+        want = oracle.cpu_align(a, b, prm, trace=False)
+        second = restated.align(a, b, heuristic="sh", k=12, trace=False)
+        assert cost == want[0] == second[0] == 11353 and cigar is None
+        assert {k: stats[k] for k in keys} == {k: want[2][k] for k in keys} == {k: second[2][k] for k in keys}
+        vs = variants(oracle)
+        for name, (n, e, seed) in [("simple", (4000, 0.1, 5)), ("sh12", (9000, 0.2, 6)), ("dijkstra", (3000, 0.05, 7)), ("full", (8000, 0.1, 8)),
+                                   ("gap_incr", (5000, 0.15, 9)), ("linear300", (2500, 0.1, 10))]:
+            oc, kw = vs[name]
+            a2, b2 = gen_pair(n, e, seed)
+            cost, cigar, stats = gpu_params(pa, oc).make_aligner(False).align_with_stats(a2, b2)
+            want = oracle.cpu_align(a2, b2, oc, trace=False)
+            assert (cost, cigar) == (want[0], None) and {k: stats[k] for k in keys} == {k: want[2][k] for k in keys}, name
+    finally:
+        capi.load().pa_set_reference_cost_only(0)
+    assert al.align(a, b) == (11325, None)
+
+
 def test_invalid_base_raises(pa):
     with pytest.raises(ValueError):
         pa.astarpa2_simple(b"ACGTN", b"ACGT")

@@ -205,3 +205,20 @@ def test_c3_pair_of_the_bench_full_preset(oracle):
     want = oracle.cpu_align(a, b, prm)
     assert (got[0], got[1]) == want[:2] and {k: got[2][k] for k in KEYS} == {k: want[2][k] for k in KEYS}
     assert int((~r.gcsh.active).sum()) > 1000  # matches were pruned on the way
+
+
+def test_sh_with_local_pruning(oracle):
+    """HeuristicParams.p reaches SH as well (pa-heuristic/src/cli.rs:168-180 sets MatchConfig.local_pruning for every heuristic; sh.rs:48):
+    a seed counts as matched only if one of its matches survives MatchBuilder::push's local pruning (matches.rs:205-247).  Both
+    restatements, cost + CIGAR + statistics; the pruning has to change the table on a good share of the pairs."""
+    rng = random.Random(1)
+    changed = 0
+    for it in range(80):
+        n, e = rng.choice([200, 1500, 6000]), rng.choice([0.02, 0.1, 0.25])
+        k, p = rng.choice([5, 8, 12]), rng.choice([1, 3, 14])
+        a, b = gen_pair(n, e, rng.randint(1, 10**9))
+        incr = rng.random() < 0.3
+        compare(oracle, a, b, oracle.make_params(**{**BASE, "heuristic": "sh", "k": k, "p": p, "incremental_doubling": incr}),
+                dict(heuristic="sh", k=k, p=p, incremental_doubling=incr))
+        changed += restated.sh_table(a, b, k, p) != restated.sh_table(a, b, k, 0)
+    assert changed >= 20, changed

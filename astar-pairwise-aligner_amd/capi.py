@@ -55,8 +55,9 @@ def load(build_if_stale: bool = True) -> C.CDLL:
         raise PaError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
     L = C.CDLL(str(path))
     L.pa_runtime_hints.restype = C.c_int
-    L.pa_set_reference_cost_only.argtypes = [C.c_int]
-    L.pa_set_reference_cost_only.restype = None
+    if hasattr(L, "pa_set_reference_cost_only"):  # (PA_LIB_PATH may point at an older build of the library: diagnostics)
+        L.pa_set_reference_cost_only.argtypes = [C.c_int]
+        L.pa_set_reference_cost_only.restype = None
     L.pa_release_pools.restype = None
     L.pa_alloc_cache_stats.argtypes = [C.POINTER(C.c_uint64)] * 3
     L.pa_free_cigars.argtypes = [C.c_void_p, C.c_size_t]

@@ -70,6 +70,10 @@ __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t old_, uint32_t src) {
     // v_mov_b32_dpp wave_shr:1 ; lane 0 has no source lane and keeps `old_`
     return (uint32_t)__builtin_amdgcn_update_dpp((int)old_, (int)src, 0x138, 0xf, 0xf, false);
 }
+__device__ __forceinline__ uint32_t dpp_wave_rol1(uint32_t x) {
+    // v_mov_b32_dpp wave_rol:1 ; lane i takes lane i + 1's value, lane 63 lane 0's
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x134, 0xf, 0xf, false);
+}
 __device__ __forceinline__ uint2 ld_boundary(const uint2* p) {  // L1-bypassing 8-byte load, one access (agent scope: the producer may sit on another XCD)
     const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
@@ -80,7 +84,9 @@ __device__ __forceinline__ void st_boundary(uint2* p, uint32_t hp, uint32_t hm) 
 
 // Two rows (A = i, B = i + 1) of one column step, in an order in which no instruction reads the result of the one before it and the chain
 // value hm_B is ready eight instructions before the block ends.  Inline asm because the compiler's own order hoists the whole hm chain of
-// the lane in front of everything else (2 R live temporaries: spills at R >= 40) -- tools/slice_probe.hip, SLICE_ASM=0.
+// the lane in front of everything else (2 R live temporaries: spills at R >= 40) -- tools/slice_probe.hip, SLICE_ASM=0.  Every asm statement
+// costs one s_nop (the hazard recognizer assumes the worst of a register that one asm statement writes and the next reads); blocks of FOUR
+// rows halve those and run 16-20 % SLOWER all the same, whichever order the 32 instructions have (profiles/r06_runs/slice_variants.log).
 #define PA_SLICE_ROW_PAIR(vpA, vmA, vpB, vmB, nb0A, nb1A, nb0B, nb1B, a0, a1, hpp, hmp, hpo, hmo)                                      \
     do {                                                                                                                                \
         uint32_t eA_, eB_, x_, vx_, hmA_, hpA_;                                                                                          \
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(64, 2) void slice_kernel(const SliceJob* __restrict
             vm[i] = 0u;
         }
         // Columns come in CHUNKS of 64: lane j loads column 64 q + j of the group's planes and of the boundary row above (one coalesced load
-        // each per chunk, issued a whole chunk ahead); step j of the chunk hands lane j's values to lane 0 (v_readlane with a uniform index),
+        // each per chunk, issued a whole chunk ahead); the chunk registers ROTATE one lane per step (DPP wave_rol:1), so that at step j lane 0 finds column 64 q + j in its own lane,
         // and everything -- the column's two code planes AND the row's (hp, hm) -- then moves down the lanes one lane per step through DPP
         // wave_shr:1.  No vector memory load sits in the step loop, so no wait does either.
         uint32_t o_hp = 0, o_hm = 0, o_a0 = 0, o_a1 = 0;
@@ -152,8 +158,9 @@ __global__ __launch_bounds__(64, 2) void slice_kernel(const SliceJob* __restrict
             uint2 cA = nA, cH = nH;
             const int col = q * 64 + lane;  // the column this lane holds for lane 0
             if (has_in) {
-                // the strip above has to be past this chunk.  It normally is (it started first and runs at the same pace); when this strip has
-                // caught up, waiting here until all 64 columns are there lets it run them at full speed instead of riding at the other's heels
+                // The strip above has to be past this chunk.  It normally is (it started first and runs at the same pace); when this strip has
+                // caught up, waiting here until all 64 columns are there lets it run them at full speed.  (Letting the strip above get three
+                // chunks ahead once a chunk was found missing changed nothing: profiles/r06_runs/slice_variants.log.)
                 uint32_t spins = 0;
                 while (col < n && (cH.x & cH.y) != 0u) {
                     __builtin_amdgcn_s_sleep(32);
@@ -172,10 +179,14 @@ __global__ __launch_bounds__(64, 2) void slice_kernel(const SliceJob* __restrict
             const int jend = min(64, n + 63 - q * 64);
             for (int j = 0; j < jend; ++j) {
                 const int c = q * 64 + j - lane;
-                const uint32_t ia0 = (uint32_t)__builtin_amdgcn_readlane((int)cA.x, j), ia1 = (uint32_t)__builtin_amdgcn_readlane((int)cA.y, j);
-                const uint32_t ihp = (uint32_t)__builtin_amdgcn_readlane((int)cH.x, j), ihm = (uint32_t)__builtin_amdgcn_readlane((int)cH.y, j);
-                const uint32_t a0 = dpp_wave_shr1(ia0, o_a0), a1 = dpp_wave_shr1(ia1, o_a1);
-                uint32_t hpp = dpp_wave_shr1(ihp, o_hp), hmp = dpp_wave_shr1(ihm, o_hm);
+                // lane 0 takes the chunk registers' value of ITS lane -- they rotate one lane per step, so that is column 64 q + j --, every other
+                // lane the value the lane above it had a step ago
+                const uint32_t a0 = dpp_wave_shr1(cA.x, o_a0), a1 = dpp_wave_shr1(cA.y, o_a1);
+                uint32_t hpp = dpp_wave_shr1(cH.x, o_hp), hmp = dpp_wave_shr1(cH.y, o_hm);
+                cA.x = dpp_wave_rol1(cA.x);
+                cA.y = dpp_wave_rol1(cA.y);
+                cH.x = dpp_wave_rol1(cH.x);
+                cH.y = dpp_wave_rol1(cH.y);
                 o_a0 = a0;
                 o_a1 = a1;
                 if ((unsigned)c < (unsigned)n) {
@@ -265,7 +276,9 @@ __global__ __launch_bounds__(256) void slice_pack_b_kernel(const SliceGroup* __r
     B[grp.b_off + (size_t)j * 64 + lane] = make_uint2(nb0, nb1);
 }
 
-// cost of pair p = |a_p| + sum over its rows r < |b_p| of (vp - vm) of the captured column (Block::index from the top: block.rs:100-121)
+// cost of pair p = |a_p| + sum over its rows r < |b_p| of (vp - vm) of the captured column (Block::index from the top: block.rs:100-121).
+// One wavefront per (group, span of kScoreSpan rows); cost_out is zeroed before the pass and every wavefront adds its share.
+constexpr int kScoreSpan = 4096;
 __global__ __launch_bounds__(64) void slice_score_kernel(const SliceGroup* __restrict__ groups, const SlicePair* __restrict__ spairs,
                                                          const uint2* __restrict__ V, int32_t* __restrict__ cost_out) {
     const SliceGroup grp = groups[blockIdx.x];
@@ -281,11 +294,13 @@ __global__ __launch_bounds__(64) void slice_score_kernel(const SliceGroup* __res
     int max_m = my_m;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) max_m = max(max_m, __shfl_xor(max_m, o));
-    int acc = 0;
-    for (int r0 = 0; r0 < max_m; r0 += 64) {
+    const int lo = (int)blockIdx.y * kScoreSpan, hi = min(max_m, lo + kScoreSpan);
+    if (lo >= max_m) return;
+    int acc = blockIdx.y == 0 ? my_n : 0;
+    for (int r0 = lo; r0 < hi; r0 += 64) {
         const int r = r0 + lane;
         uint2 v = make_uint2(0u, 0u);
-        if (r < max_m) v = V[grp.b_off + r];
+        if (r < hi) v = V[grp.b_off + r];
         for (int p = 0; p < grp.npairs; ++p) {
             const int mp = __shfl(my_m, p);
             const bool in = r < mp;
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(64) void slice_score_kernel(const SliceGroup* __res
             if (lane == p) acc += pos - neg;
         }
     }
-    if (lane < grp.npairs) cost_out[my_pair] = my_n + acc;
+    if (lane < grp.npairs && acc != 0) atomicAdd(&cost_out[my_pair], acc);
 }
 
 }  // namespace slice

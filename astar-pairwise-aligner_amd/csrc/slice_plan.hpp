@@ -12,8 +12,9 @@ namespace slice {
 
 struct Plan;
 
-// Rows per lane the kernel is instantiated for (two wavefronts per SIMD: 4 R + ~30 VGPRs <= 256).
-constexpr int kRowsPerLane[] = {54, 50, 46, 42, 38, 34, 30};
+// Rows per lane the kernel is instantiated for (two wavefronts per SIMD: 4 R + ~40 VGPRs <= 256; even: the rows are stepped in asm blocks of four, then
+// one of two).
+constexpr int kRowsPerLane[] = {52, 50, 48, 46, 44, 42, 40, 36, 32, 28};
 
 // Which R (0 = do not use the sliced kernel) and the estimated time of one pass in ns, for ranking against the other batch shapes.
 // A batch qualifies when it has enough pairs to fill the chip with (group, strip) jobs.
@@ -24,7 +25,7 @@ Plan* create(const size_t* a_len, const size_t* b_len, size_t pairs, const size_
 void destroy(Plan* p);
 
 // Queues one pass on `s`: transposes (from the codes / profile the batch's encode kernels have just written), boundary rows reset, the
-// kernel (bracketed by ev0 / ev1), the score kernel.  d_costs[pair] receives the distance of every pair with two non-empty sequences;
+// kernel (bracketed by ev0 / ev1), the score kernel.  d_costs[pair] -- ZERO before the call -- receives the distance of every pair with two non-empty sequences;
 // d_ticket_err: two u32, zeroed here; [1] != 0 afterwards = a bounded poll expired (slice::kErrSpin).
 int run(Plan* p, hipStream_t s, const uint32_t* d_codes, const uint64_t* d_prof, int32_t* d_costs, uint32_t* d_ticket_err, hipEvent_t ev0, hipEvent_t ev1);
 

@@ -15,7 +15,7 @@ namespace pa {
 namespace slice {
 
 struct Plan {
-    int R = 54;
+    int R = 52;
     size_t pairs = 0;
     std::vector<SliceGroup> groups;
     std::vector<SliceJob> jobs;
@@ -182,18 +182,21 @@ int run(Plan* p, hipStream_t s, const uint32_t* d_codes, const uint64_t* d_prof,
     if (ev0 && !hip_ok(hipEventRecord(ev0, s), "event")) return PA_E_HIP;
     hipError_t e = hipSuccess;
     switch (p->R) {
-        case 54: e = launch_slice<54>(grid, s, p, d_ticket_err); break;
+        case 52: e = launch_slice<52>(grid, s, p, d_ticket_err); break;
         case 50: e = launch_slice<50>(grid, s, p, d_ticket_err); break;
+        case 48: e = launch_slice<48>(grid, s, p, d_ticket_err); break;
         case 46: e = launch_slice<46>(grid, s, p, d_ticket_err); break;
+        case 44: e = launch_slice<44>(grid, s, p, d_ticket_err); break;
         case 42: e = launch_slice<42>(grid, s, p, d_ticket_err); break;
-        case 38: e = launch_slice<38>(grid, s, p, d_ticket_err); break;
-        case 34: e = launch_slice<34>(grid, s, p, d_ticket_err); break;
-        case 30: e = launch_slice<30>(grid, s, p, d_ticket_err); break;
+        case 40: e = launch_slice<40>(grid, s, p, d_ticket_err); break;
+        case 36: e = launch_slice<36>(grid, s, p, d_ticket_err); break;
+        case 32: e = launch_slice<32>(grid, s, p, d_ticket_err); break;
+        case 28: e = launch_slice<28>(grid, s, p, d_ticket_err); break;
         default: set_error("slice: no kernel for %d rows per lane", p->R); return PA_E_INTERNAL;
     }
     if (!hip_ok(e, "slice_kernel")) return PA_E_HIP;
     if (ev1 && !hip_ok(hipEventRecord(ev1, s), "event")) return PA_E_HIP;
-    hipLaunchKernelGGL(slice_score_kernel, dim3(G), dim3(64), 0, s, p->d_groups.as<SliceGroup>(), p->d_spairs.as<SlicePair>(), p->d_V.as<uint2>(), d_costs);
+    hipLaunchKernelGGL(slice_score_kernel, dim3(G, getenv("PA_SCORE_ONE") ? 1u : (p->max_row_blocks * 256u + kScoreSpan - 1) / kScoreSpan), dim3(64), 0, s, p->d_groups.as<SliceGroup>(), p->d_spairs.as<SlicePair>(), p->d_V.as<uint2>(), d_costs);
     if (!hip_ok(hipGetLastError(), "slice_score_kernel")) return PA_E_HIP;
     return 0;
 }

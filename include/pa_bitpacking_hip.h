@@ -118,7 +118,7 @@ void pa_batch_shape(const pa_batch* plan, int* k, int* sequential, double* valu_
  * PA_SLICE=<rows> forces the rows per lane) run BIT-SLICED (csrc/slice_kernel.hpp): the pairs are sorted by length and cut into groups of
  * 32; bit p of every register belongs to pair p of the group and a register is one DP row, which turns the add and the shifts of the Myers
  * step (pa-bitpacking/src/myers.rs:27-55) into eight boolean instructions per row -- the same distances, 1.5x the cells per second.
- * Returns the rows per lane of that kernel (56, 48, 40, 32), 0 when the batch runs on the strip kernels (pa_batch_shape then says which);
+ * Returns the rows per lane of that kernel (52 down to 28), 0 when the batch runs on the strip kernels (pa_batch_shape then says which);
  * groups, (group, strip) jobs, cells computed including the padding to whole strips and to the group's longest sequences, device bytes
  * of the plan, and how many of them (the boundary rows between strips) are reset before every pass. */
 int pa_batch_slice_info(const pa_batch* plan, double* groups, double* jobs, double* computed_cells, double* device_bytes, double* boundary_bytes);

@@ -2191,7 +2191,7 @@ static pa_batch* batch_create(const uint8_t* const* a, const size_t* a_len, cons
                         std::memcpy(dst + (pc.lo - base), src[pc.q] + (pc.lo - off[pc.q]), pc.hi - pc.lo);
                     }
                 };
-                const size_t nthreads = (end - base >= (size_t(8) << 20) && pieces.size() >= 8) ? 4 : 1;
+                const size_t nthreads = (end - base >= (size_t(8) << 20) && pieces.size() >= 8) ? std::min<size_t>(4, host_threads()) : 1;
                 if (nthreads > 1) {
                     std::vector<std::thread> th;
                     for (size_t t = 1; t < nthreads; ++t) th.emplace_back(gather, pieces.size() * t / nthreads, pieces.size() * (t + 1) / nthreads);

@@ -152,7 +152,12 @@ def _sharded(pairs, compute, group, with_cigar, all_ranks, work, min_chunk):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if work is None:
         work = [work_estimate(len(a), len(b)) for a, b in pairs]
+    import time as _time
+
+    t_call = _time.perf_counter()
+    tim = {"plan_s": 0.0, "queue_s": 0.0, "compute_s": 0.0, "gather_s": 0.0, "unpack_s": 0.0, "chunks": 0, "pairs": 0}
     chunks = plan_chunks(work, world, min_chunk=min_chunk)  # the same queue on every rank
+    tim["plan_s"] = _time.perf_counter() - t_call
     store = _queue_store(dist, group)
     # ---- pull chunks until the queue is empty ----
     mine: list[int] = []      # pair indices in the order computed
@@ -172,21 +177,29 @@ def _sharded(pairs, compute, group, with_cigar, all_ranks, work, min_chunk):
         dist.broadcast(qid, src=src, group=group)
         key = f"pa_work_queue_{int(qid.item())}"
         while True:
+            tq = _time.perf_counter()
             c = int(store.add(key, 1)) - 1
+            tim["queue_s"] += _time.perf_counter() - tq
             if c >= len(chunks):
                 break
             taken.append(c)
+            tc = _time.perf_counter()
             res = list(compute([pairs[i] for i in chunks[c]]))
+            tim["compute_s"] += _time.perf_counter() - tc
             mine.extend(chunks[c])
             local.extend(res)
     else:
         static = plan_shards([sum(work[i] for i in ch) for ch in chunks], world)[rank]
         for c in static:
             taken.append(c)
+            tc = _time.perf_counter()
             res = list(compute([pairs[i] for i in chunks[c]]))
+            tim["compute_s"] += _time.perf_counter() - tc
             mine.extend(chunks[c])
             local.extend(res)
     sharded_last_chunks[:] = taken  # (tests / reporting: which chunks this rank took)
+    tim["chunks"], tim["pairs"] = len(taken), len(mine)
+    t_gather = _time.perf_counter()
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     # ---- (1) how much every rank has: [pairs, text bytes] per rank, one tiny all_gather ----
     texts = [str(x[1]).encode() for x in local] if with_cigar else []
@@ -234,8 +247,13 @@ def _sharded(pairs, compute, group, with_cigar, all_ranks, work, min_chunk):
             store.delete_key(key)
         except Exception:
             pass
+    tim["gather_s"] = _time.perf_counter() - t_gather
+    tim["total_s"] = _time.perf_counter() - t_call
+    sharded_last_timing.clear()
+    sharded_last_timing.update(tim)
     if not i_collect:
         return None
+    t_unpack = _time.perf_counter()
     heads = heads.cpu().view(world, cap, 3).numpy()
     n = len(pairs)
     costs = [0] * n
@@ -255,7 +273,12 @@ def _sharded(pairs, compute, group, with_cigar, all_ranks, work, min_chunk):
             seen += 1
     if seen != n:
         raise RuntimeError(f"sharded run returned {seen} results for {n} pairs")
+    sharded_last_timing["unpack_s"] = _time.perf_counter() - t_unpack
+    sharded_last_timing["total_s"] = _time.perf_counter() - t_call
     return out if with_cigar else costs
 
 
 sharded_last_chunks: list[int] = []
+# Where the last sharded call of THIS rank went (seconds): planning the queue, waiting for the queue's counter (one round trip to the process
+# group's store per chunk), inside `compute` (the GPU's share), the result gather, unpacking on the collecting rank; chunks and pairs taken.
+sharded_last_timing: dict = {}

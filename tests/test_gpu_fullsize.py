@@ -221,7 +221,7 @@ def test_bench_two_rank_code_path_dry_run(tmp_path):
     env = dict(os.environ, PA_BENCH_DRY_MULTI="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29617", str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "8",
-           "--seq-len", "20000", "--no-cpu-baseline", "--no-single-pair", "--no-c4", "--no-banded", "--c4-pairs", "300"]
+           "--seq-len", "20000", "--no-cpu-baseline", "--no-single-pair", "--no-c4", "--no-banded", "--c4-pairs", "300", "--c4-strong-pairs", "900"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -232,3 +232,13 @@ def test_bench_two_rank_code_path_dry_run(tmp_path):
     # the C4 strong-scaling leg: both ranks aligned their shard with traceback and every rank got all results
     assert j["c4_sharded"]["n_gpus"] == 2 and j["c4_sharded"]["scaling"] == "strong" and j["c4_sharded"]["pairs_per_sec"] > 0
     assert j["c4_sharded"]["cost_checksum"] > 0 and j["c4_sharded"]["cigar_bytes"] > 300
+    # round 6: the strong leg repeats the C4 pairs up to --c4-strong-pairs (the same work for every N), reports where every rank's time went,
+    # caps the host threads per rank at the node's share, and a WEAK leg (own pairs per rank) stands next to it
+    cs = j["c4_sharded"]
+    assert cs["pairs"] == 900 and cs["ms_repetitions"]["reps"] == 3 and cs["host_threads_per_rank"] >= 1
+    assert len(cs["rank_busy_s"]) == 2 and len(cs["rank_timing_s"]) == 2
+    for t in cs["rank_timing_s"]:
+        assert {"plan_s", "queue_s", "compute_s", "gather_s", "chunks", "pairs", "total_s"} <= set(t)
+    assert sum(t["pairs"] for t in cs["rank_timing_s"]) == 900
+    assert cs["weak"]["scaling"] == "weak" and cs["weak"]["n_gpus"] == 2 and cs["weak"]["pairs_per_sec"] > 0 and cs["weak"]["ms_repetitions"]["reps"] == 3
+    assert cs["astarpa2_simple"]["pairs"] == 900

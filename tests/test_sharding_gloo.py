@@ -36,6 +36,11 @@ def _worker(rank, world, port, q):
         return [oracle.levenshtein(a, b) for a, b in sub]
 
     out = sharded_costs(pairs, compute=compute, min_chunk=3)  # a queue of nine chunks, pulled by whoever is free
+    from astar_pairwise_aligner_amd import sharding as _sh
+
+    tim = dict(_sh.sharded_last_timing)  # round 6: where this rank's call went (bench.py prints it per rank)
+    ok_tim = ({"plan_s", "queue_s", "compute_s", "gather_s", "total_s", "chunks", "pairs"} <= set(tim) and tim["pairs"] == sum(calls)
+              and tim["chunks"] == len(calls) and tim["total_s"] >= tim["compute_s"] >= 0.0)
     want = [oracle.levenshtein(a, b) for a, b in pairs]
     # gathered to rank 0 only: the other rank gets None
     out0 = sharded_costs(pairs, compute=lambda sub: [oracle.levenshtein(a, b) for a, b in sub], all_ranks=False, min_chunk=5)
@@ -49,7 +54,7 @@ def _worker(rank, world, port, q):
     ok_al = all(c == w and oracle.cigar_verify(g, a, b) == c for (c, g), w, (a, b) in zip(al, want, pairs))
     al0 = sharded_align(pairs[:9], compute=lambda sub: [oracle.cpu_align(a, b, prm)[:2] for a, b in sub], min_chunk=2, all_ranks=False)
     ok_al0 = (al0 == al) if rank == 0 else (al0 is None)
-    q.put((rank, out == want and ok_al and ok_root and ok_al0, calls))
+    q.put((rank, out == want and ok_al and ok_root and ok_al0 and ok_tim, calls))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -146,15 +146,34 @@ def _sharded(pairs, compute, group, with_cigar, all_ranks, work, min_chunk):
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()):
-        local = compute(list(pairs))
-        return [(int(c), str(g)) for c, g in local] if with_cigar else [int(c) for c in local]
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if work is None:
-        work = [work_estimate(len(a), len(b)) for a, b in pairs]
     import time as _time
 
     t_call = _time.perf_counter()
+    if not (dist.is_available() and dist.is_initialized()):
+        # One process, one GPU: the same queue of chunks, taken in order.  A batch's device buffers grow with its pairs (the traceback
+        # keeps 0.6 MB of re-fill scratch per 10 kbp pair: 100 000 pairs at once are 85 GB of hipMalloc, seconds of it), so a long list
+        # goes through the GPU in the chunks a rank of a larger job would take.
+        if work is None:
+            work = [work_estimate(len(a), len(b)) for a, b in pairs]
+        chunks = plan_chunks(work, 1, min_chunk=min_chunk)
+        tim = {"plan_s": _time.perf_counter() - t_call, "queue_s": 0.0, "compute_s": 0.0, "gather_s": 0.0, "unpack_s": 0.0,
+               "chunks": len(chunks), "pairs": len(pairs)}
+        n = len(pairs)
+        res_all: list = [None] * n
+        for ch in chunks:
+            tc = _time.perf_counter()
+            res = list(compute([pairs[i] for i in ch]))
+            tim["compute_s"] += _time.perf_counter() - tc
+            for i, x in zip(ch, res):
+                res_all[i] = (int(x[0]), str(x[1])) if with_cigar else int(x)
+        sharded_last_chunks[:] = list(range(len(chunks)))
+        tim["total_s"] = _time.perf_counter() - t_call
+        sharded_last_timing.clear()
+        sharded_last_timing.update(tim)
+        return res_all
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if work is None:
+        work = [work_estimate(len(a), len(b)) for a, b in pairs]
     tim = {"plan_s": 0.0, "queue_s": 0.0, "compute_s": 0.0, "gather_s": 0.0, "unpack_s": 0.0, "chunks": 0, "pairs": 0}
     chunks = plan_chunks(work, world, min_chunk=min_chunk)  # the same queue on every rank
     tim["plan_s"] = _time.perf_counter() - t_call

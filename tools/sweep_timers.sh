@@ -11,8 +11,9 @@ LIB=$R/astar-pairwise-aligner_amd/libastarpa_c_hip_timers.so
 case "${1:-build}" in
   build)
     C=$R/astar-pairwise-aligner_amd/csrc
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DPA_SWEEP_PHASE_TIMERS -I $R/include -o $LIB \
-        $C/pa_hip.hip $C/engine_hip.hip $C/astarpa_c.hip $C/pairs_io.hip
+    B=$R/astar-pairwise-aligner_amd/build   # the product build's objects (python -c "import __graft_entry__ as g; g.build()" first)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DPA_SWEEP_PHASE_TIMERS -I $R/include -c $C/engine_hip.hip -o $B/engine_hip_timers.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $LIB $B/engine_hip_timers.o $(ls $B/*.o | grep -v "engine_hip")
     ls -la $LIB ;;
   run)
     [ -f $LIB ] || { echo "build it first (tools/sweep_timers.sh build)"; exit 2; }

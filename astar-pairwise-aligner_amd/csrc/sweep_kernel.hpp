@@ -175,84 +175,81 @@ struct DeviceWave {
         asm volatile("" : "+v"(k40), "+v"(k80));
         myers_k<FORCE>(s_x, X, vp, vm, nb0, nb1, acc, andm, orm, k40, k80);
     }
+    // The 32 steps of a CROSSING chunk are rolled loops (PA_SWEEP_UNROLL steps per trip) -- round 6: fully unrolled, the kernel was
+    // 16 000 instructions (110 KB), the crossing chunks alone 8 KB each, executed twice per block between 25 us of other code: a lone
+    // wavefront waits for every cold line of it (measured: 3.9 us per crossing chunk for 1 100 instructions, twice their issue time;
+    // 3.1 us rolled: profiles/r06_runs/sweep_timers.log).
+#ifndef PA_SWEEP_UNROLL
+#define PA_SWEEP_UNROLL 4
+#endif
+#define PA_PRAGMA_(x) _Pragma(#x)
+#define PA_UNROLL_N(n) PA_PRAGMA_(unroll n)
     template <bool FORCE>
     static __device__ __forceinline__ void chunk(vec XS, vec& X, vec& vp, vec& vm, vec nb0, vec nb1, vec& acc_lo, vec& acc_hi, vec andm, vec orm) {
         uint32_t k40 = 0x40000000u, k80 = 0x80000000u;  // kept in VGPRs and opaque (see strip_kernel.hpp)
         asm volatile("" : "+v"(k40), "+v"(k80));
+        // (the plain chunk stays unrolled: six of them run back to back per block, the code is hot, and a loop costs it 20 %)
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const uint32_t s_x = (uint32_t)__builtin_amdgcn_readlane((int)XS, j);
-            myers_k<FORCE>(s_x, X, vp, vm, nb0, nb1, j < 16 ? acc_lo : acc_hi, andm, orm, k40, k80);
-        }
+        for (int j = 0; j < 16; ++j) myers_k<FORCE>((uint32_t)__builtin_amdgcn_readlane((int)XS, j), X, vp, vm, nb0, nb1, acc_lo, andm, orm, k40, k80);
+#pragma unroll
+        for (int j = 16; j < 32; ++j) myers_k<FORCE>((uint32_t)__builtin_amdgcn_readlane((int)XS, j), X, vp, vm, nb0, nb1, acc_hi, andm, orm, k40, k80);
     }
     static __device__ __forceinline__ bool any(vec x) { return __builtin_amdgcn_ballot_w64(x != 0) != 0; }
 
     // A chunk in which lane cl0 + j leaves its block at step j: snapshot of its V (the block's column); EXTRA: a lane that may
     // hold the next block's first row starts forcing +1 (fpend), a lane that was below the band restarts from V::one()
-    // (resetm; blocks.rs:753-767).  All predicates are per-lane compares against the step number (VALU only: a scalar AND of
-    // two lane masks between a v_cmp and a v_cndmask stalls a lone wavefront), 3 resp. 9 more VALU per step than `chunk`.
+    // (resetm; blocks.rs:753-767).  3 resp. 9 more VALU per step than `chunk`.
+    template <bool FORCE, bool EXTRA>
+    static __device__ __forceinline__ void cross_step(int j, vec XS, vec& X, vec& vp, vec& vm, vec nb0, vec nb1, vec& acc, vec& andm, vec& orm, uint32_t rel,
+                                                       uint32_t relr, uint32_t relf, vec& snap_p, vec& snap_m, uint32_t k40, uint32_t k80) {
+        // rel / relr / relf are ONE-HOT step masks (bit j set: the lane's event is due in step j): a predicate is one v_bfe_i32 (0 / ~0)
+        // and the selects are v_bitop3 -- VALU to VALU, no scalar mask in between (same time as v_cmp + v_cndmask; fewer scalar registers).
+        const uint32_t me = (uint32_t)__builtin_amdgcn_sbfe((int)rel, j, 1);
+        snap_p = __builtin_amdgcn_bitop3_b32(me, vp, snap_p, 0xCA);  // me ? vp : snap_p
+        snap_m = __builtin_amdgcn_bitop3_b32(me, vm, snap_m, 0xCA);
+        if (EXTRA) {
+            if (FORCE) {
+                const uint32_t mf = (uint32_t)__builtin_amdgcn_sbfe((int)relf, j, 1);
+                andm = __builtin_amdgcn_bitop3_b32(mf, 3u, andm, 0xCA);
+                orm = __builtin_amdgcn_bitop3_b32(mf, k80, orm, 0xCA);
+            }
+            const uint32_t mr = (uint32_t)__builtin_amdgcn_sbfe((int)relr, j, 1);
+            vp |= mr;
+            vm &= ~mr;
+        }
+        myers_k<FORCE>((uint32_t)__builtin_amdgcn_readlane((int)XS, j), X, vp, vm, nb0, nb1, acc, andm, orm, k40, k80);
+    }
     template <bool FORCE, bool EXTRA>
     static __device__ __forceinline__ void chunk_cross(vec XS, vec& X, vec& vp, vec& vm, vec nb0, vec nb1, vec& acc_lo, vec& acc_hi, vec& andm, vec& orm,
                                                         vec lane, int32_t cl0, vec& snap_p, vec& snap_m, vec resetm, vec fpend) {
         uint32_t k40 = 0x40000000u, k80 = 0x80000000u;
         asm volatile("" : "+v"(k40), "+v"(k80));
-        const uint32_t rel = lane - (uint32_t)cl0;               // == j at the lane's crossing step
-        const uint32_t relr = resetm != 0 ? rel : 0xFFFFFFFFu;   // never matches for lanes that do not reset
-        const uint32_t relf = fpend != 0 ? rel : 0xFFFFFFFFu;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const bool me = rel == (uint32_t)j;
-            snap_p = me ? vp : snap_p;
-            snap_m = me ? vm : snap_m;
-            if (EXTRA) {
-                if (FORCE) {
-                    const bool mf = relf == (uint32_t)j;
-                    andm = mf ? 3u : andm;
-                    orm = mf ? 0x80000000u : orm;
-                }
-                const bool mr = relr == (uint32_t)j;
-                vp = mr ? 0xFFFFFFFFu : vp;
-                vm = mr ? 0u : vm;
-            }
-            myers_k<FORCE>((uint32_t)__builtin_amdgcn_readlane((int)XS, j), X, vp, vm, nb0, nb1, j < 16 ? acc_lo : acc_hi, andm, orm, k40, k80);
-        }
+        const uint32_t d = lane - (uint32_t)cl0;                 // == j at the lane's crossing step
+        const uint32_t rel = d < 32u ? 1u << d : 0u;             // one-hot over the chunk's steps
+        const uint32_t relr = resetm != 0 ? rel : 0u;            // never set for lanes that do not reset
+        const uint32_t relf = fpend != 0 ? rel : 0u;
+        PA_UNROLL_N(PA_SWEEP_UNROLL)
+        for (int j = 0; j < 16; ++j) cross_step<FORCE, EXTRA>(j, XS, X, vp, vm, nb0, nb1, acc_lo, andm, orm, rel, relr, relf, snap_p, snap_m, k40, k80);
+        PA_UNROLL_N(PA_SWEEP_UNROLL)
+        for (int j = 16; j < 32; ++j) cross_step<FORCE, EXTRA>(j, XS, X, vp, vm, nb0, nb1, acc_hi, andm, orm, rel, relr, relf, snap_p, snap_m, k40, k80);
     }
     // Steps [j0, j1) of such a chunk in the strip that runs the top-down scan (the scan interrupts the chunk where the scanned
-    // row's lane crosses): one unrolled copy of the 32 steps entered and left through a switch.
+    // row's lane crosses): the same step, one at a time.
     static __device__ __forceinline__ void chunk_cross_range(vec XS, vec& X, vec& vp, vec& vm, vec nb0, vec nb1, vec& acc_lo, vec& acc_hi, vec& andm,
                                                               vec& orm, vec lane, int32_t cl0, vec& snap_p, vec& snap_m, vec resetm, vec fpend, int32_t j0,
                                                               int32_t j1) {
         uint32_t k40 = 0x40000000u, k80 = 0x80000000u;
         asm volatile("" : "+v"(k40), "+v"(k80));
-        uint32_t rel = lane - (uint32_t)cl0;
-        uint32_t relr = resetm != 0 ? rel : 0xFFFFFFFFu;
-        uint32_t relf = fpend != 0 ? rel : 0xFFFFFFFFu;
-        // opaque: else the 96 lane compares below are hoisted out of the caller's loop as loop invariants -- 192 scalar registers
-        // of masks, spilled lane by lane at every entry
-        asm volatile("" : "+v"(rel), "+v"(relr), "+v"(relf));
-#define PA_XSTEP(J)                                                                                                  \
-    case J: {                                                                                                        \
-        if (J >= j1) break;                                                                                          \
-        const bool me = rel == (uint32_t)(J);                                                                        \
-        snap_p = me ? vp : snap_p;                                                                                   \
-        snap_m = me ? vm : snap_m;                                                                                   \
-        const bool mf = relf == (uint32_t)(J);                                                                       \
-        andm = mf ? 3u : andm;                                                                                       \
-        orm = mf ? 0x80000000u : orm;                                                                                \
-        const bool mr = relr == (uint32_t)(J);                                                                       \
-        vp = mr ? 0xFFFFFFFFu : vp;                                                                                  \
-        vm = mr ? 0u : vm;                                                                                           \
-        myers_k<true>((uint32_t)__builtin_amdgcn_readlane((int)XS, J), X, vp, vm, nb0, nb1, (J) < 16 ? acc_lo : acc_hi, andm, orm, k40, k80); \
-    }                                                                                                                \
-        [[fallthrough]];
-        switch (j0) {
-            PA_XSTEP(0) PA_XSTEP(1) PA_XSTEP(2) PA_XSTEP(3) PA_XSTEP(4) PA_XSTEP(5) PA_XSTEP(6) PA_XSTEP(7)
-            PA_XSTEP(8) PA_XSTEP(9) PA_XSTEP(10) PA_XSTEP(11) PA_XSTEP(12) PA_XSTEP(13) PA_XSTEP(14) PA_XSTEP(15)
-            PA_XSTEP(16) PA_XSTEP(17) PA_XSTEP(18) PA_XSTEP(19) PA_XSTEP(20) PA_XSTEP(21) PA_XSTEP(22) PA_XSTEP(23)
-            PA_XSTEP(24) PA_XSTEP(25) PA_XSTEP(26) PA_XSTEP(27) PA_XSTEP(28) PA_XSTEP(29) PA_XSTEP(30) PA_XSTEP(31)
-            default: break;
-        }
-#undef PA_XSTEP
+        const uint32_t d = lane - (uint32_t)cl0;
+        const uint32_t rel = d < 32u ? 1u << d : 0u;
+        const uint32_t relr = resetm != 0 ? rel : 0u;
+        const uint32_t relf = fpend != 0 ? rel : 0u;
+        // (four steps per trip instead of one changed nothing: profiles/r06_runs/sweep_timers.log)
+        const int32_t mid = j1 < 16 ? j1 : 16;
+#pragma unroll 1
+        for (int j = j0; j < mid; ++j) cross_step<true, true>(j, XS, X, vp, vm, nb0, nb1, acc_lo, andm, orm, rel, relr, relf, snap_p, snap_m, k40, k80);
+#pragma unroll 1
+        for (int j = j0 > 16 ? j0 : 16; j < j1; ++j) cross_step<true, true>(j, XS, X, vp, vm, nb0, nb1, acc_hi, andm, orm, rel, relr, relf, snap_p, snap_m, k40, k80);
     }
 };
 

@@ -36,6 +36,9 @@
 namespace pa {
 namespace slice {
 
+#ifndef PA_SLICE_YIELD
+#define PA_SLICE_YIELD 2
+#endif
 constexpr int kPad = 64;          // entries in front of column 0 and behind the last column of the per-column arrays: no clamping in the loop
 constexpr int kErrSpin = 7;       // a boundary value did not arrive in time (PA_ERR_SPIN_TIMEOUT of the strip kernels)
 constexpr uint32_t kSpinLimit = 1u << 22;  // reloads of one boundary value (a reload is a round trip to the L2 or further: seconds in total)
@@ -66,6 +69,7 @@ struct SlicePair {  // per position of the sorted order
     uint32_t pad_;
 };
 
+typedef uint32_t pa_slice_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t dpp_wave_shr1(uint32_t old_, uint32_t src) {
     // v_mov_b32_dpp wave_shr:1 ; lane 0 has no source lane and keeps `old_`
     return (uint32_t)__builtin_amdgcn_update_dpp((int)old_, (int)src, 0x138, 0xf, 0xf, false);
@@ -117,9 +121,10 @@ __device__ __forceinline__ void st_boundary(uint2* p, uint32_t hp, uint32_t hm) 
 template <int R>
 __global__ __launch_bounds__(64, 2) void slice_kernel(const SliceJob* __restrict__ jobs, int njobs, const SliceGroup* __restrict__ groups,
                                                       const SliceEvent* __restrict__ events, const uint2* __restrict__ A, const uint2* __restrict__ B,
-                                                      uint2* H, uint2* V, uint32_t* ticket_err) {
+                                                      uint2* H, uint2* V, uint32_t* ticket_err, unsigned long long* dbg) {
     static_assert(R % 2 == 0, "rows are stepped in pairs");
     const int lane = (int)threadIdx.x;
+    const uint32_t wave_slot = (uint32_t)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 4) & 15u;  // HW_REG_HW_ID[3:0]: this wavefront's slot on its SIMD
     for (;;) {
         uint32_t tk = 0;
         if (lane == 0) tk = atomicAdd(ticket_err, 1u);
@@ -127,6 +132,11 @@ __global__ __launch_bounds__(64, 2) void slice_kernel(const SliceJob* __restrict
         if (tk >= (uint32_t)njobs) break;
         const SliceJob job = jobs[tk];
         const SliceGroup grp = groups[job.group];
+        // diagnostics (PA_SLICE_JOBTIMES; dbg is null otherwise): ticks of 10 ns of this job, and of them asleep waiting for the strip above
+        const unsigned long long t_job0 = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        unsigned long long t_parked = 0, n_parks = 0;
+        [[maybe_unused]] bool waited_before = false;
+        [[maybe_unused]] int slack = 0;
         const int s = (int)job.strip, n = grp.n;
         const bool has_in = s > 0, has_out = s + 1 < grp.nstrips;
         const uint2* Ag = A + grp.a_off + kPad;
@@ -147,21 +157,46 @@ __global__ __launch_bounds__(64, 2) void slice_kernel(const SliceJob* __restrict
         // each per chunk, issued a whole chunk ahead); the chunk registers ROTATE one lane per step (DPP wave_rol:1), so that at step j lane 0 finds column 64 q + j in its own lane,
         // and everything -- the column's two code planes AND the row's (hp, hm) -- then moves down the lanes one lane per step through DPP
         // wave_shr:1.  No vector memory load sits in the step loop, so no wait does either.
+        //
+        // The wait for the prefetched chunk (round 6).  Loads and stores of a wavefront retire in order through ONE counter (vmcnt), and the
+        // compiler's wait for the next chunk's registers -- placed at their first use, the top of the next chunk -- was vmcnt(0): behind the
+        // write-through boundary store of the step just before, i.e. one round trip to memory per chunk with the wavefront parked
+        // (SQ_WAIT_ANY 18.6 % of the wave cycles with chained strips against 9.0 % without: tools/slice_wait_probe.py).  So the prefetch
+        // loads are issued from inline asm (the compiler keeps no score for them) and waited for by hand kWaitStep steps later with
+        // vmcnt(kWaitStep): by then exactly kWaitStep younger boundary stores have been issued -- one per step, from every strip that has a
+        // strip below, by ALL lanes through a raw buffer store whose offset is out of range except in lane 63 (so the instruction is
+        // issued whenever any lane is at a column, which is every step of the loop) -- and "at most kWaitStep operations outstanding" means
+        // "everything older than those stores has retired": the loads, and the stores of the chunk before, issued microseconds ago.
+        constexpr int kWaitStep = 8;
         uint32_t o_hp = 0, o_hm = 0, o_a0 = 0, o_a1 = 0;
         uint32_t ev_i = 0;
         int ev_col = ev[0].col;
         const int nchunks = (n + 63 + 63) / 64;  // steps 0 .. n + 62
-        uint2 nA = Ag[lane], nH = make_uint2(~0u, 0u);
-        if (has_in) nH = ld_boundary(Hin + lane);
-        __builtin_amdgcn_s_waitcnt(0);  // nothing in flight when the loops start (a wait the compiler derives from these loads would sit inside them)
+        const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)Hout, 0, (int)((uint32_t)n * 8u), 0x00020000);
+        unsigned long long nA = 0, nH = ~0ull;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(nA) : "v"(Ag + lane) : "memory");
+        if (has_in) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(nH) : "v"(Hin + lane) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(nA), "+v"(nH)::"memory");  // nothing in flight when the loops start ...
+        __builtin_amdgcn_s_waitcnt(0);  // ... and the compiler knows it (a wait it derives from the row loads above would sit inside the loops)
+        uint2 kA = make_uint2((uint32_t)nA, (uint32_t)(nA >> 32));
+        uint2 kH = has_in ? make_uint2((uint32_t)nH, (uint32_t)(nH >> 32)) : make_uint2(~0u, 0u);
         for (int q = 0; q < nchunks; ++q) {
-            uint2 cA = nA, cH = nH;
+            // Fair shares of the SIMD.  With equal priority the OLDER of a SIMD's two wavefronts wins every arbitration (MI355X_MICROARCH.md:
+            // priority, then age): equal jobs took 83 ms on one and 96 ms on the other wavefront of a SIMD (PA_SLICE_JOBTIMES), a chain of
+            // strips runs at the pace of its slowest member and the fast members sleep at the chunk tops while their SIMD runs half empty.
+            // So the two take turns: priority 1 in every other chunk, the wavefront in the odd slot of the SIMD starting with the odd chunks
+            // (equal jobs: 87 .. 92 ms; the bench batch 408 -> 392 ms.  Turns of 8 / 16 / 32 steps, a third wavefront per SIMD with three-way
+            // turns, priority by slack: profiles/r06_runs/slice_variants.log).
+            if (((uint32_t)q ^ wave_slot) & 1u) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+            uint2 cA = kA, cH = kH;
             const int col = q * 64 + lane;  // the column this lane holds for lane 0
             if (has_in) {
                 // The strip above has to be past this chunk.  It normally is (it started first and runs at the same pace); when this strip has
                 // caught up, waiting here until all 64 columns are there lets it run them at full speed.  (Letting the strip above get three
                 // chunks ahead once a chunk was found missing changed nothing: profiles/r06_runs/slice_variants.log.)
                 uint32_t spins = 0;
+                const unsigned long long t_p0 = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
                 while (col < n && (cH.x & cH.y) != 0u) {
                     __builtin_amdgcn_s_sleep(32);
                     cH = ld_boundary(Hin + col);
@@ -170,14 +205,35 @@ __global__ __launch_bounds__(64, 2) void slice_kernel(const SliceJob* __restrict
                         cH = make_uint2(~0u, 0u);
                     }
                 }
+                const bool waited = __builtin_amdgcn_readfirstlane((int)(__ballot(spins != 0u) != 0ull)) != 0;
+#if PA_SLICE_YIELD == 1
+                if (waited) __builtin_amdgcn_s_setprio(0);  // slack: whatever the turn, the neighbour goes first in this chunk
+#elif PA_SLICE_YIELD == 2
+                if (waited || waited_before) __builtin_amdgcn_s_setprio(0);
+                waited_before = waited;
+#elif PA_SLICE_YIELD >= 3
+                // yield in the chunk of a wait and the PA_SLICE_YIELD - 1 chunks after it
+                slack = waited ? PA_SLICE_YIELD : (slack > 0 ? slack - 1 : 0);
+                if (slack > 0) __builtin_amdgcn_s_setprio(0);
+#endif
+                if (dbg && waited) {
+                    t_parked += __builtin_amdgcn_s_memrealtime() - t_p0;
+                    n_parks += 1;
+                }
             }
             // the next chunk's values, a whole chunk ahead of their use (issued after the test above: a wait for THIS chunk's values must not
             // cover loads that have only just been issued)
             const int pcol = min(col + 64, n + kPad - 1);  // (behind the last column: the pad, never used)
-            nA = Ag[pcol];
-            if (has_in) nH = ld_boundary(Hin + pcol);
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(nA) : "v"(Ag + pcol) : "memory");
+            if (has_in) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(nH) : "v"(Hin + pcol) : "memory");
             const int jend = min(64, n + 63 - q * 64);
             for (int j = 0; j < jend; ++j) {
+                if (j == kWaitStep) {  // (uniform)
+                    if (has_out) asm volatile("s_waitcnt vmcnt(8)" : "+v"(nA), "+v"(nH)::"memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(nA), "+v"(nH)::"memory");
+                    kA = make_uint2((uint32_t)nA, (uint32_t)(nA >> 32));
+                    if (has_in) kH = make_uint2((uint32_t)nH, (uint32_t)(nH >> 32));
+                }
                 const int c = q * 64 + j - lane;
                 // lane 0 takes the chunk registers' value of ITS lane -- they rotate one lane per step, so that is column 64 q + j --, every other
                 // lane the value the lane above it had a step ago
@@ -199,7 +255,10 @@ __global__ __launch_bounds__(64, 2) void slice_kernel(const SliceJob* __restrict
                     }
                     o_hp = hpp;
                     o_hm = hmp;
-                    if (lane == 63 && has_out) st_boundary(Hout + c, hpp, hmp);
+                    if (has_out) {  // (uniform) lane 63's (hp, hm) of column c: 8 bytes, write-through; the other lanes' offsets are out of range
+                        const pa_slice_u32x2 d = {hpp, hmp};
+                        __builtin_amdgcn_raw_buffer_store_b64(d, hrs, lane == 63 ? (uint32_t)c * 8u : 0x7FFFFFF0u, 0, 16);  // aux 16 = sc1
+                    }
                     if (c + 1 == ev_col) {  // some pairs' a ends here: keep their bits of this lane's rows (the last event is the last column)
                         const uint32_t mask = ev[ev_i].mask;
                         // V is zeroed before every pass; a pair is captured once, so OR-ing its bit in is exact.  One row at a time (the
@@ -216,6 +275,27 @@ __global__ __launch_bounds__(64, 2) void slice_kernel(const SliceJob* __restrict
                     }
                 }
             }
+            if (jend <= kWaitStep) {  // (the last chunk of the strip: nothing follows)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(nA), "+v"(nH)::"memory");
+                kA = make_uint2((uint32_t)nA, (uint32_t)(nA >> 32));
+                if (has_in) kH = make_uint2((uint32_t)nH, (uint32_t)(nH >> 32));
+            }
+        }
+        if (dbg && lane == 0) {
+            const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_job0;
+            atomicMin(dbg + 0, dt);
+            atomicMax(dbg + 1, dt);
+            atomicAdd(dbg + 2, dt);
+            atomicAdd(dbg + 3, 1ull);
+            atomicAdd(dbg + 4, t_parked);
+            atomicAdd(dbg + 5, n_parks);
+            if (s == 0) {
+                atomicMin(dbg + 6, dt);
+                atomicMax(dbg + 7, dt);
+            }
+            const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7u;  // HW_REG_XCC_ID[3:0]: which of the eight XCDs ran the job
+            atomicAdd(dbg + 8 + 2 * xcc, dt - t_parked);  // (awake time)
+            atomicAdd(dbg + 9 + 2 * xcc, 1ull);
         }
     }
 }

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <memory>
 #include <numeric>
@@ -151,9 +152,9 @@ Plan* create(const size_t* a_len, const size_t* b_len, size_t pairs, const size_
 void destroy(Plan* p) { delete p; }
 
 template <int R>
-static hipError_t launch_slice(int grid, hipStream_t s, const Plan* p, uint32_t* d_ticket_err) {
+static hipError_t launch_slice(int grid, hipStream_t s, const Plan* p, uint32_t* d_ticket_err, unsigned long long* dbg) {
     hipLaunchKernelGGL((slice_kernel<R>), dim3((unsigned)grid), dim3(64), 0, s, p->d_jobs.as<SliceJob>(), (int)p->jobs.size(), p->d_groups.as<SliceGroup>(),
-                       p->d_events.as<SliceEvent>(), p->d_A.as<uint2>(), p->d_B.as<uint2>(), p->d_H.as<uint2>(), p->d_V.as<uint2>(), d_ticket_err);
+                       p->d_events.as<SliceEvent>(), p->d_A.as<uint2>(), p->d_B.as<uint2>(), p->d_H.as<uint2>(), p->d_V.as<uint2>(), d_ticket_err, dbg);
     return hipGetLastError();
 }
 
@@ -179,23 +180,41 @@ int run(Plan* p, hipStream_t s, const uint32_t* d_codes, const uint64_t* d_prof,
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
     }
     const int grid = (int)std::min<size_t>(p->jobs.size(), (size_t)cus * 8);  // two wavefronts per SIMD, one wavefront per workgroup
+    // diagnostics: PA_SLICE_JOBTIMES=1 prints, per pass, how long the (group, strip) jobs took their wavefronts and how much of that they slept
+    static const bool jobtimes = getenv("PA_SLICE_JOBTIMES") != nullptr;
+    unsigned long long* dbg = nullptr;
+    if (jobtimes && hipMalloc((void**)&dbg, 192) == hipSuccess) {
+        const unsigned long long init[24] = {~0ull, 0, 0, 0, 0, 0, ~0ull, 0};
+        if (hipMemcpyAsync(dbg, init, 192, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) dbg = nullptr;
+    }
     if (ev0 && !hip_ok(hipEventRecord(ev0, s), "event")) return PA_E_HIP;
     hipError_t e = hipSuccess;
     switch (p->R) {
-        case 52: e = launch_slice<52>(grid, s, p, d_ticket_err); break;
-        case 50: e = launch_slice<50>(grid, s, p, d_ticket_err); break;
-        case 48: e = launch_slice<48>(grid, s, p, d_ticket_err); break;
-        case 46: e = launch_slice<46>(grid, s, p, d_ticket_err); break;
-        case 44: e = launch_slice<44>(grid, s, p, d_ticket_err); break;
-        case 42: e = launch_slice<42>(grid, s, p, d_ticket_err); break;
-        case 40: e = launch_slice<40>(grid, s, p, d_ticket_err); break;
-        case 36: e = launch_slice<36>(grid, s, p, d_ticket_err); break;
-        case 32: e = launch_slice<32>(grid, s, p, d_ticket_err); break;
-        case 28: e = launch_slice<28>(grid, s, p, d_ticket_err); break;
+        case 52: e = launch_slice<52>(grid, s, p, d_ticket_err, dbg); break;
+        case 50: e = launch_slice<50>(grid, s, p, d_ticket_err, dbg); break;
+        case 48: e = launch_slice<48>(grid, s, p, d_ticket_err, dbg); break;
+        case 46: e = launch_slice<46>(grid, s, p, d_ticket_err, dbg); break;
+        case 44: e = launch_slice<44>(grid, s, p, d_ticket_err, dbg); break;
+        case 42: e = launch_slice<42>(grid, s, p, d_ticket_err, dbg); break;
+        case 40: e = launch_slice<40>(grid, s, p, d_ticket_err, dbg); break;
+        case 36: e = launch_slice<36>(grid, s, p, d_ticket_err, dbg); break;
+        case 32: e = launch_slice<32>(grid, s, p, d_ticket_err, dbg); break;
+        case 28: e = launch_slice<28>(grid, s, p, d_ticket_err, dbg); break;
         default: set_error("slice: no kernel for %d rows per lane", p->R); return PA_E_INTERNAL;
     }
     if (!hip_ok(e, "slice_kernel")) return PA_E_HIP;
     if (ev1 && !hip_ok(hipEventRecord(ev1, s), "event")) return PA_E_HIP;
+    if (dbg) {
+        unsigned long long h[24] = {0};
+        if (hipMemcpyAsync(h, dbg, 192, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess && h[3]) {
+            std::fprintf(stderr, "[slice jobs] awake us per job by XCD:");
+            for (int x = 0; x < 8; ++x) std::fprintf(stderr, " %d: %.0f (%llu)", x, h[9 + 2 * x] ? h[8 + 2 * x] * 0.01 / (double)h[9 + 2 * x] : 0.0, h[9 + 2 * x]);
+            std::fprintf(stderr, "\n");
+            std::fprintf(stderr, "[slice jobs] R %d: %llu jobs, us per job: min %.1f mean %.1f max %.1f (first strips: min %.1f max %.1f); asleep behind the strip above: %.2f %% of the job time, %.1f waits per job\n",
+                         p->R, h[3], h[0] * 0.01, h[2] * 0.01 / (double)h[3], h[1] * 0.01, h[6] * 0.01, h[7] * 0.01, 100.0 * (double)h[4] / (double)h[2], (double)h[5] / (double)h[3]);
+        }
+        (void)hipFree(dbg);
+    }
     hipLaunchKernelGGL(slice_score_kernel, dim3(G, getenv("PA_SCORE_ONE") ? 1u : (p->max_row_blocks * 256u + kScoreSpan - 1) / kScoreSpan), dim3(64), 0, s, p->d_groups.as<SliceGroup>(), p->d_spairs.as<SlicePair>(), p->d_V.as<uint2>(), d_costs);
     if (!hip_ok(hipGetLastError(), "slice_score_kernel")) return PA_E_HIP;
     return 0;

@@ -28,8 +28,11 @@ struct Plan {
 
 static int strips_for(size_t m, int R) { return (int)((m + (size_t)64 * R - 1) / ((size_t)64 * R)); }
 
-// ns per row step (8 instructions) per wavefront at two wavefronts per SIMD, and per step outside the rows (profiles/r06_runs/slice_probe.log)
-static constexpr double kNsPerRowStep = 2 * 10.66 / 1.035, kNsStepOverhead = 2 * 10.66 * 0.035 * 56 / 1.035;
+// ns per row step (8 instructions) per wavefront at two wavefronts per SIMD, and per step outside the rows (24 instructions = three row
+// steps): the bench batch's 8192 jobs of 100 063 steps x (50 rows + 3) take their wave slots 4 x 95.2 ms (profiles/r06_runs/slice_variants.log);
+// kChainPenalty: what a strip loses per strip of its group's chain (asleep behind the strip above, filling and draining the chain) -- 36 strips
+// of 44 rows against 32 of 50 for 16 384 x 100 kbp: 789 against 760 ms where the plain count of instructions calls it a tie.
+static constexpr double kNsPerRowStep = 17.9, kNsStepOverhead = 3 * 17.9, kChainPenalty = 0.0015;
 
 int choose_rows_per_lane(const size_t* a_len, const size_t* b_len, size_t pairs, double simds, double* est_ns) {
     if (const char* e = getenv("PA_SLICE")) {
@@ -56,8 +59,8 @@ int choose_rows_per_lane(const size_t* a_len, const size_t* b_len, size_t pairs,
                 n = std::max(n, a_len[order[t]]);
                 m = std::max(m, b_len[order[t]]);
             }
-            const double per_strip = ((double)n + 63.0) * (R * kNsPerRowStep + kNsStepOverhead);
             const int S = strips_for(m, R);
+            const double per_strip = ((double)n + 63.0) * (R * kNsPerRowStep + kNsStepOverhead) * (1.0 + kChainPenalty * (S - 1));
             work += per_strip * S;
             jobs += S;
             longest = std::max(longest, per_strip + 128.0 * (S - 1) * (R * kNsPerRowStep + kNsStepOverhead));  // the chain of a group's strips

@@ -900,7 +900,9 @@ def main():
                 continue
             worse = (was - now) / was if higher else (now - was) / was
             # a leg that was repeated fires only beyond its own run-to-run spread (host-bound legs: 10-30 %); the others beyond 5 %
-            limit = max(0.05, 1.25 * noise.get(path, 0.0))
+            # (the end-to-end rates of the batched legs include the host's creation of 10 000 Python strings: 5-8 % from run to run)
+            host_bound = path.startswith(("c4_astarpa2_", "c3_batch_", "c4_batch_align.pairs", "pcie_inclusive"))
+            limit = max(0.10 if host_bound else 0.05, 1.25 * noise.get(path, 0.0))
             if worse > limit:
                 regs.append({"leg": path, "reference": was, "now": now, "worse_by_pct": round(100 * worse, 1), "limit_pct": round(100 * limit, 1)})
         out["regressions"] = regs

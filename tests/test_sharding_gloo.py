@@ -242,6 +242,31 @@ def test_queue_on_a_subgroup_without_global_rank0():
     assert sum(n for _, _, _, n in res) == 40  # the world call
 
 
+def test_single_process_takes_the_same_chunks_in_order():
+    """Without a process group the call still goes through the queue's chunks (a batch's device buffers grow with its pairs: round 6),
+    results come back in the order of the pairs, and the call reports where its time went."""
+    sys.path.insert(0, str(ROOT))
+    import oracle
+    from astar_pairwise_aligner_amd import sharding as sh
+    from tests.util_seq import gen_pair
+
+    pairs = [gen_pair(20 + 37 * (i % 11), 0.1, seed=100 + i) for i in range(50)]
+    sizes = []
+
+    def compute(sub):
+        sizes.append(len(sub))
+        return [oracle.levenshtein(a, b) for a, b in sub]
+
+    out = sh.sharded_costs(pairs, compute=compute, min_chunk=8)
+    assert out == [oracle.levenshtein(a, b) for a, b in pairs]
+    assert len(sizes) > 1 and sum(sizes) == 50 and max(sizes) <= 8 + 1
+    t = sh.sharded_last_timing
+    assert t["chunks"] == len(sizes) and t["pairs"] == 50 and t["total_s"] >= t["compute_s"] >= 0.0
+    prm = oracle.params_simple()
+    al = sh.sharded_align(pairs[:12], compute=lambda sub: [oracle.cpu_align(a, b, prm)[:2] for a, b in sub], min_chunk=5)
+    assert [c for c, _ in al] == out[:12] and all(oracle.cigar_verify(g, a, b) == c for (c, g), (a, b) in zip(al, pairs))
+
+
 def test_few_pairs_are_dealt_by_work_not_sliced():
     from astar_pairwise_aligner_amd.sharding import plan_chunks
 

@@ -161,12 +161,18 @@ __global__ __launch_bounds__(64, 2) void slice_kernel(const SliceJob* __restrict
         // The wait for the prefetched chunk (round 6).  Loads and stores of a wavefront retire in order through ONE counter (vmcnt), and the
         // compiler's wait for the next chunk's registers -- placed at their first use, the top of the next chunk -- was vmcnt(0): behind the
         // write-through boundary store of the step just before, i.e. one round trip to memory per chunk with the wavefront parked
-        // (SQ_WAIT_ANY 18.6 % of the wave cycles with chained strips against 9.0 % without: tools/slice_wait_probe.py).  So the prefetch
-        // loads are issued from inline asm (the compiler keeps no score for them) and waited for by hand kWaitStep steps later with
-        // vmcnt(kWaitStep): by then exactly kWaitStep younger boundary stores have been issued -- one per step, from every strip that has a
-        // strip below, by ALL lanes through a raw buffer store whose offset is out of range except in lane 63 (so the instruction is
-        // issued whenever any lane is at a column, which is every step of the loop) -- and "at most kWaitStep operations outstanding" means
+        // (tools/slice_wait_probe.py).  So the prefetch loads are issued from inline asm (the compiler keeps no score for them) and waited
+        // for by hand kWaitStep steps later with vmcnt(kWaitStep): by then exactly kWaitStep younger stores have been issued -- ONE PER STEP,
+        // by EVERY strip, by ALL lanes: a raw buffer store whose offset is out of range except in lane 63 of a strip that has a strip below
+        // (an out-of-range store is dropped by the memory pipeline but issued and counted like any other), so the instruction is issued
+        // whenever any lane is at a column, which is every step of the loop -- and "at most kWaitStep operations outstanding" then means
         // "everything older than those stores has retired": the loads, and the stores of the chunk before, issued microseconds ago.
+        // Rules that keep this sound (tests/test_slice_isa.py checks the first two in the compiled code of every instantiation):
+        //  * between the load and the wait nothing may READ the loads' destination registers -- the compiler believes they are valid from
+        //    the asm statement on; one place issues them and one place consumes them, on every path (no prefetch in a strip's last chunk:
+        //    every other chunk has all 64 steps), so there is no join that would need a copy;
+        //  * no compiler-visible wait may sit in the step loop (the row loads of the job are waited for before the loops);
+        //  * more operations in between (the capture's atomics) only make the wait stronger.
         constexpr int kWaitStep = 8;
         uint32_t o_hp = 0, o_hm = 0, o_a0 = 0, o_a1 = 0;
         uint32_t ev_i = 0;
@@ -174,12 +180,9 @@ __global__ __launch_bounds__(64, 2) void slice_kernel(const SliceJob* __restrict
         const int nchunks = (n + 63 + 63) / 64;  // steps 0 .. n + 62
         const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc((void*)Hout, 0, (int)((uint32_t)n * 8u), 0x00020000);
         unsigned long long nA = 0, nH = ~0ull;
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(nA) : "v"(Ag + lane) : "memory");
-        if (has_in) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(nH) : "v"(Hin + lane) : "memory");
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(nA), "+v"(nH)::"memory");  // nothing in flight when the loops start ...
-        __builtin_amdgcn_s_waitcnt(0);  // ... and the compiler knows it (a wait it derives from the row loads above would sit inside the loops)
-        uint2 kA = make_uint2((uint32_t)nA, (uint32_t)(nA >> 32));
-        uint2 kH = has_in ? make_uint2((uint32_t)nH, (uint32_t)(nH >> 32)) : make_uint2(~0u, 0u);
+        uint2 kA = Ag[lane], kH = make_uint2(~0u, 0u);  // chunk 0: ordinary loads
+        if (has_in) kH = ld_boundary(Hin + lane);
+        __builtin_amdgcn_s_waitcnt(0);  // nothing in flight when the loops start (a wait the compiler derives from these loads would sit inside them)
         for (int q = 0; q < nchunks; ++q) {
             // Fair shares of the SIMD.  With equal priority the OLDER of a SIMD's two wavefronts wins every arbitration (MI355X_MICROARCH.md:
             // priority, then age): equal jobs took 83 ms on one and 96 ms on the other wavefront of a SIMD (PA_SLICE_JOBTIMES), a chain of
@@ -224,13 +227,16 @@ __global__ __launch_bounds__(64, 2) void slice_kernel(const SliceJob* __restrict
             // the next chunk's values, a whole chunk ahead of their use (issued after the test above: a wait for THIS chunk's values must not
             // cover loads that have only just been issued)
             const int pcol = min(col + 64, n + kPad - 1);  // (behind the last column: the pad, never used)
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(nA) : "v"(Ag + pcol) : "memory");
-            if (has_in) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(nH) : "v"(Hin + pcol) : "memory");
+            const bool more = q + 1 < nchunks;              // (uniform) a chunk follows: this one has all 64 steps
+            if (more) {
+                asm volatile("global_load_dwordx2 %0, %1, off ; pa_prefetch_load" : "=v"(nA) : "v"(Ag + pcol) : "memory");
+                if (has_in) asm volatile("global_load_dwordx2 %0, %1, off sc1 ; pa_prefetch_load" : "=v"(nH) : "v"(Hin + pcol) : "memory");
+            }
             const int jend = min(64, n + 63 - q * 64);
+            const int wait_at = more ? kWaitStep : -1;  // (one scalar compare per step)
             for (int j = 0; j < jend; ++j) {
-                if (j == kWaitStep) {  // (uniform)
-                    if (has_out) asm volatile("s_waitcnt vmcnt(8)" : "+v"(nA), "+v"(nH)::"memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(nA), "+v"(nH)::"memory");
+                if (j == wait_at) {  // (uniform)
+                    asm volatile("s_waitcnt vmcnt(8) ; pa_prefetch_wait" : "+v"(nA), "+v"(nH)::"memory");
                     kA = make_uint2((uint32_t)nA, (uint32_t)(nA >> 32));
                     if (has_in) kH = make_uint2((uint32_t)nH, (uint32_t)(nH >> 32));
                 }
@@ -255,9 +261,9 @@ __global__ __launch_bounds__(64, 2) void slice_kernel(const SliceJob* __restrict
                     }
                     o_hp = hpp;
                     o_hm = hmp;
-                    if (has_out) {  // (uniform) lane 63's (hp, hm) of column c: 8 bytes, write-through; the other lanes' offsets are out of range
+                    {  // lane 63's (hp, hm) of column c: 8 bytes, write-through; every other offset is out of range (see the rules above)
                         const pa_slice_u32x2 d = {hpp, hmp};
-                        __builtin_amdgcn_raw_buffer_store_b64(d, hrs, lane == 63 ? (uint32_t)c * 8u : 0x7FFFFFF0u, 0, 16);  // aux 16 = sc1
+                        __builtin_amdgcn_raw_buffer_store_b64(d, hrs, (lane == 63 && has_out) ? (uint32_t)c * 8u : 0x7FFFFFF0u, 0, 16);  // aux 16 = sc1
                     }
                     if (c + 1 == ev_col) {  // some pairs' a ends here: keep their bits of this lane's rows (the last event is the last column)
                         const uint32_t mask = ev[ev_i].mask;
@@ -274,11 +280,6 @@ __global__ __launch_bounds__(64, 2) void slice_kernel(const SliceJob* __restrict
                         __builtin_amdgcn_s_waitcnt(0);  // (otherwise the compiler waits for this load at the test above, in EVERY step -- behind the store)
                     }
                 }
-            }
-            if (jend <= kWaitStep) {  // (the last chunk of the strip: nothing follows)
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(nA), "+v"(nH)::"memory");
-                kA = make_uint2((uint32_t)nA, (uint32_t)(nA >> 32));
-                if (has_in) kH = make_uint2((uint32_t)nH, (uint32_t)(nH >> 32));
             }
         }
         if (dbg && lane == 0) {

@@ -775,9 +775,9 @@ struct HipSweepLauncher {
         if (timing_on()) {
             uint64_t tm[8] = {0};
             (void)hipMemcpy(tm, sl.d_misc.as<uint64_t>() + 64, 64, hipMemcpyDeviceToHost);
-            std::fprintf(stderr, "sweep pass %u (seq %d): f_max=%d waves=%d state=%u value=%d k_end=%d  %.3f ms after its launch | strip-us: begin %.0f slow %.0f cross %.0f (probes %.0f) end %.0f bottom %.0f plain %.0f gran %.0f\n",
+            std::fprintf(stderr, "sweep pass %u (seq %d): f_max=%d waves=%d state=%u value=%d k_end=%d  %.3f ms after its launch | strip-us: begin %.0f slow %.0f cross %.0f (probes %.0f) end %.0f bottom %.0f plain %.0f gran %.0f flush %.0f\n",
                          sl.pass, seq, sl.f_max, sl.waves, st.state, st.value, st.k_end, (engine::now_s() - sl.t_launch) * 1e3, tm[0] * 0.01, tm[1] * 0.01,
-                         tm[6] * 0.01, tm[7] * 0.01, tm[2] * 0.01, tm[3] * 0.01, tm[4] * 0.01, tm[5] * 0.01);
+                         tm[6] * 0.01, tm[7] * 0.01, tm[2] * 0.01, tm[3] * 0.01, tm[4] * 0.01, (double)(tm[5] & 0xFFFFFFFFull) * 0.01, (double)(tm[5] >> 32) * 0.01);
         }
         return st;
     }

@@ -149,7 +149,7 @@ struct StripProg {
     flag_t alive;                        // false: stop (pass over, abort, timeout)
     // deferred flag publications (after the payload stores have drained)
     uint64_t st_num_blocks = 0, st_unique = 0, st_computed = 0, st_incremental = 0;  // my share of the pass's BlockStats
-    uint64_t t_cross2 = 0, t_probe = 0;
+    uint64_t t_cross2 = 0, t_probe = 0, t_flush = 0;
     uint64_t t_begin = 0, t_cross = 0, t_end = 0, t_bottom = 0, t_plain = 0, t_wait_gran = 0;  // phase clocks (W::clock ticks)
     int32_t pend_k, pend_p, pend_cont_j;  // deferred publications (see flush_deferred)
     flag_t pend_cont;
@@ -1008,7 +1008,11 @@ struct StripProg {
                     if (!okd) return;
                 }
                 if (q - q_first >= 3 && has_below) publish_granule(q - 3);  // completed two chunks ago (lane 63 lags 64 steps)
-                flush_deferred();  // (before the prefetches: its drain must not wait for loads issued just now)
+                {
+                    [[maybe_unused]] const uint64_t tf0 = PA_CLK(W);
+                    flush_deferred();  // (before the prefetches: its drain must not wait for loads issued just now)
+                    PA_CLK_ADD(t_flush, W::clock() - tf0);
+                }
                 prefetch_inputs(q + 1);
                 // the next boundary's records / the strip above's prefix word: in flight during this chunk's steps
                 if (!crossing && kc < c.nblk && t0 + 32 == blk_end(c, kc)) prefetch_boundary();
@@ -1181,7 +1185,7 @@ PA_HD void wave_main(const Ctx& c) {
             W::add_u64(c.timing + 2, prog.t_end - prog.t_bottom);
             W::add_u64(c.timing + 3, prog.t_bottom);
             W::add_u64(c.timing + 4, prog.t_plain);
-            W::add_u64(c.timing + 5, prog.t_wait_gran);
+            W::add_u64(c.timing + 5, prog.t_wait_gran + (prog.t_flush << 32));  // (diagnostics: the drain of the deferred publications rides in the upper half)
             W::add_u64(c.timing + 6, prog.t_cross2);
             W::add_u64(c.timing + 7, prog.t_probe);
         }

@@ -36,6 +36,9 @@
 namespace pa {
 namespace slice {
 
+#ifndef PA_SLICE_CLOCK_TURNS
+#define PA_SLICE_CLOCK_TURNS 15
+#endif
 #ifndef PA_SLICE_YIELD
 #define PA_SLICE_YIELD 2
 #endif
@@ -187,11 +190,18 @@ __global__ __launch_bounds__(64, 2) void slice_kernel(const SliceJob* __restrict
             // Fair shares of the SIMD.  With equal priority the OLDER of a SIMD's two wavefronts wins every arbitration (MI355X_MICROARCH.md:
             // priority, then age): equal jobs took 83 ms on one and 96 ms on the other wavefront of a SIMD (PA_SLICE_JOBTIMES), a chain of
             // strips runs at the pace of its slowest member and the fast members sleep at the chunk tops while their SIMD runs half empty.
-            // So the two take turns: priority 1 in every other chunk, the wavefront in the odd slot of the SIMD starting with the odd chunks
-            // (equal jobs: 87 .. 92 ms; the bench batch 408 -> 392 ms.  Turns of 8 / 16 / 32 steps, a third wavefront per SIMD with three-way
-            // turns, priority by slack: profiles/r06_runs/slice_variants.log).
+            // So the two take TURNS at priority 1, the wavefront in the odd slot of the SIMD (HW_REG_HW_ID) the other way round -- by a bit of the
+            // shared 100 MHz clock (2^15 ticks = 0.33 ms, five chunks), looked at once per chunk, so that the two are complementary whatever
+            // their phases (by the wavefront's own chunk count: equal jobs 87 .. 92 ms, the bench batch 408 -> 392 ms; by the clock 1.5 % more.
+            // Turns of 8 / 16 / 32 steps, other clock bits, a third wavefront per SIMD with three-way turns: profiles/r06_runs/slice_variants.log).
+#if PA_SLICE_CLOCK_TURNS
+            // (whose turn it is by the shared 100 MHz clock instead of the wavefront's own chunk count: complementary whatever the phases)
+            if ((((uint32_t)__builtin_amdgcn_s_memrealtime() >> PA_SLICE_CLOCK_TURNS) ^ wave_slot) & 1u) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+#else
             if (((uint32_t)q ^ wave_slot) & 1u) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
+#endif
             uint2 cA = kA, cH = kH;
             const int col = q * 64 + lane;  // the column this lane holds for lane 0
             if (has_in) {

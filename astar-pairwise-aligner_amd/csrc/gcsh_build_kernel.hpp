@@ -129,7 +129,11 @@ struct BuildCtx {
 
 // Local pruning of ONE candidate by ONE lane, without the matches kept before it (prepruning.rs:95-203 with an empty next_match_per_diag):
 // true = the search reaches the end of the next p seeds.  fr / nx: this lane's columns of the two LDS arrays, index (d + 1) * 64.
-__device__ __forceinline__ bool prune_alone(const BuildCtx& cx, int32_t si, int32_t sj, int32_t* fa, int32_t* fb) {
+// The furthest-reaching columns live in LDS as 16-bit offsets from the candidate's start si (a search spans p seeds: at most (p + 1) k <= 480
+// columns): half the LDS of 32-bit columns, and with it twelve instead of seven wavefronts to a CU (round 6) -- the kernel is bound by
+// what a wavefront waits for, not by what it issues.  kNeg16 = "no column yet"; a diagonal inside [d0, d1) always has one.
+constexpr int16_t kNeg16 = INT16_MIN;
+__device__ __forceinline__ bool prune_alone(const BuildCtx& cx, int32_t si, int32_t sj, int16_t* fa, int16_t* fb) {
     const GcshBuildJob& jb = cx.jb;
     const int32_t ei = si + jb.k, ej = sj + jb.k;
     const int32_t start_pot = cx.P(si);
@@ -138,44 +142,44 @@ __device__ __forceinline__ bool prune_alone(const BuildCtx& cx, int32_t si, int3
     if (last_seed > jb.nseeds - 1) last_seed = jb.nseeds - 1;
     const int32_t end_i = last_seed * jb.k + jb.k;
     const int32_t pd = start_pot - cx.P(end_i);
-    int32_t* fr = fa;
-    int32_t* nx = fb;
+    int16_t* fr = fa;
+    int16_t* nx = fb;
 #define FR(d) fr[((d) + 1) * 64]
 #define NX(d) nx[((d) + 1) * 64]
     for (int32_t d = -1; d <= 2 * pd + 1; ++d) {
-        FR(d) = kBuildNeg;
-        NX(d) = kBuildNeg;
+        FR(d) = kNeg16;
+        NX(d) = kNeg16;
     }
     int32_t d0 = pd, d1 = pd + 1;
     {
         int32_t i = ei;
         if (cx.extend(i, ej, end_i)) return true;
-        FR(pd) = i;
+        FR(pd) = (int16_t)(i - si);
     }
     for (int32_t g = 1; g < pd; ++g) {
-        FR(d0 - 1) = kBuildNeg;
-        FR(d1) = kBuildNeg;
-        NX(d0 - 1) = kBuildNeg;
-        NX(d1) = kBuildNeg;
+        FR(d0 - 1) = kNeg16;
+        FR(d1) = kNeg16;
+        NX(d0 - 1) = kNeg16;
+        NX(d1) = kNeg16;
         for (int32_t d = d0; d < d1; ++d) {
             const int32_t f = FR(d);
-            if (NX(d - 1) < f) NX(d - 1) = f;
-            if (NX(d) < f + 1) NX(d) = f + 1;
-            if (NX(d + 1) < f + 1) NX(d + 1) = f + 1;
+            if (NX(d - 1) < f) NX(d - 1) = (int16_t)f;
+            if (NX(d) < f + 1) NX(d) = (int16_t)(f + 1);
+            if (NX(d + 1) < f + 1) NX(d + 1) = (int16_t)(f + 1);
         }
-        int32_t* t = fr;
+        int16_t* t = fr;
         fr = nx;
         nx = t;
         d0 -= 1;
         d1 += 1;
-        while (d0 < d1 && g + cx.P(FR(d0)) >= start_pot) d0 += 1;
-        while (d0 < d1 && g + cx.P(FR(d1 - 1)) >= start_pot) d1 -= 1;
+        while (d0 < d1 && g + cx.P(si + FR(d0)) >= start_pot) d0 += 1;
+        while (d0 < d1 && g + cx.P(si + FR(d1 - 1)) >= start_pot) d1 -= 1;
         if (d0 >= d1) return false;
         for (int32_t d = d0; d < d1; ++d) {
-            int32_t i = FR(d);
+            int32_t i = si + FR(d);
             const int32_t dd = ei - ej + (d - pd);
             if (cx.extend(i, i - dd, end_i)) return true;
-            FR(d) = i;
+            FR(d) = (int16_t)(i - si);
         }
     }
 #undef FR
@@ -255,9 +259,17 @@ __device__ __forceinline__ bool prune_with_kept(const BuildCtx& cx, int32_t si, 
 
 #ifdef PA_UNIT_GCSH_BUILD  // (the kernel is compiled in a translation unit of its own: csrc/apa2_units.hpp)
 __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __restrict__ jobs, int npairs, uint32_t* ticket) {
-    __shared__ int32_t lds_fr[2][kBuildFr * 64];
+    // One pool, used phase by phase: the sieve of phases A / B (2048 words) lies over the search columns (2 x kBuildFr x 64 16-bit offsets)
+    // and the head of the sequence windows, which phases D / E fill before they use them.  12.8 KB with the ring: twelve wavefronts to a CU.
+    constexpr int kFrWords = kBuildFr * 64;          // 2 arrays x kBuildFr x 64 int16 = kFrWords 32-bit words
+    constexpr int kWinWords = kBuildWin / 4 + 2;
+    constexpr int kPoolWords = kFrWords + 2 * kWinWords > 2048 ? kFrWords + 2 * kWinWords : 2048;
+    __shared__ __attribute__((aligned(16))) uint32_t lds_pool[kPoolWords];
     __shared__ int32_t ring_i[64], ring_d[64], nm_lds[64];
-    __shared__ uint32_t lds_wa[kBuildWin / 4 + 2], lds_wb[kBuildWin / 4 + 2];
+    int16_t* const lds_fr0 = reinterpret_cast<int16_t*>(lds_pool);
+    int16_t* const lds_fr1 = lds_fr0 + kBuildFr * 64;
+    uint32_t* const lds_wa = lds_pool + kFrWords;
+    uint32_t* const lds_wb = lds_wa + kWinWords;
     const int lane = (int)(threadIdx.x & 63);
     for (;;) {
         uint32_t tk = atomicAdd(ticket, lane == 0 ? 1u : 0u);
@@ -318,7 +330,7 @@ __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __re
             // In front of the table: one bit per hashed seed key (round 5; csrc/gcsh.hpp does the same on the host).  Almost every position
             // of b matches no seed at all, and half of those still find their table slot occupied (two dependent loads from global
             // memory): 64 K bits in the LDS array phase D will use later stop seven of eight positions with one LDS read.
-            uint32_t* const sieve = (uint32_t*)&lds_fr[0][0];  // 2048 words of the 3968
+            uint32_t* const sieve = lds_pool;  // 2048 words
             for (int32_t t = lane; t < 2048; t += 64) sieve[t] = 0u;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             for (int32_t s = lane; s < jb.nseeds; s += 64) {
@@ -480,7 +492,7 @@ __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __re
                         const int mid = (ntodo - base < 64 ? ntodo - base : 64) / 2;
                         const int32_t nb0 = (__builtin_amdgcn_readlane(sj, 0) + jb.k - 16) & ~3;
                         cx.stage(lds_wa, lds_wb, (nb0 + __builtin_amdgcn_readlane(si, mid) - __builtin_amdgcn_readlane(sj, mid)) & ~3, nb0);
-                        if (t >= 0) flag[t] = prune_alone(cx, si, sj, &lds_fr[0][lane], &lds_fr[1][lane]) ? 1 : 0;
+                        if (t >= 0) flag[t] = prune_alone(cx, si, sj, lds_fr0 + lane, lds_fr1 + lane) ? 1 : 0;
                         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the windows are rewritten by the next round)
                     }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

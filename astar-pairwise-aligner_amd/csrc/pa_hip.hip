@@ -2019,9 +2019,10 @@ static bool astar_full_jobs(pa_batch* p, const uint8_t* const* a, const uint8_t*
     cmark("pair jobs + order");
     if (launch_build) {
         // The matches of GCSH are part of the batch like the sequences they are derived from: found here, once, by the GPU (one wavefront
-        // per pair, 16 KB of LDS each: eight to a CU), on the batch's stream -- the first alignment call queues behind it.
+        // per pair, 12.8 KB of LDS each: twelve to a CU), on the batch's stream -- the first alignment call queues behind it.
         const int cus = g_device_props_cus > 0 ? g_device_props_cus : 256;
-        const int grid = (int)std::min<size_t>(P, (size_t)cus * 8);
+        static const int per_cu = getenv("PA_BUILD_WAVES_PER_CU") ? std::max(1, atoi(getenv("PA_BUILD_WAVES_PER_CU"))) : 12;
+        const int grid = (int)std::min<size_t>(P, (size_t)cus * (size_t)per_cu);
         if (!hip_ok(hipMemsetAsync(p->d_bticket.ptr, 0, 64, p->stream), "memset") || !hip_ok(hipEventRecord(p->evB0, p->stream), "event")) return false;
         if (!hip_ok(apa2::launch_gcsh_build_kernel(grid, p->stream, p->d_bjobs.as<apa2::GcshBuildJob>(), (int)P, p->d_bticket.as<uint32_t>()), "gcsh_build_kernel launch") || !hip_ok(hipEventRecord(p->evB1, p->stream), "event")) return false;
     }

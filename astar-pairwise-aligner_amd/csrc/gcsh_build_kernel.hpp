@@ -15,7 +15,8 @@
 //     the reference's push order (rows descending when read backwards) with a ballot prefix;
 //  C. a counting sort by seed gives the by-start order (prune.rs wants the matches of a seed side by side);
 //  D. local pruning WITHOUT help from other matches, one lane per candidate: the furthest-reaching columns of the candidate's search
-//     sit in the lane's column of a 16 KB LDS array -- at 5 % divergence nine candidates in ten end here, kept;
+//     sit in the lane's column of an 8 KB LDS array (16-bit offsets from the candidate's start, round 6) -- at 5 % divergence nine
+//     candidates in ten end here, kept;
 //  E. the rest in the reference's order, one after the other, the search spread over the lanes (one diagonal each), with the
 //     reference's `next_match_per_diag` -- the latest kept match of a diagonal -- served from a ring of the last 64 kept matches in
 //     LDS (a kept match further back than that cannot be met: the search spans p seeds);

@@ -39,7 +39,12 @@ int choose_rows_per_lane(const size_t* a_len, const size_t* b_len, size_t pairs,
         if (atoi(e) == 0) return 0;
     }
     size_t live = 0;
-    for (size_t i = 0; i < pairs; ++i) live += a_len[i] > 0 && b_len[i] > 0;
+    for (size_t i = 0; i < pairs; ++i) {
+        live += a_len[i] > 0 && b_len[i] > 0;
+        // (the boundary rows are addressed through a buffer descriptor of n * 8 bytes, the columns through 32-bit counters: pairs beyond
+        //  2^27 columns stay with the strip kernels)
+        if (a_len[i] >= (size_t(1) << 27) || b_len[i] >= (size_t(1) << 27)) return 0;
+    }
     const bool forced = getenv("PA_SLICE") && atoi(getenv("PA_SLICE")) > 0;
     if (live < 64 && !forced) return 0;
     // groups of 32 in the order of the lengths; a group costs its longest a times the strips of its longest b

@@ -134,30 +134,43 @@ struct BuildCtx {
 // columns): half the LDS of 32-bit columns, and with it twelve instead of seven wavefronts to a CU (round 6) -- the kernel is bound by
 // what a wavefront waits for, not by what it issues.  kNeg16 = "no column yet"; a diagonal inside [d0, d1) always has one.
 constexpr int16_t kNeg16 = INT16_MIN;
-__device__ __forceinline__ bool prune_alone(const BuildCtx& cx, int32_t si, int32_t sj, int16_t* fa, int16_t* fb) {
-    const GcshBuildJob& jb = cx.jb;
-    const int32_t ei = si + jb.k, ej = sj + jb.k;
-    const int32_t start_pot = cx.P(si);
-    const int32_t seed_idx = cx.divk(si);
-    int32_t last_seed = seed_idx + jb.p - 1;
-    if (last_seed > jb.nseeds - 1) last_seed = jb.nseeds - 1;
-    const int32_t end_i = last_seed * jb.k + jb.k;
-    const int32_t pd = start_pot - cx.P(end_i);
-    int16_t* fr = fa;
-    int16_t* nx = fb;
+// The search as a RESUMABLE object, one per lane (round 6): begin() runs level 0, level() one further level.  Phase D keeps every lane
+// busy -- a lane whose search has ended takes the next candidate at once instead of idling until the deepest search of its round of 64 is
+// through (the lanes used 45 % of the levels their rounds lasted: PA_BUILD_CLOCKS).  The decisions are those of the loop they replace.
+struct AloneSearch {
+    int32_t si, ei, ej, start_pot, end_i, pd, d0, d1, g;
+    int16_t* fr;
+    int16_t* nx;
 #define FR(d) fr[((d) + 1) * 64]
 #define NX(d) nx[((d) + 1) * 64]
-    for (int32_t d = -1; d <= 2 * pd + 1; ++d) {
-        FR(d) = kNeg16;
-        NX(d) = kNeg16;
-    }
-    int32_t d0 = pd, d1 = pd + 1;
-    {
+    // +1: kept at once, -1: dropped at once (no level to run), 0: level() has to go on
+    __device__ __forceinline__ int begin(const BuildCtx& cx, int32_t si_, int32_t sj, int16_t* fa, int16_t* fb) {
+        const GcshBuildJob& jb = cx.jb;
+        si = si_;
+        ei = si + jb.k;
+        ej = sj + jb.k;
+        start_pot = cx.P(si);
+        const int32_t seed_idx = cx.divk(si);
+        int32_t last_seed = seed_idx + jb.p - 1;
+        if (last_seed > jb.nseeds - 1) last_seed = jb.nseeds - 1;
+        end_i = last_seed * jb.k + jb.k;
+        pd = start_pot - cx.P(end_i);
+        fr = fa;
+        nx = fb;
+        for (int32_t d = -1; d <= 2 * pd + 1; ++d) {
+            FR(d) = kNeg16;
+            NX(d) = kNeg16;
+        }
+        d0 = pd;
+        d1 = pd + 1;
         int32_t i = ei;
-        if (cx.extend(i, ej, end_i)) return true;
+        if (cx.extend(i, ej, end_i)) return 1;
         FR(pd) = (int16_t)(i - si);
+        g = 1;
+        return g < pd ? 0 : -1;
     }
-    for (int32_t g = 1; g < pd; ++g) {
+    // level g (prepruning.rs:137-200): +1 kept, -1 dropped, 0 another level follows
+    __device__ __forceinline__ int level(const BuildCtx& cx) {
         FR(d0 - 1) = kNeg16;
         FR(d1) = kNeg16;
         NX(d0 - 1) = kNeg16;
@@ -175,18 +188,19 @@ __device__ __forceinline__ bool prune_alone(const BuildCtx& cx, int32_t si, int3
         d1 += 1;
         while (d0 < d1 && g + cx.P(si + FR(d0)) >= start_pot) d0 += 1;
         while (d0 < d1 && g + cx.P(si + FR(d1 - 1)) >= start_pot) d1 -= 1;
-        if (d0 >= d1) return false;
+        if (d0 >= d1) return -1;
         for (int32_t d = d0; d < d1; ++d) {
             int32_t i = si + FR(d);
             const int32_t dd = ei - ej + (d - pd);
-            if (cx.extend(i, i - dd, end_i)) return true;
+            if (cx.extend(i, i - dd, end_i)) return 1;
             FR(d) = (int16_t)(i - si);
         }
+        g += 1;
+        return g < pd ? 0 : -1;
     }
 #undef FR
 #undef NX
-    return false;
-}
+};
 
 // The same search with the matches kept so far, spread over the wavefront: lane l owns diagonal l (0 .. 2 pd) of the search.
 // ring_i / ring_d: the last kept matches (start column, diagonal), `nring` of them valid.  The reference's next_match_per_diag[dd] is
@@ -480,21 +494,56 @@ __global__ __launch_bounds__(64) void gcsh_build_kernel(const GcshBuildJob* __re
                         ntodo += __builtin_popcountll(need);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                    // ---- D. local pruning alone, one lane per candidate that has no successor ----
-                    for (int32_t base = 0; base < ntodo; base += 64) {
-                        const int32_t q = base + lane;
-                        const int32_t t = q < ntodo ? todo[q] : -1;
-                        int32_t si = 0, sj = 0;
-                        if (t >= 0) {
-                            si = tmp_s[t] * jb.k;
-                            sj = tmp_j[t];
+                    // ---- D. local pruning alone, one lane per candidate that has no successor; a lane that is through takes the next one ----
+                    {
+                        AloneSearch S{};
+                        bool active = false;
+                        int32_t t = -1, next = 0, staged = -64;  // next: first candidate of `todo` not handed out yet; staged: `next` at the last staging
+                        uint64_t lv_sum = 0, lv_rounds = 0;
+                        for (;;) {
+                            for (;;) {  // hand out candidates while there are idle lanes and candidates
+                                const uint64_t idle = __ballot(!active);
+                                const int32_t remaining = ntodo - next;
+                                if (idle == 0 || remaining <= 0) break;
+                                const int32_t nidle = __builtin_popcountll(idle), give = nidle < remaining ? nidle : remaining;
+                                if (next - staged >= 32) {
+                                    // the windows follow the candidates (rows ascend along `todo`): b from the row of the oldest search still
+                                    // running or the first new candidate, a along the new candidates' middle diagonal; a search that leaves
+                                    // them reads global memory
+                                    const int32_t tf = todo[next], tm = todo[next + give / 2];
+                                    int32_t lowj = active ? S.ej - jb.k : tmp_j[tf];
+                                    for (int o = 32; o > 0; o >>= 1) lowj = min(lowj, __shfl_xor(lowj, o));
+                                    const int32_t firstj = tmp_j[tf];
+                                    if (lowj < firstj - kBuildWin / 2) lowj = firstj - kBuildWin / 2;  // (a straggler far behind does not hold the window back)
+                                    const int32_t nb0 = (lowj + jb.k - 16) & ~3;
+                                    cx.stage(lds_wa, lds_wb, (nb0 + tmp_s[tm] * jb.k - tmp_j[tm]) & ~3, nb0);
+                                    staged = next;
+                                }
+                                const int32_t rank = __builtin_popcountll(idle & ((1ull << lane) - 1ull));
+                                if (!active && rank < give) {
+                                    t = todo[next + rank];
+                                    const int r = S.begin(cx, tmp_s[t] * jb.k, tmp_j[t], lds_fr0 + lane, lds_fr1 + lane);
+                                    if (r != 0) flag[t] = r > 0 ? 1 : 0;
+                                    else active = true;
+                                }
+                                next += give;
+                            }
+                            const uint64_t running = __ballot(active);
+                            if (running == 0) break;
+                            if (active) {
+                                const int r = S.level(cx);
+                                if (r != 0) {
+                                    flag[t] = r > 0 ? 1 : 0;
+                                    active = false;
+                                }
+                            }
+                            lv_sum += (uint64_t)__builtin_popcountll(running);
+                            lv_rounds += 64;
                         }
-                        // rows ascend with the lane: b from the first candidate's end, a along the diagonal of the middle candidate
-                        const int mid = (ntodo - base < 64 ? ntodo - base : 64) / 2;
-                        const int32_t nb0 = (__builtin_amdgcn_readlane(sj, 0) + jb.k - 16) & ~3;
-                        cx.stage(lds_wa, lds_wb, (nb0 + __builtin_amdgcn_readlane(si, mid) - __builtin_amdgcn_readlane(sj, mid)) & ~3, nb0);
-                        if (t >= 0) flag[t] = prune_alone(cx, si, sj, lds_fr0 + lane, lds_fr1 + lane) ? 1 : 0;
-                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the windows are rewritten by the next round)
+                        if (jb.clocks && lane == 0) {  // diagnostics: search levels run, and lane slots the loop's iterations offered
+                            atomicAdd(jb.clocks + 9, (unsigned long long)lv_sum);
+                            atomicAdd(jb.clocks + 10, (unsigned long long)lv_rounds);
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     lap(3);

@@ -3185,8 +3185,8 @@ extern "C" long pa_debug_gcsh_matches(const uint8_t* a, size_t a_len, const uint
     if (clocks) {
         unsigned long long c[16] = {0};
         (void)hipMemcpy(c, d_clk.ptr, 128, hipMemcpyDeviceToHost);
-        std::fprintf(stderr, "[gcsh build] n %zu m %zu k %d p %d: A %.3f  B %.3f  C %.3f  D %.3f  E %.3f  F %.3f ms; %llu candidates, %llu kept alone, %llu searches in E; status %d\n", a_len, b_len,
-                     k, p_local, c[0] * 1e-5, c[1] * 1e-5, c[2] * 1e-5, c[3] * 1e-5, c[4] * 1e-5, c[5] * 1e-5, c[6], c[7], c[8], res[1]);
+        std::fprintf(stderr, "[gcsh build] n %zu m %zu k %d p %d: A %.3f  B %.3f  C %.3f  D %.3f  E %.3f  F %.3f ms; %llu candidates, %llu kept alone, %llu searches in E; D: %llu search levels of %llu that its rounds last (deepest lane x lanes); status %d\n", a_len, b_len,
+                     k, p_local, c[0] * 1e-5, c[1] * 1e-5, c[2] * 1e-5, c[3] * 1e-5, c[4] * 1e-5, c[5] * 1e-5, c[6], c[7], c[8], c[9], c[10], res[1]);
     }
     if (res[1] != 0) return -(100 + (long)res[1]);
     const size_t cnt = (size_t)std::max(res[0], 0), take = std::min(cnt, cap_out);

@@ -72,6 +72,20 @@ struct BuildCtx {
         __builtin_memcpy(&x, (const uint8_t*)g + pos, 4);
         return x;
     }
+    // eight bytes at `pos`: three aligned LDS words and two byte funnel shifts (the price of four bytes through a 64-bit shift)
+    __device__ __forceinline__ void ld8(const uint32_t* w, int32_t w0, const PA_GLOBAL uint8_t* g, int32_t pos, uint32_t& lo, uint32_t& hi) const {
+        const int32_t off = pos - w0;
+        if (off >= 0 && off + 8 <= kBuildWin) {
+            const uint32_t x0 = w[off >> 2], x1 = w[(off >> 2) + 1], x2 = w[(off >> 2) + 2];
+            lo = __builtin_amdgcn_alignbyte(x1, x0, (uint32_t)(off & 3));
+            hi = __builtin_amdgcn_alignbyte(x2, x1, (uint32_t)(off & 3));
+            return;
+        }
+        uint64_t x;
+        __builtin_memcpy(&x, (const uint8_t*)g + pos, 8);
+        lo = (uint32_t)x;
+        hi = (uint32_t)(x >> 32);
+    }
     // stage a[a0 .. a0 + kBuildWin) and b[b0 ..) (clipped to the sequences; what lies beyond is never compared)
     __device__ __forceinline__ void stage(uint32_t* la, uint32_t* lb, int32_t na0, int32_t nb0) {
         const PA_GLOBAL uint8_t* a = (const PA_GLOBAL uint8_t*)jb.a;
@@ -108,7 +122,18 @@ struct BuildCtx {
         const PA_GLOBAL uint8_t* a = (const PA_GLOBAL uint8_t*)jb.a;
         const PA_GLOBAL uint8_t* b = (const PA_GLOBAL uint8_t*)jb.b;
         while (i < end_i && i < jb.n && j < jb.m) {
-            if (i + 4 <= jb.n && j + 4 <= jb.m) {
+            if (i + 8 <= jb.n && j + 8 <= jb.m) {  // eight characters per round (round 6: half the rounds of a typical run of matches)
+                uint32_t xl, xh, yl, yh;
+                ld8(wa, a0, a, i, xl, xh);
+                ld8(wb, b0, b, j, yl, yh);
+                const uint32_t dl = xl ^ yl, dh = xh ^ yh;
+                if (dl | dh) {
+                    i += dl ? (__builtin_ctz(dl) >> 3) : 4 + (__builtin_ctz(dh) >> 3);
+                    return i >= end_i;
+                }
+                i += 8;
+                j += 8;
+            } else if (i + 4 <= jb.n && j + 4 <= jb.m) {
                 const uint32_t x = ld4(wa, a0, a, i), y = ld4(wb, b0, b, j);
                 const uint32_t d = x ^ y;
                 if (d) {

@@ -790,9 +790,11 @@ struct RectArgs {
     uint32_t* counter;      // device: [0] strips finished so far, [1] the strip ticket; both left at zero
     int32_t n, col0, w0, w1, exact_end;
     uint32_t seq;
+    uint32_t* values;       // FILL: V of every column, values[col][fill_stride] (host-mapped: the traceback's re-fill reads it on the host)
+    int32_t fill_stride;
 };
 
-template <int K>
+template <int K, bool FILL = false>
 __global__ __launch_bounds__(64) void rect_kernel(RectArgs r) {
     const int S = (int)gridDim.x;
     const int lane = (int)(threadIdx.x & 63);
@@ -808,14 +810,14 @@ __global__ __launch_bounds__(64) void rect_kernel(RectArgs r) {
     j.hin_arr = s == 0 ? r.hin_arr : nullptr;
     j.hout_gran = s + 1 < S ? r.gran + (size_t)s * r.gran_stride : nullptr;
     j.hout_arr = s + 1 < S ? nullptr : r.hout_arr;
-    j.values = nullptr;
+    j.values = FILL ? r.values : nullptr;
     j.sum_out = s + 1 < S ? nullptr : r.sum_out;
     j.n = r.n;
     j.word0 = r.w0 + s * wps;
     const int words = (r.w1 - j.word0) < wps ? (r.w1 - j.word0) : wps;
     j.nlanes = 2 * words;
-    j.fill_stride = 0;
-    j.fill_word0 = 0;
+    j.fill_stride = FILL ? r.fill_stride : 0;
+    j.fill_word0 = FILL ? j.word0 - r.w0 : 0;
     j.exact_tail = s + 1 < S ? 1 : ((r.exact_end || r.hout_arr) ? 1 : 0);
     j.flags = 0;
     j.col0 = r.col0;
@@ -825,8 +827,8 @@ __global__ __launch_bounds__(64) void rect_kernel(RectArgs r) {
     j.ckpt_stride = 0;
     j.hin_n = 0;
     j.vsum_out = nullptr;
-    if (K == 1 && j.nlanes <= 32) run_strip<1, false, false, false, false, false, true>(j, r.err);  // half-wave: one chunk less
-    else run_strip<K, false, false>(j, r.err);
+    if (K == 1 && j.nlanes <= 32) run_strip<1, FILL, false, false, false, false, true>(j, r.err);  // half-wave: one chunk less
+    else run_strip<K, FILL, false>(j, r.err);
     // completion: results first (system scope: v and the sum are in host memory), then the count, then the flag
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     uint32_t c = 0;

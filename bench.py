@@ -902,7 +902,9 @@ def main():
             # a leg that was repeated fires only beyond its own run-to-run spread (host-bound legs: 10-30 %); the others beyond 5 %
             # (the end-to-end rates of the batched legs include the host's creation of 10 000 Python strings: 5-8 % from run to run)
             host_bound = path.startswith(("c4_astarpa2_", "c3_batch_", "c4_batch_align.pairs", "pcie_inclusive"))
-            limit = max(0.10 if host_bound else 0.05, 1.25 * noise.get(path, 0.0))
+            if path == "c5.seconds":
+                host_bound = True  # (twelve pipelined passes of one pair, a single run: 1.5-1.8 s from run to run, profiles/README.md)
+            limit = max((0.15 if path == "c5.seconds" else 0.10) if host_bound else 0.05, 1.25 * noise.get(path, 0.0))
             if worse > limit:
                 regs.append({"leg": path, "reference": was, "now": now, "worse_by_pct": round(100 * worse, 1), "limit_pct": round(100 * limit, 1)})
         out["regressions"] = regs

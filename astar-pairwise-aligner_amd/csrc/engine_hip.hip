@@ -822,6 +822,42 @@ struct HipSweepLauncher {
         SweepSlot& sl = slot_of(seq);
         const size_t recs = (size_t)nblk + 1;
         if (!pool.d_recs.reserve(recs * sizeof(BlockOut)) || !pool.d_offs.reserve(recs * 8)) hip_fail("hipMalloc");
+        // One synchronisation (round 6): a block's column holds at most col_stride words, so the packed columns fit a pinned buffer of
+        // nblk * col_stride words that the gather kernel writes directly; the records come with them.  (Beyond 16 MB -- Mbp pairs --
+        // the two-step route below, which sizes the buffer by what the records say.)
+        static const bool two_step = std::getenv("PA_SWEEP_READ_TWO_STEP") != nullptr;
+        const size_t bound_words = (size_t)nblk * (size_t)sl.geo.col_stride;
+        if (!two_step && bound_words * 16 <= (size_t(16) << 20)) {
+            const size_t off_cols = (recs * sizeof(BlockOut) + 63) & ~size_t(63);
+            uint8_t* hb = static_cast<uint8_t*>(pool.pinned(off_cols + bound_words * 16 + 64));
+            if (!hb) hip_fail("pinned");
+            BlockOut* hrp = reinterpret_cast<BlockOut*>(hb);
+            uint64_t* hp = reinterpret_cast<uint64_t*>(hb + off_cols);
+            hipLaunchKernelGGL(sweep_records_offsets_kernel, dim3(1), dim3(1024), 0, be.s, sl.d_brec.as<BRec>(), pool.d_recs.as<BlockOut>(), hrp,
+                               pool.d_offs.as<int64_t>(), nblk);
+            hipLaunchKernelGGL(sweep_gather_kernel, dim3((unsigned)nblk), dim3(256), 0, be.s, sl.d_col.as<uint64_t>(), sl.geo.col_stride, sl.geo.win,
+                               pool.d_recs.as<BlockOut>(), pool.d_offs.as<int64_t>(), hp, nblk);
+            if (!hip_ok(hipGetLastError(), "sweep gather launch") || !hip_ok(hipStreamSynchronize(be.s), "sync")) hip_fail("columns");
+            int64_t at = 0;
+            for (int32_t k = 1; k <= nblk; ++k) {
+                engine::Block& bl = blocks[(size_t)k];
+                const BlockOut o = hrp[(size_t)k];
+                bl.i_range = engine::IRange{(k - 1) * kBlockW, k * kBlockW < n ? k * kBlockW : n};
+                bl.original_j_range = engine::JRange{o.ojs, o.oje};
+                bl.j_range = engine::JRange{o.js, o.je};
+                bl.fixed_j_range = engine::JRange{o.fs, o.fe};
+                bl.offset = o.js;
+                bl.top_val = o.top_val;
+                bl.bot_val = o.bot_val;
+                bl.j_h.reset();
+                const size_t w = (size_t)(o.je - o.js) / 64;
+                if ((size_t)at + w > bound_words) hip_fail("sweep columns beyond their bound");
+                bl.v.resize(w);
+                std::memcpy(bl.v.data(), hp + at * 2, w * 16);
+                at += (int64_t)w;
+            }
+            return;
+        }
         hipLaunchKernelGGL(sweep_records_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, be.s, sl.d_brec.as<BRec>(),
                            pool.d_recs.as<BlockOut>(), nblk);
         std::vector<BlockOut> hr(recs);

@@ -357,6 +357,48 @@ __global__ void sweep_records_kernel(const BRec* brec, BlockOut* out, int32_t nb
     o.bot_val = tw_val(s.bot_val);
     out[k] = o;
 }
+// The same records AND where every block's column goes in the packed buffer (an exclusive prefix over the blocks' heights), in one
+// launch of one workgroup: the host does not have to see the records before the columns can be gathered (round 6: one stream
+// synchronisation per traceback instead of two).  `out_host`: the host's pinned copy of the records.
+__global__ __launch_bounds__(1024) void sweep_records_offsets_kernel(const BRec* brec, BlockOut* out, BlockOut* out_host, int64_t* offs, int32_t nblk) {
+    __shared__ int64_t sh[1024];
+    __shared__ int64_t carry_s;
+    const int t = (int)threadIdx.x;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (int32_t base = 1; base <= nblk; base += 1024) {
+        const int32_t k = base + t;
+        int64_t len = 0;
+        if (k <= nblk) {
+            const BRec& s = brec[k];
+            BlockOut o;
+            o.js = tw_val(s.js);
+            o.je = tw_val(s.je);
+            o.ojs = tw_val(s.ojs);
+            o.oje = tw_val(s.oje);
+            o.fs = tw_val(s.fs);
+            o.fe = tw_val(s.fe);
+            o.top_val = tw_val(s.top_val);
+            o.bot_val = tw_val(s.bot_val);
+            out[k] = o;
+            out_host[k] = o;
+            len = (o.je - o.js) / 64;
+        }
+        sh[t] = len;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {  // inclusive scan over the 1024 blocks of this round
+            const int64_t v = t >= d ? sh[t - d] : 0;
+            __syncthreads();
+            sh[t] += v;
+            __syncthreads();
+        }
+        const int64_t carry = carry_s;
+        if (k <= nblk) offs[k] = carry + sh[t] - len;
+        __syncthreads();
+        if (t == 1023) carry_s = carry + sh[1023];
+        __syncthreads();
+    }
+}
 __global__ void sweep_gather_kernel(const uint64_t* col, int64_t col_stride, int32_t win, const BlockOut* recs, const int64_t* offs,
                                     uint64_t* out, int32_t nblk) {
     const int32_t k = 1 + (int32_t)blockIdx.x;

@@ -799,6 +799,11 @@ struct HipSweepLauncher {
         return st;
     }
 
+    // (short pairs: the speculative passes' wavefronts are few and the traceback's kernels small; on C3 waiting first measured better)
+    bool cancel_without_waiting() const {
+        static const bool off = std::getenv("PA_SWEEP_CANCEL_WAIT") != nullptr;
+        return !off && nblk <= kShortPairBlocks;
+    }
     // Give up every launched pass behind `seq` and wait until they (and their merges) are gone.
     void cancel_after(int seq, bool wait = true) {
         bool any = false;

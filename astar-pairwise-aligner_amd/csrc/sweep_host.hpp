@@ -77,6 +77,7 @@ struct PassInit {
 //                                             runs, its merged records afterwards (prev_seq 0: no earlier pass)
 //   wait_pass(seq) -> Status                  block until pass seq is over and merged (passes are waited for in order)
 //   cancel_after(seq, wait = true)            give up every launched pass > seq and (wait) block until they are gone
+//   cancel_without_waiting()                  policy: after the successful pass, start the traceback before the passes behind it are gone
 //   read_merged(seq, k) -> BlockRec           block k's record after pass seq was merged (waited)
 //   read_blocks(seq, blocks)                  the blocks of pass seq for Blocks::trace
 //   pass_waves(f_max), wave_budget()          wavefronts a pass occupies / may be in flight together
@@ -328,7 +329,13 @@ class SweepAligner {
                     st = dev.wait_pass(cur.p.seq);
                     // found: the passes behind it are not needed.  (Waiting for them here costs less than letting them run into the
                     // traceback's kernels: 14.4 against 14.9 ms on C3.)
-                    if (st.state == kStDone && st.value <= cur.p.f_max) give_up();
+                    // Short pairs (round 6): the cancel words go out, the traceback does not wait for the passes to see them -- three
+                    // speculative passes of a 10 kbp pair took 30-90 us to wind down plus their merges, a tenth of the call, and their
+                    // handful of wavefronts does not hurt the traceback's two small kernels; give_up() below waits when they are long gone.
+                    if (st.state == kStDone && st.value <= cur.p.f_max) {
+                        if (dev.cancel_without_waiting() && head < fl.size()) dev.cancel_after(fl[head].p.seq - 1, false);
+                        else give_up();
+                    }
                     r = complete(cur.p, st);
                 } catch (...) {
                     give_up();

@@ -64,6 +64,12 @@ struct HostLauncher {
     ~HostLauncher() { cancel_after(0); }
     Slot& slot_of(int seq) { return slots[seq % kSlots]; }
     int max_in_flight() const { return in_flight; }
+    // (the product's policy for short pairs; PA_SWEEP_EMU_CANCEL_NOWAIT=1 runs the emulation that way, so that the hosts's bookkeeping of
+    //  passes that are cancelled but not yet waited for is exercised under the thread sanitizer too)
+    bool cancel_without_waiting() const {
+        static const bool on = std::getenv("PA_SWEEP_EMU_CANCEL_NOWAIT") != nullptr;
+        return on;
+    }
     int pass_waves(int32_t) const { return 1; }
     int wave_budget() const { return 1 << 20; }
 

@@ -69,15 +69,29 @@ struct HipBackend {
         if (!d_a.reserve(n) || !d_b.reserve(m) || !d_codes.reserve(cw * 4) || !d_prof.reserve(w_total * 16 + 16) ||
             !d_misc.reserve(16) || !d_htmp.reserve(n + 64)) { err = PA_E_HIP; return; }
         if (!s && !hip_ok(hipStreamCreate(&s), "hipStreamCreate")) { err = PA_E_HIP; return; }
-        bool good = hip_ok(hipMemsetAsync(d_codes.ptr, 0, cw * 4, s), "memset") &&
-                    hip_ok(hipMemsetAsync(d_misc.ptr, 0, 16, s), "memset") &&
-                    (n == 0 || hip_ok(hipMemcpyAsync(d_a.ptr, a, n, hipMemcpyHostToDevice, s), "H2D a")) &&
-                    (m == 0 || hip_ok(hipMemcpyAsync(d_b.ptr, b, m, hipMemcpyHostToDevice, s), "H2D b")) &&
-                    encode_a_device(d_a.as<uint8_t>(), (int)n, d_codes.as<uint32_t>(), d_misc.as<uint32_t>() + 3, s) &&
-                    build_b_device(d_b.as<uint8_t>(), (int)m, d_prof.as<uint64_t>(), d_misc.as<uint32_t>() + 3, s);
+        // The per-call set-up in four stream operations (round 6; there were eight, two of them copies from pageable memory): the sequences go
+        // through the pinned staging buffer, ONE kernel packs a (zero padding included) and builds b's profile, the "character outside ACGT"
+        // flag is a word of the host-mapped mailbox.
         uint32_t misc[4] = {0, 0, 0, 0};
-        good = good && hip_ok(hipMemcpyAsync(misc, d_misc.ptr, 16, hipMemcpyDeviceToHost, s), "D2H") &&
-               hip_ok(hipStreamSynchronize(s), "sync");
+        bool good = true;
+        try {
+            ensure_mailbox(0);
+            uint8_t* st = static_cast<uint8_t*>(stage(n + m + 64));
+            const size_t off_b = (n + 63) & ~size_t(63);
+            if (n) std::memcpy(st, a, n);
+            if (m) std::memcpy(st + off_b, b, m);
+            volatile uint32_t* mb = reinterpret_cast<volatile uint32_t*>(mbox);
+            mb[3] = 0;
+            __atomic_thread_fence(__ATOMIC_SEQ_CST);
+            good = (n == 0 || hip_ok(hipMemcpyAsync(d_a.ptr, st, n, hipMemcpyHostToDevice, s), "H2D a")) &&
+                   (m == 0 || hip_ok(hipMemcpyAsync(d_b.ptr, st + off_b, m, hipMemcpyHostToDevice, s), "H2D b")) &&
+                   encode_pair_device(d_a.as<uint8_t>(), (int)n, d_codes.as<uint32_t>(), (int)cw, d_b.as<uint8_t>(), (int)m, d_prof.as<uint64_t>(),
+                                      reinterpret_cast<uint32_t*>(mbox_dev) + 3, s) &&
+                   hip_ok(hipStreamSynchronize(s), "sync");
+            misc[3] = mb[3];
+        } catch (const engine::EnginePanic&) {
+            good = false;
+        }
         if (!good) { err = PA_E_HIP; return; }
         if (misc[3]) {
             set_error("sequence contains a base outside ACGT");

@@ -546,6 +546,56 @@ void DeviceBuf::release() {
     size = 0;
 }
 
+// Both encodings of ONE pair in one launch (the single-pair engine's per-call set-up, round 6: eight stream operations were four): the
+// first blocks pack a -- every word of `codes` up to code_words, so the padding the kernels read past the last column is zeroed here --,
+// the others build b's profile.  `bad` may be host-mapped: every writer stores the same 1.
+__global__ void encode_pair_kernel(const uint8_t* __restrict__ a, int n, uint32_t* __restrict__ codes, int code_words, int a_blocks,
+                                   const uint8_t* __restrict__ b, int m, uint64_t* __restrict__ prof, int prof_words, uint32_t* bad) {
+    if ((int)blockIdx.x < a_blocks) {
+        const int i = blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= code_words) return;
+        uint32_t w = 0;
+        bool invalid = false;
+        for (int k = 0; k < 16; ++k) {
+            const int c = i * 16 + k;
+            if (c < n) {
+                const int r = rank_acgt(a[c]);
+                invalid |= r < 0;
+                w |= (uint32_t)(r & 3) << (2 * k);
+            }
+        }
+        codes[i] = w;
+        if (invalid) __hip_atomic_store(bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    const int word = ((int)blockIdx.x - a_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (word >= prof_words) return;
+    const int lane = threadIdx.x & 63;
+    const int j = word * 64 + lane;
+    int r = 3;
+    bool invalid = false;
+    if (j < m) {
+        r = rank_acgt(b[j]);
+        invalid = r < 0;
+        r &= 3;
+    }
+    const uint64_t nb0 = __ballot(((r & 1) ^ 1) != 0);
+    const uint64_t nb1 = __ballot((((r >> 1) & 1) ^ 1) != 0);
+    if (lane == 0) {
+        prof[2 * word] = nb0;
+        prof[2 * word + 1] = nb1;
+    }
+    if (invalid) __hip_atomic_store(bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+bool encode_pair_device(const uint8_t* d_a, int n, uint32_t* d_codes, int code_words, const uint8_t* d_b, int m, uint64_t* d_prof, uint32_t* bad,
+                        hipStream_t s) {
+    const int a_blocks = (code_words + 255) / 256, prof_words = (m + 63) / 64, b_blocks = (prof_words + 3) / 4;
+    if (a_blocks + b_blocks == 0) return true;
+    hipLaunchKernelGGL(encode_pair_kernel, dim3((unsigned)(a_blocks + b_blocks)), dim3(256), 0, s, d_a, n, d_codes, code_words, a_blocks, d_b, m, d_prof,
+                       prof_words, bad);
+    return hip_ok(hipGetLastError(), "encode_pair_kernel");
+}
+
 bool encode_a_device(const uint8_t* d_a, int n, uint32_t* d_codes, uint32_t* d_bad, hipStream_t s) {
     const int nwords = (n + 15) / 16;
     if (nwords == 0) return true;

@@ -79,5 +79,8 @@ int align_hip(const uint8_t* a, size_t a_len, const uint8_t* b, size_t b_len, co
               int32_t* cost_out, std::string* cigar_out, pa_astarpa2_stats* stats_out);
 bool encode_a_device(const uint8_t* d_a, int n, uint32_t* d_codes, uint32_t* d_bad, hipStream_t s);
 bool build_b_device(const uint8_t* d_b, int m, uint64_t* d_prof, uint32_t* d_bad, hipStream_t s);
+// both in one launch; all `code_words` words of d_codes are written (zero beyond the sequence); `bad` may be host-mapped memory
+bool encode_pair_device(const uint8_t* d_a, int n, uint32_t* d_codes, int code_words, const uint8_t* d_b, int m, uint64_t* d_prof, uint32_t* bad,
+                        hipStream_t s);
 
 }  // namespace pa
